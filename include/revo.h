@@ -1,0 +1,116 @@
+/* librevo -- C ABI of the MI355X-native embed + search hot path of revers-o.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no
+ * torch types.  Each entry point names the reference interface it replaces
+ * (file:line relative to the reference tree).  The reference itself has no FFI:
+ * its hot path is two Python calls into third-party packages, so the entry points
+ * below are what a ctypes binding in core_system.py would call instead of
+ *   self.pe_model.encode_image(...)          core_system.py:341, :442
+ *   self.vector_db.search(...)               core_system.py:659-664
+ *   client.recreate_collection / upsert      core_system.py:600-603, :621
+ * (binding stub: INTEGRATION.md).
+ *
+ * Conventions: every function returns 0 on success and a negative status on
+ * failure; the message is available from revo_last_error() (thread-local).
+ * Nothing throws across the boundary.  `stream` is a hipStream_t (NULL = the
+ * default stream); work is enqueued asynchronously on it and the caller owns
+ * ordering (revo_sync).  A handle is bound to one device and must not be used
+ * from two threads at once; distinct handles are independent.  All device
+ * pointers must belong to the handle's device.
+ */
+#ifndef REVO_H
+#define REVO_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct revo_vit revo_vit;
+typedef struct revo_gallery revo_gallery;
+
+/* Dimensions of a Perception-Encoder vision tower (the values the reference gets
+ * implicitly from pe.CLIP.from_config("PE-Core-L14-336"), core_system.py:177-181). */
+typedef struct revo_vit_cfg {
+    int32_t image_size, patch_size, width, layers, heads, mlp_dim, out_dim, pool_heads;
+    int32_t use_cls;    /* class token + (0,0) rope position */
+    int32_t use_ls;     /* LayerScale tensors (ls_1.gamma / ls_2.gamma) present */
+    float ln_eps, rope_theta;
+} revo_vit_cfg;
+
+/* One checkpoint tensor: upstream name ("visual.conv1.weight", ...), fp32 values
+ * in host or device memory. */
+typedef struct revo_tensor {
+    const char* name;
+    const float* data;
+    int64_t numel;
+} revo_tensor;
+
+const char* revo_last_error(void);
+int32_t revo_version(void);
+int32_t revo_sync(void* stream);
+
+/* ---- embed: replaces load_pe_model + encode_image (core_system.py:169-203, :341, :442) */
+int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* weights, int32_t n_weights, int32_t device,
+                        int32_t max_batch, revo_vit** out);
+int32_t revo_vit_destroy(revo_vit* vit);
+/* images: NCHW at the model resolution on the device; image_dtype 0 = fp32 already
+ * normalised to [-1,1] (what self.preprocess yields, core_system.py:439), 1 = uint8
+ * (normalised (v/255-0.5)/0.5 inside the patchify kernel).  out: [B, out_dim] fp32 on
+ * the device; normalize != 0 applies embedding / embedding.norm() (core_system.py:447). */
+int32_t revo_vit_forward(revo_vit* vit, const void* images, int32_t image_dtype, int32_t batch, float* out,
+                         int32_t normalize, void* stream);
+/* parity-test hooks: run only the first n transformer blocks (n < 0: all) and copy the
+ * fp32 residual stream [batch*seq, width] of the last forward to dst (device). */
+int32_t revo_vit_set_debug_layers(revo_vit* vit, int32_t n_layers);
+int32_t revo_vit_read_residual(revo_vit* vit, int32_t batch, float* dst, void* stream);
+int32_t revo_vit_seq_len(const revo_vit* vit);
+
+/* ---- gallery: replaces recreate_collection(size=D, COSINE) + upsert (core_system.py:600-622) */
+int32_t revo_gallery_create(int32_t dim, int64_t capacity, int32_t device, int32_t keep_f32, revo_gallery** out);
+int32_t revo_gallery_destroy(revo_gallery* g);
+/* vecs: [n, dim] fp32, host (src_on_device = 0) or device memory.  normalize != 0
+ * L2-normalises each row at insert, as qdrant does for Distance.COSINE. */
+int32_t revo_gallery_append(revo_gallery* g, const float* vecs, int64_t n, int32_t normalize, int32_t src_on_device,
+                            void* stream);
+int64_t revo_gallery_size(const revo_gallery* g);
+int32_t revo_gallery_clear(revo_gallery* g);
+/* copy rows [start, start+n) of the fp32 master copy to dst (host or device); needs keep_f32 */
+int32_t revo_gallery_read(revo_gallery* g, int64_t start, int64_t n, float* dst, int32_t dst_on_device);
+
+/* ---- search: replaces vector_db.search(query_vector, limit, score_threshold) (core_system.py:659-664)
+ * queries: [n_queries, dim] fp32 on the device (normalised internally, cosine semantics).
+ * Results, best first under (score desc, index asc): scores [n_queries, k] fp32, indices
+ * [n_queries, k] int64 (row index + index_offset), counts [n_queries] int32; entries past
+ * counts[q] are -inf / -1.  has_threshold != 0 keeps only score >= threshold. */
+int32_t revo_search_topk(revo_gallery* g, const float* queries, int32_t n_queries, int32_t k, int32_t has_threshold,
+                         float threshold, int64_t index_offset, float* scores, int64_t* indices, int32_t* counts,
+                         void* stream);
+/* merge `parts` result sets laid out [parts, n_queries, k] (the all-gathered per-shard
+ * results of a row-sharded gallery) into one [n_queries, k] set, same ordering rule. */
+int32_t revo_topk_merge(const float* scores, const int64_t* indices, int32_t parts, int32_t n_queries, int32_t k,
+                        int32_t has_threshold, float threshold, float* out_scores, int64_t* out_indices,
+                        int32_t* out_counts, void* stream);
+
+/* ---- single kernels, exposed for parity tests and micro-benchmarks (device pointers) */
+int32_t revo_op_gemm(int32_t epilogue, const void* a_bf16, int64_t lda, const void* b_bf16, int64_t ldb, int32_t m,
+                     int32_t n, int32_t k, void* c, int64_t ldc, const float* bias, const float* gamma, void* stream);
+int32_t revo_op_layernorm(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows,
+                          int32_t width, void* out, int64_t ldo, int32_t out_is_bf16, void* stream);
+int32_t revo_op_rope(void* qkv_bf16, int64_t ld, const float* cos_sin, int32_t rows, int32_t seq, int32_t width,
+                     int32_t heads, void* stream);
+int32_t revo_op_attention(const void* qkv_bf16, int64_t ld, void* out_bf16, int64_t ldo, int32_t batch, int32_t seq,
+                          int32_t heads, int32_t head_dim, void* stream);
+int32_t revo_op_f32_to_bf16(const float* src, int64_t ld_src, void* dst_bf16, int64_t ld_dst, int64_t rows,
+                            int32_t cols, void* stream);
+
+/* ---- per-kernel-class device timing (HIP events on the launch stream) for bench.py */
+int32_t revo_prof_enable(int32_t on);
+int32_t revo_prof_reset(void);
+/* writes a JSON object {"class": {"launches": n, "ms": t}, ...} into buf */
+int32_t revo_prof_report(char* buf, int32_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REVO_H */

@@ -1,0 +1,130 @@
+"""CPU oracle: brute-force cosine similarity + top-k, the search half of the path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/pe_vit.py header).  PARITY UNPINNED: the
+arithmetic lives in qdrant-client (``requirements.txt:39`` ``>=1.3.0``, local /
+embedded mode), absent from ``/root/reference`` and this image; the reference
+has no tests or golden vectors.  Restated from the reference's call sites:
+
+* ``core_system.py:600-603``  collection created with ``Distance.COSINE``
+* ``core_system.py:608``      vectors stored as plain float lists (float32 rows)
+* ``core_system.py:657-664``  one query vector, ``limit=max_results``,
+  ``score_threshold=similarity_threshold``
+* ``core_system.py:666``      empty result list when nothing passes the threshold
+
+and qdrant-client's local-mode behaviour as recalled in SURVEY.md §8(a) a8/a10:
+gallery rows L2-normalised at insert, query normalised, ``scores = G @ q``,
+descending order, stop at ``limit`` or at the first ``score < score_threshold``.
+
+Tie order: upstream's ``argsort()[::-1]`` is not stable, so exact duplicates
+(which real revers-o galleries contain, ``core_system.py:406-408``) come back in
+arbitrary order there.  This oracle fixes the order as (score desc, index asc);
+tests compare tie groups accordingly.
+"""
+import numpy as np
+
+
+def normalize_rows(x, dtype=np.float32):
+    """L2-normalise rows; a zero row stays zero (qdrant local guards the same way)."""
+    x = np.asarray(x, dtype=dtype)
+    n = np.linalg.norm(x.astype(np.float64), axis=-1, keepdims=True)
+    n = np.where(n == 0.0, 1.0, n)
+    return (x.astype(np.float64) / n).astype(dtype)
+
+
+def cosine_scores(gallery, queries, acc=np.float64):
+    """[N,D] x [Q,D] -> [Q,N] cosine of already-normalised rows, accumulated in
+    ``acc`` and rounded once to float32 (the score dtype the path returns)."""
+    g = np.asarray(gallery, dtype=acc)
+    q = np.asarray(queries, dtype=acc)
+    return (q @ g.T).astype(np.float32)
+
+
+def rank_topk(scores_row, k, threshold=None):
+    """Indices of the k best entries of one score row, (score desc, index asc),
+    cut at ``score >= threshold``."""
+    n = scores_row.shape[0]
+    order = np.lexsort((np.arange(n), -scores_row.astype(np.float64)))
+    order = order[:k]
+    if threshold is not None:
+        order = order[scores_row[order] >= np.float32(threshold)]
+    return order
+
+
+def search(gallery, queries, k, threshold=None, normalize=True, acc=np.float64):
+    """Brute-force cosine top-k.
+
+    Returns (scores float32 [Q,k], indices int64 [Q,k], counts int32 [Q]) padded
+    with -inf / -1 past ``counts`` — the layout of the build's ``search()``.
+    """
+    g = normalize_rows(gallery) if normalize else np.asarray(gallery, dtype=np.float32)
+    q = normalize_rows(queries) if normalize else np.asarray(queries, dtype=np.float32)
+    Q = q.shape[0]
+    out_s = np.full((Q, k), -np.inf, dtype=np.float32)
+    out_i = np.full((Q, k), -1, dtype=np.int64)
+    out_c = np.zeros((Q,), dtype=np.int32)
+    if g.shape[0] == 0:
+        return out_s, out_i, out_c
+    # block over queries so a 1M-row gallery does not materialise Q x N at once
+    step = max(1, min(Q, (1 << 27) // max(1, g.shape[0])))
+    g_acc = g.astype(acc)
+    for s in range(0, Q, step):
+        sc = (q[s:s + step].astype(acc) @ g_acc.T).astype(np.float32)
+        for r in range(sc.shape[0]):
+            row = sc[r]
+            kk = min(k, row.shape[0])
+            # partial selection first, then exact ordering of the survivors
+            if row.shape[0] > 4 * kk + 16:
+                kth = np.partition(row, row.shape[0] - kk)[row.shape[0] - kk]
+                cand = np.nonzero(row >= kth)[0]
+            else:
+                cand = np.arange(row.shape[0])
+            o = cand[np.lexsort((cand, -row[cand].astype(np.float64)))][:kk]
+            if threshold is not None:
+                o = o[row[o] >= np.float32(threshold)]
+            c = o.shape[0]
+            out_s[s + r, :c] = row[o]
+            out_i[s + r, :c] = o
+            out_c[s + r] = c
+    return out_s, out_i, out_c
+
+
+def search_one_reference_style(gallery_f32_normalized, query, k, threshold=None):
+    """The reference's actual usage: ONE query (``region_embeddings[0]``,
+    core_system.py:657), float32 ``G @ q``, full argsort, walk until ``limit`` or
+    the first score below the threshold.  Used for the cpu_baseline timing."""
+    q = np.asarray(query, dtype=np.float32)
+    n = np.linalg.norm(q)
+    if n > 0:
+        q = q / n
+    scores = gallery_f32_normalized @ q
+    order = np.argsort(scores)[::-1]
+    out = []
+    for idx in order:
+        if len(out) >= k:
+            break
+        if threshold is not None and scores[idx] < threshold:
+            break
+        out.append((int(idx), float(scores[idx])))
+    return out
+
+
+def merge_topk(part_scores, part_indices, k, threshold=None):
+    """Merge per-shard top-k lists: inputs [P,Q,k] (padded with -inf/-1, indices
+    already global) -> ([Q,k], [Q,k], [Q]) under (score desc, index asc)."""
+    P, Q, kk = part_scores.shape
+    s = np.transpose(part_scores, (1, 0, 2)).reshape(Q, P * kk)
+    i = np.transpose(part_indices, (1, 0, 2)).reshape(Q, P * kk)
+    out_s = np.full((Q, k), -np.inf, dtype=np.float32)
+    out_i = np.full((Q, k), -1, dtype=np.int64)
+    out_c = np.zeros((Q,), dtype=np.int32)
+    for r in range(Q):
+        valid = i[r] >= 0
+        sv, iv = s[r][valid], i[r][valid]
+        o = np.lexsort((iv, -sv.astype(np.float64)))[:k]
+        if threshold is not None:
+            o = o[sv[o] >= np.float32(threshold)]
+        c = o.shape[0]
+        out_s[r, :c] = sv[o]
+        out_i[r, :c] = iv[o]
+        out_c[r] = c
+    return out_s, out_i, out_c

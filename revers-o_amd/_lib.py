@@ -1,0 +1,92 @@
+"""ctypes binding of librevo.so (C ABI: include/revo.h).
+
+The HIP library is the product: there is no CPU fallback.  If the shared object
+is missing or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librevo.so")
+
+
+class RevoError(RuntimeError):
+    pass
+
+
+class VitCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "image_size", "patch_size", "width", "layers", "heads", "mlp_dim", "out_dim", "pool_heads",
+        "use_cls", "use_ls")] + [("ln_eps", C.c_float), ("rope_theta", C.c_float)]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+_p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); mirrors include/revo.h one to one
+SIGNATURES = {
+    "revo_last_error": (C.c_char_p, []),
+    "revo_version": (_i32, []),
+    "revo_sync": (_i32, [_p]),
+    "revo_vit_create": (_i32, [C.POINTER(VitCfg), C.POINTER(Tensor), _i32, _i32, _i32, C.POINTER(_p)]),
+    "revo_vit_destroy": (_i32, [_p]),
+    "revo_vit_forward": (_i32, [_p, _p, _i32, _i32, _p, _i32, _p]),
+    "revo_vit_set_debug_layers": (_i32, [_p, _i32]),
+    "revo_vit_read_residual": (_i32, [_p, _i32, _p, _p]),
+    "revo_vit_seq_len": (_i32, [_p]),
+    "revo_gallery_create": (_i32, [_i32, _i64, _i32, _i32, C.POINTER(_p)]),
+    "revo_gallery_destroy": (_i32, [_p]),
+    "revo_gallery_append": (_i32, [_p, _p, _i64, _i32, _i32, _p]),
+    "revo_gallery_size": (_i64, [_p]),
+    "revo_gallery_clear": (_i32, [_p]),
+    "revo_gallery_read": (_i32, [_p, _i64, _i64, _p, _i32]),
+    "revo_search_topk": (_i32, [_p, _p, _i32, _i32, _i32, _f32, _i64, _p, _p, _p, _p]),
+    "revo_topk_merge": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p]),
+    "revo_op_gemm": (_i32, [_i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p]),
+    "revo_op_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i64, _i32, _p]),
+    "revo_op_rope": (_i32, [_p, _i64, _p, _i32, _i32, _i32, _i32, _p]),
+    "revo_op_attention": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+    "revo_op_f32_to_bf16": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p]),
+    "revo_prof_enable": (_i32, [_i32]),
+    "revo_prof_reset": (_i32, []),
+    "revo_prof_report": (_i32, [C.c_char_p, _i32]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librevo.so and attach prototypes.  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RevoError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C revers-o_amd/csrc`).  There is no CPU fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().revo_last_error().decode("utf-8", "replace")
+        raise RevoError(f"{what} failed (status {rc}): {msg}")
+
+
+def ptr(t):
+    """Device/host address of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,619 @@
+// C ABI of librevo (include/revo.h): model and gallery handles, the embed forward
+// schedule, the search pipeline, error plumbing and the per-kernel-class profiler.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/revo.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------ error state --
+static thread_local std::string g_err;
+void revo_set_error(const std::string& msg) { g_err = msg; }
+extern "C" const char* revo_last_error(void) { return g_err.c_str(); }
+extern "C" int32_t revo_version(void) { return 100; }
+
+#define API_BEGIN try {
+#define API_END                                            \
+    }                                                      \
+    catch (const std::exception& e) {                      \
+        revo_set_error(std::string("exception: ") + e.what()); \
+        return -3;                                         \
+    }                                                      \
+    catch (...) {                                          \
+        revo_set_error("unknown exception");               \
+        return -3;                                         \
+    }
+#define CHECK_RC(expr)            \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc) return _rc;      \
+    } while (0)
+
+extern "C" int32_t revo_sync(void* stream) {
+    REVO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+// --------------------------------------------------------------- profiler --
+namespace {
+struct ProfRec { std::string cls; hipEvent_t a, b; };
+struct Profiler {
+    bool on = false;
+    std::mutex mu;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    std::map<std::string, std::pair<long, double>> acc;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    void drain() {
+        for (auto& r : recs) {
+            float ms = 0.f;
+            if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                auto& s = acc[r.cls];
+                s.first += 1; s.second += ms;
+            }
+            pool.push_back(r.a); pool.push_back(r.b);
+        }
+        recs.clear();
+    }
+} g_prof;
+
+struct ProfScope {
+    bool active; hipStream_t st; ProfRec rec;
+    ProfScope(const char* cls, hipStream_t s) : active(g_prof.on), st(s) {
+        if (!active) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        rec.cls = cls; rec.a = g_prof.get(); rec.b = g_prof.get();
+        (void)hipEventRecord(rec.a, st);
+    }
+    ~ProfScope() {
+        if (!active) return;
+        (void)hipEventRecord(rec.b, st);
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        g_prof.recs.push_back(rec);
+    }
+};
+}  // namespace
+
+extern "C" int32_t revo_prof_enable(int32_t on) { g_prof.on = on != 0; return 0; }
+extern "C" int32_t revo_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.drain();
+    g_prof.acc.clear();
+    return 0;
+}
+extern "C" int32_t revo_prof_report(char* buf, int32_t capacity) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.drain();
+    std::string s = "{";
+    bool first = true;
+    for (auto& kv : g_prof.acc) {
+        if (!first) s += ", ";
+        first = false;
+        s += "\"" + kv.first + "\": {\"launches\": " + std::to_string(kv.second.first) +
+             ", \"ms\": " + std::to_string(kv.second.second) + "}";
+    }
+    s += "}";
+    if ((int)s.size() + 1 > capacity) { revo_set_error("prof_report: buffer too small"); return -2; }
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return 0;
+}
+
+// ------------------------------------------------------------- small ops ---
+namespace revo {
+// q[o] = scale * (bias[o] + sum_i w[o][i] * probe[i])   -- the pool head's query is input independent
+__global__ __launch_bounds__(256) void probe_q_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const float* __restrict__ probe, int W, float scale,
+                                                      float* __restrict__ q) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= W) return;
+    float acc = 0.f;
+    for (int i = lane; i < W; i += 64) acc = fmaf(w[(long)o * W + i], probe[i], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) q[o] = (acc + bias[o]) * scale;
+}
+}  // namespace revo
+
+// ------------------------------------------------------------ the model ----
+struct DevBuf {
+    void* p = nullptr;
+    int alloc(size_t bytes) {
+        REVO_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+        return 0;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } }
+};
+
+struct LayerW {
+    bf16_t *w_qkv, *w_o, *w_fc1, *w_fc2;
+    float *b_qkv, *b_o, *b_fc1, *b_fc2, *ln1w, *ln1b, *ln2w, *ln2b, *ls1, *ls2;
+};
+
+struct revo_vit {
+    revo_vit_cfg cfg;
+    int device = 0, max_batch = 0, S = 0, G2 = 0, Kp = 0, hd = 0, phd = 0, debug_layers = -1;
+    std::vector<void*> owned;
+    // weights
+    bf16_t* w_patch = nullptr; float *cls = nullptr, *pos = nullptr, *lnpre_w = nullptr, *lnpre_b = nullptr,
+            *lnpost_w = nullptr, *lnpost_b = nullptr;
+    std::vector<LayerW> layers;
+    float* q_probe = nullptr; bf16_t* w_kv = nullptr; float* b_kv = nullptr; bf16_t* w_po = nullptr; float* b_po = nullptr;
+    float *pln_w = nullptr, *pln_b = nullptr; bf16_t* w_pfc1 = nullptr; float* b_pfc1 = nullptr; bf16_t* w_pfc2 = nullptr;
+    float* b_pfc2 = nullptr; bf16_t* w_proj = nullptr; float2* rope_cs = nullptr;
+    // workspace
+    bf16_t *patches = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr, *pool_att = nullptr,
+           *pool_h = nullptr, *pool_m = nullptr, *pool_ob = nullptr;
+    float *x = nullptr, *pool_o = nullptr, *feat = nullptr;
+
+    template <class T> int dalloc(T** out, size_t count) {
+        void* p = nullptr;
+        REVO_HIP_CHECK(hipMalloc(&p, count * sizeof(T) + 256));
+        owned.push_back(p);
+        *out = (T*)p;
+        return 0;
+    }
+    ~revo_vit() { for (void* p : owned) (void)hipFree(p); }
+};
+
+namespace {
+struct WeightMap {
+    std::map<std::string, const revo_tensor*> m;
+    const revo_tensor* get(const std::string& name, int64_t numel) {
+        auto it = m.find(name);
+        if (it == m.end()) { revo_set_error("missing weight tensor: " + name); return nullptr; }
+        if (it->second->numel != numel) {
+            revo_set_error("weight " + name + ": expected " + std::to_string(numel) + " elements, got " +
+                           std::to_string(it->second->numel));
+            return nullptr;
+        }
+        return it->second;
+    }
+};
+
+// fp32 (host or device) -> device fp32
+int up_f32(revo_vit* v, WeightMap& wm, const std::string& name, int64_t numel, float** out) {
+    const revo_tensor* t = wm.get(name, numel);
+    if (!t) return -2;
+    CHECK_RC(v->dalloc(out, (size_t)numel));
+    REVO_HIP_CHECK(hipMemcpy(*out, t->data, (size_t)numel * 4, hipMemcpyDefault));
+    return 0;
+}
+// fp32 [rows][cols] (host or device) -> device bf16 [rows][ld] zero padded
+int up_bf16(revo_vit* v, float* stage, const float* src, int64_t rows, int64_t cols, int64_t ld, bf16_t** out) {
+    CHECK_RC(v->dalloc(out, (size_t)(rows * ld)));
+    REVO_HIP_CHECK(hipMemcpy(stage, src, (size_t)(rows * cols) * 4, hipMemcpyDefault));
+    CHECK_RC(revo::launch_f32_to_bf16(stage, cols, *out, ld, rows, (int)cols, 0));
+    REVO_HIP_CHECK(hipStreamSynchronize(0));
+    return 0;
+}
+}  // namespace
+
+extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* weights, int32_t n_weights,
+                                   int32_t device, int32_t max_batch, revo_vit** out) {
+    API_BEGIN
+    REVO_REQUIRE(cfg && weights && out, "vit_create: null argument");
+    REVO_REQUIRE(max_batch >= 1, "vit_create: max_batch must be >= 1");
+    const revo_vit_cfg& c = *cfg;
+    REVO_REQUIRE(c.image_size % c.patch_size == 0, "vit_create: image_size must be a multiple of patch_size");
+    REVO_REQUIRE(c.width % c.heads == 0 && c.width % c.pool_heads == 0, "vit_create: width must divide into heads");
+    REVO_REQUIRE(c.width % 64 == 0 && c.mlp_dim % 64 == 0, "vit_create: width and mlp_dim must be multiples of 64");
+    REVO_REQUIRE(c.out_dim % 4 == 0, "vit_create: out_dim must be a multiple of 4");
+    REVO_REQUIRE(c.width / c.heads == 64, "vit_create: body head_dim must be 64 (PE-Core B16 / L14)");
+    REVO_HIP_CHECK(hipSetDevice(device));
+    std::unique_ptr<revo_vit> v(new revo_vit());
+    v->cfg = c; v->device = device; v->max_batch = max_batch;
+    const int W = c.width, M = c.mlp_dim, D = c.out_dim, P = c.patch_size, G = c.image_size / P;
+    v->G2 = G * G; v->S = v->G2 + (c.use_cls ? 1 : 0);
+    v->hd = W / c.heads; v->phd = W / c.pool_heads;
+    const int Kreal = 3 * P * P;
+    v->Kp = (Kreal + 63) / 64 * 64;
+    const int S = v->S;
+
+    WeightMap wm;
+    for (int i = 0; i < n_weights; ++i) wm.m[weights[i].name] = &weights[i];
+
+    // staging buffer for fp32 -> bf16 conversion: the largest matrix
+    size_t stage_elems = (size_t)std::max({(long)3 * W * W, (long)M * W, (long)W * Kreal, (long)W * D});
+    float* stage = nullptr;
+    REVO_HIP_CHECK(hipMalloc((void**)&stage, stage_elems * 4));
+    struct StageGuard { float* p; ~StageGuard() { (void)hipFree(p); } } sg{stage};
+
+    const revo_tensor* t;
+    if (!(t = wm.get("visual.conv1.weight", (int64_t)W * Kreal))) return -2;
+    CHECK_RC(up_bf16(v.get(), stage, t->data, W, Kreal, v->Kp, &v->w_patch));
+    if (c.use_cls) CHECK_RC(up_f32(v.get(), wm, "visual.class_embedding", W, &v->cls));
+    CHECK_RC(up_f32(v.get(), wm, "visual.positional_embedding", (int64_t)S * W, &v->pos));
+    CHECK_RC(up_f32(v.get(), wm, "visual.ln_pre.weight", W, &v->lnpre_w));
+    CHECK_RC(up_f32(v.get(), wm, "visual.ln_pre.bias", W, &v->lnpre_b));
+    CHECK_RC(up_f32(v.get(), wm, "visual.ln_post.weight", W, &v->lnpost_w));
+    CHECK_RC(up_f32(v.get(), wm, "visual.ln_post.bias", W, &v->lnpost_b));
+    v->layers.resize(c.layers);
+    for (int i = 0; i < c.layers; ++i) {
+        const std::string p = "visual.transformer.resblocks." + std::to_string(i) + ".";
+        LayerW& L = v->layers[i];
+        memset(&L, 0, sizeof(L));
+        CHECK_RC(up_f32(v.get(), wm, p + "ln_1.weight", W, &L.ln1w));
+        CHECK_RC(up_f32(v.get(), wm, p + "ln_1.bias", W, &L.ln1b));
+        CHECK_RC(up_f32(v.get(), wm, p + "ln_2.weight", W, &L.ln2w));
+        CHECK_RC(up_f32(v.get(), wm, p + "ln_2.bias", W, &L.ln2b));
+        if (!(t = wm.get(p + "attn.in_proj_weight", (int64_t)3 * W * W))) return -2;
+        CHECK_RC(up_bf16(v.get(), stage, t->data, 3 * W, W, W, &L.w_qkv));
+        CHECK_RC(up_f32(v.get(), wm, p + "attn.in_proj_bias", 3 * W, &L.b_qkv));
+        if (!(t = wm.get(p + "attn.out_proj.weight", (int64_t)W * W))) return -2;
+        CHECK_RC(up_bf16(v.get(), stage, t->data, W, W, W, &L.w_o));
+        CHECK_RC(up_f32(v.get(), wm, p + "attn.out_proj.bias", W, &L.b_o));
+        if (!(t = wm.get(p + "mlp.c_fc.weight", (int64_t)M * W))) return -2;
+        CHECK_RC(up_bf16(v.get(), stage, t->data, M, W, W, &L.w_fc1));
+        CHECK_RC(up_f32(v.get(), wm, p + "mlp.c_fc.bias", M, &L.b_fc1));
+        if (!(t = wm.get(p + "mlp.c_proj.weight", (int64_t)W * M))) return -2;
+        CHECK_RC(up_bf16(v.get(), stage, t->data, W, M, M, &L.w_fc2));
+        CHECK_RC(up_f32(v.get(), wm, p + "mlp.c_proj.bias", W, &L.b_fc2));
+        if (c.use_ls) {
+            CHECK_RC(up_f32(v.get(), wm, p + "ls_1.gamma", W, &L.ls1));
+            CHECK_RC(up_f32(v.get(), wm, p + "ls_2.gamma", W, &L.ls2));
+        }
+    }
+    // attention-pool head
+    {
+        const std::string p = "visual.attn_pool.";
+        float *probe = nullptr, *wi = nullptr, *bi = nullptr;
+        CHECK_RC(up_f32(v.get(), wm, p + "probe", W, &probe));
+        CHECK_RC(up_f32(v.get(), wm, p + "attn.in_proj_weight", (int64_t)3 * W * W, &wi));
+        CHECK_RC(up_f32(v.get(), wm, p + "attn.in_proj_bias", 3 * W, &bi));
+        CHECK_RC(v->dalloc(&v->q_probe, (size_t)W));
+        hipLaunchKernelGGL(revo::probe_q_kernel, dim3((W + 3) / 4), dim3(256), 0, 0, wi, bi, probe, W,
+                           1.0f / sqrtf((float)v->phd), v->q_probe);
+        REVO_HIP_CHECK(hipGetLastError());
+        CHECK_RC(v->dalloc(&v->w_kv, (size_t)2 * W * W));
+        CHECK_RC(revo::launch_f32_to_bf16(wi + (size_t)W * W, W, v->w_kv, W, 2 * W, W, 0));
+        v->b_kv = bi + W;
+        REVO_HIP_CHECK(hipStreamSynchronize(0));
+        if (!(t = wm.get(p + "attn.out_proj.weight", (int64_t)W * W))) return -2;
+        CHECK_RC(up_bf16(v.get(), stage, t->data, W, W, W, &v->w_po));
+        CHECK_RC(up_f32(v.get(), wm, p + "attn.out_proj.bias", W, &v->b_po));
+        CHECK_RC(up_f32(v.get(), wm, p + "layernorm.weight", W, &v->pln_w));
+        CHECK_RC(up_f32(v.get(), wm, p + "layernorm.bias", W, &v->pln_b));
+        if (!(t = wm.get(p + "mlp.c_fc.weight", (int64_t)M * W))) return -2;
+        CHECK_RC(up_bf16(v.get(), stage, t->data, M, W, W, &v->w_pfc1));
+        CHECK_RC(up_f32(v.get(), wm, p + "mlp.c_fc.bias", M, &v->b_pfc1));
+        if (!(t = wm.get(p + "mlp.c_proj.weight", (int64_t)W * M))) return -2;
+        CHECK_RC(up_bf16(v.get(), stage, t->data, W, M, M, &v->w_pfc2));
+        CHECK_RC(up_f32(v.get(), wm, p + "mlp.c_proj.bias", W, &v->b_pfc2));
+    }
+    if (!(t = wm.get("visual.proj", (int64_t)W * D))) return -2;
+    CHECK_RC(v->dalloc(&v->w_proj, (size_t)D * W));
+    REVO_HIP_CHECK(hipMemcpy(stage, t->data, (size_t)W * D * 4, hipMemcpyDefault));
+    CHECK_RC(revo::launch_transpose_f32_to_bf16(stage, W, D, v->w_proj, W, 0));
+    REVO_HIP_CHECK(hipStreamSynchronize(0));
+
+    // 2-D rope table: [S][hd/2] (cos, sin); x-axis pairs first, then y-axis; cls row unrotated
+    {
+        const int hd = v->hd, d = hd / 2, nf = d / 2;
+        std::vector<float2> cs((size_t)S * (hd / 2));
+        const int start = c.use_cls ? 1 : 0;
+        for (int s = 0; s < S; ++s) {
+            for (int pi = 0; pi < hd / 2; ++pi) {
+                double ang = 0.0;
+                if (!(c.use_cls && s == 0)) {
+                    const int g = s - (c.use_cls ? 1 : 0);
+                    const int gy = g / G, gx = g % G;
+                    const bool xaxis = pi < nf;
+                    const int f = xaxis ? pi : pi - nf;
+                    const double freq = 1.0 / pow((double)c.rope_theta, (double)(2 * f) / (double)d);
+                    ang = (double)((xaxis ? gx : gy) + start) * freq;
+                }
+                cs[(size_t)s * (hd / 2) + pi] = make_float2((float)cos(ang), (float)sin(ang));
+            }
+        }
+        CHECK_RC(v->dalloc(&v->rope_cs, cs.size()));
+        REVO_HIP_CHECK(hipMemcpy(v->rope_cs, cs.data(), cs.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
+
+    // workspace for max_batch images
+    const size_t rows = (size_t)max_batch * S, B = (size_t)max_batch;
+    CHECK_RC(v->dalloc(&v->patches, (size_t)max_batch * v->G2 * v->Kp));
+    CHECK_RC(v->dalloc(&v->x, rows * W));
+    CHECK_RC(v->dalloc(&v->h, rows * W));
+    CHECK_RC(v->dalloc(&v->qkv, rows * 3 * W));
+    CHECK_RC(v->dalloc(&v->att, rows * W));
+    CHECK_RC(v->dalloc(&v->mlp, rows * M));
+    CHECK_RC(v->dalloc(&v->pool_att, B * W));
+    CHECK_RC(v->dalloc(&v->pool_o, B * W));
+    CHECK_RC(v->dalloc(&v->pool_h, B * W));
+    CHECK_RC(v->dalloc(&v->pool_m, B * M));
+    CHECK_RC(v->dalloc(&v->pool_ob, B * W));
+    CHECK_RC(v->dalloc(&v->feat, B * D));
+    REVO_HIP_CHECK(hipDeviceSynchronize());
+    *out = v.release();
+    return 0;
+    API_END
+}
+
+extern "C" int32_t revo_vit_destroy(revo_vit* vit) {
+    API_BEGIN
+    if (vit) { (void)hipSetDevice(vit->device); delete vit; }
+    return 0;
+    API_END
+}
+extern "C" int32_t revo_vit_seq_len(const revo_vit* vit) { return vit ? vit->S : -1; }
+extern "C" int32_t revo_vit_set_debug_layers(revo_vit* vit, int32_t n) {
+    REVO_REQUIRE(vit, "null handle");
+    vit->debug_layers = n;
+    return 0;
+}
+extern "C" int32_t revo_vit_read_residual(revo_vit* vit, int32_t batch, float* dst, void* stream) {
+    REVO_REQUIRE(vit && dst && batch >= 1 && batch <= vit->max_batch, "read_residual: bad arguments");
+    REVO_HIP_CHECK(hipMemcpyAsync(dst, vit->x, (size_t)batch * vit->S * vit->cfg.width * 4, hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    return 0;
+}
+
+namespace {
+int gemm(const char* cls, int epi, const bf16_t* A, long lda, const bf16_t* B, long ldb, int M, int N, int K, void* C,
+         long ldc, const float* bias, const float* gamma, hipStream_t st) {
+    revo::GemmArgs a{};
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
+    a.bias = bias; a.gamma = gamma;
+    ProfScope ps(cls, st);
+    return revo::launch_gemm(epi, a, st);
+}
+}  // namespace
+
+extern "C" int32_t revo_vit_forward(revo_vit* v, const void* images, int32_t image_dtype, int32_t batch, float* out,
+                                    int32_t normalize, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(v && images && out, "vit_forward: null argument");
+    REVO_REQUIRE(batch >= 1 && batch <= v->max_batch, "vit_forward: batch exceeds max_batch of the handle");
+    REVO_REQUIRE(image_dtype == 0 || image_dtype == 1, "vit_forward: image_dtype must be 0 (f32) or 1 (u8)");
+    hipStream_t st = (hipStream_t)stream;
+    const revo_vit_cfg& c = v->cfg;
+    const int W = c.width, Md = c.mlp_dim, D = c.out_dim, S = v->S, B = batch;
+    const int rows = B * S;
+    using namespace revo;
+
+    {   // K1 + K2: patch embed GEMM, position add, cls row
+        { ProfScope ps("patchify", st);
+          CHECK_RC(launch_patchify(images, image_dtype == 1, B, c.image_size, c.patch_size, v->patches, v->Kp, st)); }
+        GemmArgs a{};
+        a.A = v->patches; a.lda = v->Kp; a.B = v->w_patch; a.ldb = v->Kp; a.M = B * v->G2; a.N = W; a.K = v->Kp;
+        a.C = v->x; a.ldc = W; a.pos = v->pos; a.S = S; a.G2 = v->G2; a.cls = c.use_cls ? 1 : 0;
+        { ProfScope ps("gemm_patch", st); CHECK_RC(launch_gemm(EPI_PATCH, a, st)); }
+        if (c.use_cls) { ProfScope ps("elementwise", st); CHECK_RC(launch_cls_rows(v->x, W, v->cls, v->pos, B, S, W, st)); }
+    }
+    { ProfScope ps("layernorm", st);
+      CHECK_RC(launch_layernorm(v->x, W, v->lnpre_w, v->lnpre_b, c.ln_eps, rows, W, v->x, W, 0, st)); }
+
+    const int nl = v->debug_layers < 0 ? c.layers : std::min(v->debug_layers, c.layers);
+    for (int i = 0; i < nl; ++i) {
+        const LayerW& L = v->layers[i];
+        { ProfScope ps("layernorm", st);
+          CHECK_RC(launch_layernorm(v->x, W, L.ln1w, L.ln1b, c.ln_eps, rows, W, v->h, W, 1, st)); }
+        CHECK_RC(gemm("gemm_qkv", EPI_BF16, v->h, W, L.w_qkv, W, rows, 3 * W, W, v->qkv, 3 * W, L.b_qkv, nullptr, st));
+        { ProfScope ps("rope", st); CHECK_RC(launch_rope(v->qkv, 3 * W, v->rope_cs, rows, S, W, c.heads, st)); }
+        { ProfScope ps("attention", st);
+          CHECK_RC(launch_attention(v->qkv, 3 * W, v->att, W, B, S, c.heads, v->hd, st)); }
+        CHECK_RC(gemm("gemm_out", EPI_RESID_F32, v->att, W, L.w_o, W, rows, W, W, v->x, W, L.b_o, L.ls1, st));
+        { ProfScope ps("layernorm", st);
+          CHECK_RC(launch_layernorm(v->x, W, L.ln2w, L.ln2b, c.ln_eps, rows, W, v->h, W, 1, st)); }
+        CHECK_RC(gemm("gemm_fc1", EPI_BF16_GELU, v->h, W, L.w_fc1, W, rows, Md, W, v->mlp, Md, L.b_fc1, nullptr, st));
+        CHECK_RC(gemm("gemm_fc2", EPI_RESID_F32, v->mlp, Md, L.w_fc2, Md, rows, W, Md, v->x, W, L.b_fc2, L.ls2, st));
+    }
+    if (v->debug_layers >= 0) return 0;   // parity hook: residual stream only
+
+    // ln_post -> attention pool -> proj -> normalise
+    { ProfScope ps("layernorm", st);
+      CHECK_RC(launch_layernorm(v->x, W, v->lnpost_w, v->lnpost_b, c.ln_eps, rows, W, v->h, W, 1, st)); }
+    CHECK_RC(gemm("gemm_pool_kv", EPI_BF16, v->h, W, v->w_kv, W, rows, 2 * W, W, v->qkv, 2 * W, v->b_kv, nullptr, st));
+    { ProfScope ps("pool_attention", st);
+      CHECK_RC(launch_pool_attention(v->q_probe, v->qkv, 2 * W, v->pool_att, W, B, S, c.pool_heads, v->phd, st)); }
+    CHECK_RC(gemm("gemm_pool", EPI_F32, v->pool_att, W, v->w_po, W, B, W, W, v->pool_o, W, v->b_po, nullptr, st));
+    { ProfScope ps("layernorm", st);
+      CHECK_RC(launch_layernorm(v->pool_o, W, v->pln_w, v->pln_b, c.ln_eps, B, W, v->pool_h, W, 1, st)); }
+    CHECK_RC(gemm("gemm_pool", EPI_BF16_GELU, v->pool_h, W, v->w_pfc1, W, B, Md, W, v->pool_m, Md, v->b_pfc1, nullptr, st));
+    CHECK_RC(gemm("gemm_pool", EPI_RESID_F32, v->pool_m, Md, v->w_pfc2, Md, B, W, Md, v->pool_o, W, v->b_pfc2, nullptr, st));
+    { ProfScope ps("elementwise", st); CHECK_RC(launch_f32_to_bf16(v->pool_o, W, v->pool_ob, W, B, W, st)); }
+    float* feat = normalize ? v->feat : out;
+    CHECK_RC(gemm("gemm_pool", EPI_F32, v->pool_ob, W, v->w_proj, W, B, D, W, feat, D, nullptr, nullptr, st));
+    if (normalize) {
+        ProfScope ps("l2norm", st);
+        CHECK_RC(launch_l2norm_rows(v->feat, D, out, D, nullptr, 0, B, D, st));
+    }
+    return 0;
+    API_END
+}
+
+// ------------------------------------------------------------ the gallery --
+struct revo_gallery {
+    int D = 0, device = 0, keep_f32 = 1;
+    int64_t capacity = 0, size = 0;
+    bf16_t* gb = nullptr;      // [capacity][D] normalised rows, scan copy
+    float* gf = nullptr;       // [capacity][D] normalised rows, fp32 master (re-score + persistence)
+    // per-call workspace, grown on demand
+    float* qf = nullptr; bf16_t* qb = nullptr; int q_cap = 0;
+    uint64_t* part = nullptr; size_t part_cap = 0;
+    float* stage = nullptr; size_t stage_cap = 0;
+    ~revo_gallery() {
+        (void)hipFree(gb); (void)hipFree(gf); (void)hipFree(qf); (void)hipFree(qb); (void)hipFree(part);
+        (void)hipFree(stage);
+    }
+};
+
+extern "C" int32_t revo_gallery_create(int32_t dim, int64_t capacity, int32_t device, int32_t keep_f32,
+                                       revo_gallery** out) {
+    API_BEGIN
+    REVO_REQUIRE(out, "gallery_create: null argument");
+    REVO_REQUIRE(dim >= 64 && dim % 64 == 0, "gallery_create: dim must be a positive multiple of 64");
+    REVO_REQUIRE(capacity >= 1 && capacity < (1ll << 32), "gallery_create: capacity must be in [1, 2^32)");
+    REVO_HIP_CHECK(hipSetDevice(device));
+    std::unique_ptr<revo_gallery> g(new revo_gallery());
+    g->D = dim; g->device = device; g->capacity = capacity; g->keep_f32 = keep_f32 != 0;
+    REVO_HIP_CHECK(hipMalloc((void**)&g->gb, (size_t)capacity * dim * 2));
+    if (g->keep_f32) REVO_HIP_CHECK(hipMalloc((void**)&g->gf, (size_t)capacity * dim * 4));
+    *out = g.release();
+    return 0;
+    API_END
+}
+extern "C" int32_t revo_gallery_destroy(revo_gallery* g) {
+    API_BEGIN
+    if (g) { (void)hipSetDevice(g->device); delete g; }
+    return 0;
+    API_END
+}
+extern "C" int64_t revo_gallery_size(const revo_gallery* g) { return g ? g->size : -1; }
+extern "C" int32_t revo_gallery_clear(revo_gallery* g) {
+    REVO_REQUIRE(g, "null handle");
+    g->size = 0;
+    return 0;
+}
+
+extern "C" int32_t revo_gallery_append(revo_gallery* g, const float* vecs, int64_t n, int32_t normalize,
+                                       int32_t src_on_device, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(g && (vecs || n == 0), "gallery_append: null argument");
+    REVO_REQUIRE(n >= 0 && g->size + n <= g->capacity, "gallery_append: exceeds the capacity given at create");
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int D = g->D;
+    const int64_t chunk_rows = std::max<int64_t>(1, (64ll << 20) / (D * 4));
+    for (int64_t done = 0; done < n; done += chunk_rows) {
+        const int64_t m = std::min(chunk_rows, n - done);
+        const float* src = vecs + done * D;
+        if (!src_on_device) {
+            const size_t need = (size_t)m * D * 4;
+            if (g->stage_cap < need) {
+                (void)hipFree(g->stage); g->stage = nullptr; g->stage_cap = 0;
+                REVO_HIP_CHECK(hipMalloc((void**)&g->stage, need));
+                g->stage_cap = need;
+            }
+            REVO_HIP_CHECK(hipMemcpyAsync(g->stage, src, need, hipMemcpyHostToDevice, st));
+            src = g->stage;
+        }
+        const int64_t row0 = g->size + done;
+        bf16_t* db = g->gb + row0 * D;
+        float* df = g->keep_f32 ? g->gf + row0 * D : nullptr;
+        ProfScope ps("gallery_append", st);
+        if (normalize) {
+            CHECK_RC(revo::launch_l2norm_rows(src, D, df, D, db, D, m, D, st));
+        } else {
+            if (df) REVO_HIP_CHECK(hipMemcpyAsync(df, src, (size_t)m * D * 4, hipMemcpyDeviceToDevice, st));
+            CHECK_RC(revo::launch_f32_to_bf16(src, D, db, D, m, D, st));
+        }
+        if (!src_on_device) REVO_HIP_CHECK(hipStreamSynchronize(st));   // staging buffer is reused
+    }
+    g->size += n;
+    return 0;
+    API_END
+}
+
+extern "C" int32_t revo_gallery_read(revo_gallery* g, int64_t start, int64_t n, float* dst, int32_t dst_on_device) {
+    API_BEGIN
+    REVO_REQUIRE(g && dst, "gallery_read: null argument");
+    REVO_REQUIRE(g->keep_f32, "gallery_read: gallery was created without the fp32 master copy");
+    REVO_REQUIRE(start >= 0 && n >= 0 && start + n <= g->size, "gallery_read: range outside the gallery");
+    if (n == 0) return 0;
+    REVO_HIP_CHECK(hipMemcpy(dst, g->gf + start * g->D, (size_t)n * g->D * 4,
+                             dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return 0;
+    API_END
+}
+
+extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32_t Q, int32_t k, int32_t has_thr,
+                                    float thr, int64_t index_offset, float* scores, int64_t* indices, int32_t* counts,
+                                    void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(g && scores && indices && counts && (queries || Q == 0), "search: null argument");
+    REVO_REQUIRE(Q >= 0, "search: negative query count");
+    REVO_REQUIRE(k >= 1 && k <= 50, "search: k must be in [1, 50]");
+    if (Q == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    using namespace revo;
+    if (g->size == 0) return launch_topk_fill_empty(scores, (long long*)indices, counts, Q, k, st);
+    const int D = g->D;
+    // over-selection: the bf16 scan keeps ksel >= k + margin candidates, the fp32 re-score decides
+    const int ksel = (k <= 16) ? 32 : 64;
+    const int splits = topk_scan_workspace_splits(Q, g->size);
+    if (g->q_cap < Q) {
+        REVO_HIP_CHECK(hipStreamSynchronize(st));
+        (void)hipFree(g->qf); (void)hipFree(g->qb); g->qf = nullptr; g->qb = nullptr; g->q_cap = 0;
+        REVO_HIP_CHECK(hipMalloc((void**)&g->qf, (size_t)Q * D * 4));
+        REVO_HIP_CHECK(hipMalloc((void**)&g->qb, (size_t)Q * D * 2));
+        g->q_cap = Q;
+    }
+    const size_t part_need = (size_t)Q * splits * ksel * 8;
+    if (g->part_cap < part_need) {
+        REVO_HIP_CHECK(hipStreamSynchronize(st));
+        (void)hipFree(g->part); g->part = nullptr; g->part_cap = 0;
+        REVO_HIP_CHECK(hipMalloc((void**)&g->part, part_need));
+        g->part_cap = part_need;
+    }
+    { ProfScope ps("search_prep", st);
+      CHECK_RC(launch_l2norm_rows(queries, D, g->qf, D, g->qb, D, Q, D, st)); }
+    ScanArgs a{};
+    a.Qb = g->qb; a.ldq = D; a.Gb = g->gb; a.ldg = D; a.Q = Q; a.N = g->size; a.D = D; a.ksel = ksel;
+    a.splits = splits; a.part = g->part;
+    { ProfScope ps("topk_scan", st); CHECK_RC(launch_topk_scan(a, st)); }
+    { ProfScope ps("topk_reduce", st); CHECK_RC(launch_topk_reduce(g->part, Q, splits, ksel, st)); }
+    { ProfScope ps("topk_finish", st);
+      CHECK_RC(launch_topk_finish(g->part, (long)splits * ksel, ksel, g->qf, D, g->keep_f32 ? g->gf : nullptr, D, D, Q,
+                                  k, has_thr, thr, index_offset, scores, (long long*)indices, counts, st)); }
+    return 0;
+    API_END
+}
+
+extern "C" int32_t revo_topk_merge(const float* scores, const int64_t* indices, int32_t parts, int32_t Q, int32_t k,
+                                   int32_t has_thr, float thr, float* out_scores, int64_t* out_indices,
+                                   int32_t* out_counts, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(scores && indices && out_scores && out_indices && out_counts, "merge: null argument");
+    ProfScope ps("topk_merge", (hipStream_t)stream);
+    return revo::launch_topk_merge(scores, (const long long*)indices, parts, Q, k, has_thr, thr, out_scores,
+                                   (long long*)out_indices, out_counts, (hipStream_t)stream);
+    API_END
+}
+
+// ------------------------------------------------------- single kernels ----
+extern "C" int32_t revo_op_gemm(int32_t epi, const void* a, int64_t lda, const void* b, int64_t ldb, int32_t m,
+                                int32_t n, int32_t k, void* c, int64_t ldc, const float* bias, const float* gamma,
+                                void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(epi >= 0 && epi <= 3, "op_gemm: epilogue must be 0..3");
+    return gemm("gemm_op", epi, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, m, n, k, c, ldc, bias, gamma,
+                (hipStream_t)stream);
+    API_END
+}
+extern "C" int32_t revo_op_layernorm(const float* x, int64_t ldx, const float* w, const float* b, float eps,
+                                     int32_t rows, int32_t width, void* out, int64_t ldo, int32_t out_is_bf16,
+                                     void* stream) {
+    API_BEGIN
+    return revo::launch_layernorm(x, ldx, w, b, eps, rows, width, out, ldo, out_is_bf16, (hipStream_t)stream);
+    API_END
+}
+extern "C" int32_t revo_op_rope(void* qkv, int64_t ld, const float* cs, int32_t rows, int32_t seq, int32_t width,
+                                int32_t heads, void* stream) {
+    API_BEGIN
+    return revo::launch_rope((bf16_t*)qkv, ld, (const float2*)cs, rows, seq, width, heads, (hipStream_t)stream);
+    API_END
+}
+extern "C" int32_t revo_op_attention(const void* qkv, int64_t ld, void* out, int64_t ldo, int32_t batch, int32_t seq,
+                                     int32_t heads, int32_t head_dim, void* stream) {
+    API_BEGIN
+    ProfScope ps("attention", (hipStream_t)stream);
+    return revo::launch_attention((const bf16_t*)qkv, ld, (bf16_t*)out, ldo, batch, seq, heads, head_dim,
+                                  (hipStream_t)stream);
+    API_END
+}
+extern "C" int32_t revo_op_f32_to_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows,
+                                       int32_t cols, void* stream) {
+    API_BEGIN
+    return revo::launch_f32_to_bf16(src, ld_src, (bf16_t*)dst, ld_dst, rows, cols, (hipStream_t)stream);
+    API_END
+}

@@ -1,0 +1,286 @@
+// HBM-bound row kernels of the embed path: LayerNorm (K3), patchify / im2col (K1
+// staging), cls row (K2), 2-D RoPE (K5), L2 normalise (K11; core_system.py:447),
+// dtype conversion.  All loads/stores are 8-16 B per lane, one wave per row where a
+// row reduction is needed.
+#include "kernels.h"
+
+namespace revo {
+
+// ------------------------------------------------------------ LayerNorm ----
+// One wave per row; the row lives in registers (W <= 64*4*MAXC), two-pass fp32
+// statistics exactly as torch.nn.functional.layer_norm computes them.
+template <int MAXC, bool OUT_BF16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        float eps, int rows, int W, void* __restrict__ out, long ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * ldx;
+    const int nchunk = W >> 2;
+    f32x4 v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            v[i] = *(const f32x4*)(xr + c * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else {
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[i][j] - mean;
+                q = fmaf(d, d, q);
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            const f32x4 g = *(const f32x4*)(w + c * 4);
+            const f32x4 be = *(const f32x4*)(b + c * 4);
+            f32x4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = fmaf((v[i][j] - mean) * rstd, g[j], be[j]);
+            if (OUT_BF16) {
+                uint2 o;
+                o.x = pack_bf16x2(y[0], y[1]);
+                o.y = pack_bf16x2(y[2], y[3]);
+                *(uint2*)((bf16_t*)out + (long)row * ldo + c * 4) = o;
+            } else {
+                *(f32x4*)((float*)out + (long)row * ldo + c * 4) = y;
+            }
+        }
+    }
+}
+
+int launch_layernorm(const float* x, long ldx, const float* w, const float* b, float eps, int rows, int W, void* out,
+                     long ldo, int out_is_bf16, hipStream_t st) {
+    REVO_REQUIRE(W % 4 == 0 && W <= 2048, "layernorm: W must be a multiple of 4 and <= 2048");
+    REVO_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "layernorm: row strides must be multiples of 4");
+    if (rows <= 0) return 0;
+    dim3 grid((rows + 3) / 4), block(256);
+    const int chunks = (W / 4 + 63) / 64;
+#define LN_LAUNCH(MC)                                                                                              \
+    if (out_is_bf16)                                                                                               \
+        hipLaunchKernelGGL((layernorm_kernel<MC, true>), grid, block, 0, st, x, ldx, w, b, eps, rows, W, out, ldo); \
+    else                                                                                                           \
+        hipLaunchKernelGGL((layernorm_kernel<MC, false>), grid, block, 0, st, x, ldx, w, b, eps, rows, W, out, ldo);
+    if (chunks <= 1) { LN_LAUNCH(1) }
+    else if (chunks <= 3) { LN_LAUNCH(3) }
+    else if (chunks <= 4) { LN_LAUNCH(4) }
+    else if (chunks <= 6) { LN_LAUNCH(6) }
+    else { LN_LAUNCH(8) }
+#undef LN_LAUNCH
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------- patchify ----
+// Each thread produces 8 consecutive k of one patch row (one 16-byte store).
+template <bool U8>
+__global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ images, int B, int img, int P, int G,
+                                                       bf16_t* __restrict__ out, long ld) {
+    const int chunks = (int)(ld >> 3);
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * G * G * chunks;
+    if (gid >= total) return;
+    const int c8 = (int)(gid % chunks);
+    const long prow = gid / chunks;
+    const int gx = (int)(prow % G);
+    const int gy = (int)((prow / G) % G);
+    const int b = (int)(prow / ((long)G * G));
+    const int PP = P * P, Kreal = 3 * PP;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = c8 * 8 + j;
+        float f = 0.f;
+        if (k < Kreal) {
+            const int c = k / PP, rem = k - c * PP;
+            const int py = rem / P, px = rem - py * P;
+            const long off = (((long)b * 3 + c) * img + (gy * P + py)) * img + (gx * P + px);
+            if (U8) {
+                const float u = (float)((const uint8_t*)images)[off];
+                f = (u / 255.0f - 0.5f) / 0.5f;   // ToTensor then Normalize(0.5, 0.5)
+            } else {
+                f = ((const float*)images)[off];
+            }
+        }
+        v[j] = f;
+    }
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]);
+    o.w = pack_bf16x2(v[6], v[7]);
+    *(uint4*)(out + prow * ld + c8 * 8) = o;
+}
+
+int launch_patchify(const void* images, int is_u8, int B, int img, int P, bf16_t* out, long ld, hipStream_t st) {
+    REVO_REQUIRE(img % P == 0, "patchify: image size must be a multiple of the patch size");
+    REVO_REQUIRE(ld % 8 == 0 && ld >= 3 * P * P, "patchify: bad leading dimension");
+    const int G = img / P;
+    const long total = (long)B * G * G * (ld / 8);
+    if (total <= 0) return 0;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (is_u8) hipLaunchKernelGGL((patchify_kernel<true>), grid, block, 0, st, images, B, img, P, G, out, ld);
+    else hipLaunchKernelGGL((patchify_kernel<false>), grid, block, 0, st, images, B, img, P, G, out, ld);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------- cls rows ----
+__global__ void cls_rows_kernel(float* x, long ldx, const float* cls, const float* pos, int B, int S, int W) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * W) return;
+    const int b = i / W, c = i - b * W;
+    x[(long)b * S * ldx + c] = cls[c] + pos[c];
+}
+int launch_cls_rows(float* x, long ldx, const float* cls, const float* pos, int B, int S, int W, hipStream_t st) {
+    const int n = B * W;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, ldx, cls, pos, B, S, W);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ----------------------------------------------------------------- RoPE ----
+// cs: [S][hd/2] (cos, sin) per interleaved pair.  One thread rotates 4 pairs
+// (16 bytes) of q or k.
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, long ld, const float2* __restrict__ cs,
+                                                   long rows, int S, int W, int hd) {
+    const int chunks_per_row = (2 * W) >> 3;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= rows * chunks_per_row) return;
+    const long row = gid / chunks_per_row;
+    const int c8 = (int)(gid - row * chunks_per_row);
+    const int col = c8 * 8;                 // column inside [q | k]
+    const int s = (int)(row % S);
+    const int within = col % hd;            // column inside the head (same for q and k thirds: W % hd == 0)
+    bf16_t* ptr = qkv + row * ld + col;
+    uint4 raw = *(const uint4*)ptr;
+    uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
+    const float2* t = cs + (long)s * (hd >> 1) + (within >> 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x0 = bf16_to_f32((bf16_t)(wds[j] & 0xffff));
+        const float x1 = bf16_to_f32((bf16_t)(wds[j] >> 16));
+        const float2 c = t[j];
+        const float y0 = x0 * c.x - x1 * c.y;
+        const float y1 = x1 * c.x + x0 * c.y;
+        wds[j] = pack_bf16x2(y0, y1);
+    }
+    *(uint4*)ptr = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+}
+int launch_rope(bf16_t* qkv, long ld, const float2* cs, int rows, int S, int W, int heads, hipStream_t st) {
+    const int hd = W / heads;
+    REVO_REQUIRE(hd % 8 == 0 && W % 8 == 0 && ld % 8 == 0, "rope: head_dim, W and ld must be multiples of 8");
+    const long total = (long)rows * ((2 * W) / 8);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, qkv, ld, cs, (long)rows, S,
+                       W, hd);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------- conversions ----
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, long ld_src,
+                                                          bf16_t* __restrict__ dst, long ld_dst, long rows, int cols) {
+    const int chunks = (int)(ld_dst >> 3);
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= rows * chunks) return;
+    const long r = gid / chunks;
+    const int c = (int)(gid - r * chunks) * 8;
+    float v[8];
+    const float* s = src + r * ld_src + c;
+    if (c + 8 <= cols && ((((uintptr_t)s) & 15) == 0)) {
+        const f32x4 a = *(const f32x4*)s, b = *(const f32x4*)(s + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+        v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (c + j < cols) ? s[j] : 0.f;
+    }
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]);
+    o.w = pack_bf16x2(v[6], v[7]);
+    *(uint4*)(dst + r * ld_dst + c) = o;
+}
+int launch_f32_to_bf16(const float* src, long ld_src, bf16_t* dst, long ld_dst, long rows, int cols, hipStream_t st) {
+    REVO_REQUIRE(ld_dst % 8 == 0 && ld_dst >= cols, "f32_to_bf16: bad destination stride");
+    const long total = rows * (ld_dst / 8);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, ld_src, dst,
+                       ld_dst, rows, cols);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ void transpose_f32_to_bf16_kernel(const float* __restrict__ src, int rows, int cols,
+                                             bf16_t* __restrict__ dst, long ld_dst) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = by + j, c = bx + tx;
+        tile[j][tx] = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int orow = bx + j, ocol = by + tx;   // dst[c][r]
+        if (orow < cols && ocol < rows) dst[(long)orow * ld_dst + ocol] = f32_to_bf16(tile[tx][j]);
+    }
+}
+int launch_transpose_f32_to_bf16(const float* src, int rows, int cols, bf16_t* dst, long ld_dst, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(transpose_f32_to_bf16_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, src,
+                       rows, cols, dst, ld_dst);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// --------------------------------------------------------- L2 normalise ----
+// e / ||e||_2 with no epsilon (core_system.py:447); an all-zero row stays zero
+// (qdrant local mode guards the division the same way).
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ src, long ld_src,
+                                                          float* __restrict__ dst_f32, long ld_f32,
+                                                          bf16_t* __restrict__ dst_bf16, long ld_bf16, long rows,
+                                                          int D) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* s = src + row * ld_src;
+    float q = 0.f;
+    for (int c = lane; c < D; c += 64) q = fmaf(s[c], s[c], q);
+    q = wave_sum(q);
+    const float inv = q > 0.f ? 1.0f / sqrtf(q) : 1.0f;
+    for (int c = lane; c < D; c += 64) {
+        const float y = s[c] * inv;
+        if (dst_f32) dst_f32[row * ld_f32 + c] = y;
+        if (dst_bf16) dst_bf16[row * ld_bf16 + c] = f32_to_bf16(y);
+    }
+}
+int launch_l2norm_rows(const float* src, long ld_src, float* dst_f32, long ld_f32, bf16_t* dst_bf16, long ld_bf16,
+                       long rows, int D, hipStream_t st) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, src, ld_src, dst_f32,
+                       ld_f32, dst_bf16, ld_bf16, rows, D);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace revo

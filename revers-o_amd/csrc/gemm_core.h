@@ -1,0 +1,104 @@
+// bf16 MFMA GEMM main loop shared by the ViT linear layers (gemm.hip) and the
+// query x gallery scan (topk.hip):   C[M,N] = A[M,K] . B[N,K]^T
+// Both operands are K-contiguous (activations [rows][K], nn.Linear weights
+// [out][in], gallery rows [N][D]), so one LDS image serves both.
+//
+// Tile: BM x BN x 64 per workgroup of 256 threads (4 waves), fp32 accumulate in
+// v_mfma_f32_16x16x32_bf16.  Staging is direct global->LDS DMA
+// (global_load_lds_dwordx4): one wave-instruction lands 8 tile rows x 128 B.
+// The LDS image is lane-linear (DMA constraint); bank conflicts of the
+// ds_read_b128 fragment reads are removed by XOR-swizzling the 16-byte chunk
+// index with ((row>>1)&7) on the *global source* address and again on the read
+// (cdna_hip_programming.md rule 21).
+#pragma once
+#include "common.h"
+
+namespace revo {
+
+constexpr int GEMM_BK = 64;        // bf16 elements per K-step: one 128-B LDS row
+constexpr int GEMM_THREADS = 256;
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each
+// XCD a contiguous run of tile ids.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// Per-thread source pointers for one operand tile of ROWS rows.
+template <int ROWS>
+struct TileLoader {
+    static constexpr int NI = ROWS / 32;   // DMA instructions per wave per K-step
+    const bf16_t* src[NI];
+    // rows >= nrows re-read the last valid row: their products are discarded by the epilogue
+    __device__ __forceinline__ void init(const bf16_t* base, long ld, int row0, int nrows, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = (wave * NI + i) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gr = row0 + r;
+            gr = gr < nrows ? gr : nrows - 1;
+            src[i] = base + (long)gr * ld + c * 8;
+        }
+    }
+    __device__ __forceinline__ void issue(char* lds_tile, int k0, int wave) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) glds16(src[i] + k0, lds_tile + (wave * NI + i) * 1024);
+    }
+};
+
+// One 64-deep K-step on the wave's (MF*16) x (NF*16) sub-tile.
+// acc[m][n] holds C^T fragments: lane l owns row (m*16 + (l&15)) and the four
+// consecutive columns n*16 + (l>>4)*4 + {0..3}  (A and B swapped in the MFMA so
+// that every lane's four results are adjacent in a C row).
+template <int MF, int NF>
+__device__ __forceinline__ void mma_kstep(const char* ldsA, const char* ldsB, int rowA0, int rowB0, int lane,
+                                          f32x4 (&acc)[MF][NF]) {
+    const int sw = (lane >> 1) & 7;
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int ch = ((kk * 4 + lq) ^ sw) * 16;
+        bf16x8 a[MF], b[NF];
+#pragma unroll
+        for (int m = 0; m < MF; ++m) a[m] = *(const bf16x8*)(ldsA + (rowA0 + m * 16 + lr) * 128 + ch);
+#pragma unroll
+        for (int n = 0; n < NF; ++n) b[n] = *(const bf16x8*)(ldsB + (rowB0 + n * 16 + lr) * 128 + ch);
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+            for (int n = 0; n < NF; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[n], a[m], acc[m][n], 0, 0, 0);
+    }
+}
+
+// Double-buffered K loop: DMA of step t+1 is in flight while step t is multiplied.
+// smem: 2 x (BM + BN) x 128 bytes.  K % 64 == 0.
+template <int BM, int BN, int MF, int NF>
+__device__ __forceinline__ void gemm_mainloop(const TileLoader<BM>& la, const TileLoader<BN>& lb, char* smem, int K,
+                                              int wave, int lane, int rowA0, int rowB0, f32x4 (&acc)[MF][NF]) {
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+    const int nt = K / GEMM_BK;
+    la.issue(smem, 0, wave);
+    lb.issue(smem + A_BYTES, 0, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        char* cur = smem + (t & 1) * STAGE;
+        char* nxt = smem + ((t + 1) & 1) * STAGE;
+        if (t + 1 < nt) {
+            la.issue(nxt, (t + 1) * GEMM_BK, wave);
+            lb.issue(nxt + A_BYTES, (t + 1) * GEMM_BK, wave);
+        }
+        mma_kstep<MF, NF>(cur, cur + A_BYTES, rowA0, rowB0, lane, acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+}  // namespace revo

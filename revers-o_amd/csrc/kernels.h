@@ -1,0 +1,78 @@
+// Internal launcher interface of librevo (not part of the C ABI; see include/revo.h).
+#pragma once
+#include "common.h"
+
+namespace revo {
+
+// ---------------------------------------------------------------- GEMM -----
+enum GemmEpi {
+    EPI_BF16 = 0,       // C bf16 = acc + bias
+    EPI_BF16_GELU = 1,  // C bf16 = gelu_erf(acc + bias)
+    EPI_RESID_F32 = 2,  // C f32 += gamma * (acc + bias)        (residual stream, in place)
+    EPI_F32 = 3,        // C f32 = acc + bias
+    EPI_PATCH = 4,      // C f32[(m/G2)*S + cls + m%G2] = acc + pos[cls + m%G2]
+};
+
+struct GemmArgs {
+    const bf16_t* A; long lda;   // [M][lda]  activations, K-contiguous
+    const bf16_t* B; long ldb;   // [N][ldb]  weights (nn.Linear layout), K-contiguous
+    int M, N, K;
+    void* C; long ldc;
+    const float* bias;           // [N] or null
+    const float* gamma;          // [N] LayerScale or null   (EPI_RESID_F32)
+    const float* pos;            // [S][N]                    (EPI_PATCH)
+    int S, G2, cls;              //                           (EPI_PATCH)
+};
+int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
+
+// --------------------------------------------------------- elementwise -----
+// out = LayerNorm(x) * w + b over rows of width W (fp32 statistics, two-pass).
+int launch_layernorm(const float* x, long ldx, const float* w, const float* b, float eps, int rows, int W,
+                     void* out, long ldo, int out_is_bf16, hipStream_t st);
+// images NCHW (u8: normalised (v/255-0.5)/0.5 on the fly; f32: already normalised)
+// -> im2col matrix [B*G*G][ld] bf16, k = c*P*P + py*P + px, zero padded to ld.
+int launch_patchify(const void* images, int is_u8, int B, int img, int P, bf16_t* out, long ld, hipStream_t st);
+// x[b*S + 0][:] = cls + pos[0]
+int launch_cls_rows(float* x, long ldx, const float* cls, const float* pos, int B, int S, int W, hipStream_t st);
+// in-place interleaved-pair rotation of the q and k thirds of qkv [rows][3W]
+int launch_rope(bf16_t* qkv, long ld, const float2* cs, int rows, int S, int W, int heads, hipStream_t st);
+// dst[r][0..cols) = bf16(src[r][0..cols)), dst[r][cols..ld_dst) = 0
+int launch_f32_to_bf16(const float* src, long ld_src, bf16_t* dst, long ld_dst, long rows, int cols, hipStream_t st);
+// row-wise L2 normalise; writes fp32 and/or bf16 copies (either may be null)
+int launch_l2norm_rows(const float* src, long ld_src, float* dst_f32, long ld_f32, bf16_t* dst_bf16, long ld_bf16,
+                       long rows, int D, hipStream_t st);
+// dst[n][k] = src[k][n]   (fp32 -> bf16 transposed copy; visual.proj is stored [W][D])
+int launch_transpose_f32_to_bf16(const float* src, int rows, int cols, bf16_t* dst, long ld_dst, hipStream_t st);
+
+// ----------------------------------------------------------- attention -----
+// qkv [B*S][ld] bf16 (q | k | v thirds, heads contiguous inside a third) -> out [B*S][ldo] bf16
+int launch_attention(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, int hd, hipStream_t st);
+// single-probe attention pool: q [W] fp32 (already projected and scaled), kv [B*S][ld] bf16 (k | v halves)
+int launch_pool_attention(const float* q, const bf16_t* kv, long ld, bf16_t* out, long ldo, int B, int S, int H,
+                          int hd, hipStream_t st);
+
+// ---------------------------------------------------------------- top-k ----
+struct ScanArgs {
+    const bf16_t* Qb; long ldq;   // [Q][D] bf16 normalised queries
+    const bf16_t* Gb; long ldg;   // [N][D] bf16 normalised gallery rows
+    int Q; long N; int D;
+    int ksel;                     // candidates kept per query (32 or 64)
+    int splits;                   // gallery splits (grid.y); part is [Q][splits][ksel]
+    uint64_t* part;               // out: candidate keys, sorted best-first, 0 = empty
+};
+int topk_scan_workspace_splits(int Q, long N);
+int launch_topk_scan(const ScanArgs& a, hipStream_t st);
+// merge `splits` sorted candidate lists per query into one list of ksel keys (in place into part[q][0])
+int launch_topk_reduce(uint64_t* part, int Q, int splits, int ksel, hipStream_t st);
+// exact fp32 re-score of the ksel candidates of each query, final order (score desc, index asc),
+// threshold cut, write k results.  Gf may be null: then the bf16-scan scores are returned.
+int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const float* Qf, long ldqf, const float* Gf,
+                       long ldgf, int D, int Q, int k, int has_thr, float thr, long idx_offset, float* out_scores,
+                       long long* out_idx, int* out_counts, hipStream_t st);
+// all-padding result for an empty gallery
+int launch_topk_fill_empty(float* s, long long* i, int* c, int Q, int k, hipStream_t st);
+// merge P per-shard result lists [P][Q][k] -> [Q][k]
+int launch_topk_merge(const float* scores, const long long* idx, int P, int Q, int k, int has_thr, float thr,
+                      float* out_scores, long long* out_idx, int* out_counts, hipStream_t st);
+
+}  // namespace revo

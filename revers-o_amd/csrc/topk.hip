@@ -1,0 +1,360 @@
+// Gallery cosine similarity + top-k (K12/K13/K14 of SURVEY.md §2b): replaces
+// qdrant-client local mode's  scores = G @ q ; argsort ; threshold walk  behind
+// vector_db.search (reference call site core_system.py:659-664).
+//
+//   scan    bf16 MFMA  Q x G^T with the per-query candidate selection fused into
+//           the epilogue: the Q x N score matrix never reaches memory.  Every
+//           wave owns 32 query rows of the 128-row tile and keeps their current
+//           best KSEL candidates as sorted 64-bit keys in LDS; a score is looked
+//           at again only if it reaches the row's running KSEL-th best.
+//   reduce  merges the per-split candidate lists of a query (bitonic merge).
+//   finish  re-scores the KSEL survivors exactly in fp32 against the fp32 master
+//           rows, orders them (score desc, index asc), applies the threshold and
+//           writes k results.
+//   merge   combines per-shard results (multi-GPU, after the RCCL all-gather).
+#include "gemm_core.h"
+#include "kernels.h"
+
+namespace revo {
+
+// --------------------------------------------------- wave-level sorting ----
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, m, 64), hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_up1_u64(uint64_t v) {
+    const uint32_t lo = __shfl_up((uint32_t)v, 1, 64), hi = __shfl_up((uint32_t)(v >> 32), 1, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ float readlane_f32(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+// sort the 64 lane values, best (largest key) in lane 0
+__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t v, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const uint64_t o = shfl_xor_u64(v, j);
+            const bool desc = (lane & k2) == 0;
+            const bool lower = (lane & j) == 0;
+            const bool take_max = (lower == desc);
+            v = take_max ? (v > o ? v : o) : (v < o ? v : o);
+        }
+    }
+    return v;
+}
+// v is bitonic across the wave -> sorted, best in lane 0
+__device__ __forceinline__ uint64_t wave_bitonic_merge_desc(uint64_t v, int lane) {
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const uint64_t o = shfl_xor_u64(v, j);
+        v = ((lane & j) == 0) ? (v > o ? v : o) : (v < o ? v : o);
+    }
+    return v;
+}
+
+// ------------------------------------------------------------- the scan ----
+// Insert cand into the sorted (best-first) list of one row; returns the row's
+// new admission score (score of the KSEL-th entry, or -inf while the list is
+// not full).  All 64 lanes execute; lanes >= KSEL are passive.
+template <int KSEL>
+__device__ __forceinline__ float list_insert(uint64_t* list, uint64_t cand, int lane, float tau_old) {
+    const bool in = lane < KSEL;
+    const uint64_t e = in ? list[lane] : 0ull;
+    const int pos = __popcll(__ballot(in && e > cand));
+    if (pos >= KSEL) return tau_old;
+    const uint64_t prev = shfl_up1_u64(e);
+    const uint64_t ne = lane < pos ? e : (lane == pos ? cand : prev);
+    if (in) list[lane] = ne;
+    const uint64_t last = readlane_u64(ne, KSEL - 1);
+    return last ? key_score(last) : -INFINITY;
+}
+
+constexpr int SCAN_BM = 128, SCAN_BN = 128;
+constexpr int SCAN_GEMM_LDS = 2 * (SCAN_BM + SCAN_BN) * 128;
+
+template <int KSEL>
+__global__ __launch_bounds__(GEMM_THREADS) void topk_scan_kernel(ScanArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MF = 2, NF = 8;   // wave tile 32 x 128
+    uint64_t* lists = (uint64_t*)(smem + SCAN_GEMM_LDS);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int q0 = blockIdx.x * SCAN_BM;
+    const int sp = blockIdx.y;
+
+    uint64_t* mylists = lists + (wave * 32) * KSEL;
+    for (int i = lane; i < 32 * KSEL; i += 64) mylists[i] = 0ull;
+
+    float tau[MF];
+#pragma unroll
+    for (int m = 0; m < MF; ++m) tau[m] = (q0 + wave * 32 + m * 16 + lr) < p.Q ? -INFINITY : INFINITY;
+
+    const long tiles = (p.N + SCAN_BN - 1) / SCAN_BN;
+    const long per = (tiles + p.splits - 1) / p.splits;
+    const long t0 = sp * per;
+    const long t1 = (t0 + per) < tiles ? (t0 + per) : tiles;
+
+    TileLoader<SCAN_BM> la;
+    la.init(p.Qb, p.ldq, q0, p.Q, wave, lane);
+
+    for (long t = t0; t < t1; ++t) {
+        const long n0 = t * SCAN_BN;
+        TileLoader<SCAN_BN> lb;
+        {
+            // gallery rows are addressed with a 64-bit base and a 32-bit in-tile row
+            const long left = p.N - n0;
+            lb.init(p.Gb + n0 * p.ldg, p.ldg, 0, left < SCAN_BN ? (int)left : SCAN_BN, wave, lane);
+        }
+        f32x4 acc[MF][NF];
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+            for (int n = 0; n < NF; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gemm_mainloop<SCAN_BM, SCAN_BN, MF, NF>(la, lb, smem, p.D, wave, lane, wave * 32, 0, acc);
+
+        const int nvalid = (p.N - n0) < SCAN_BN ? (int)(p.N - n0) : SCAN_BN;
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int n = 0; n < NF; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = n * 16 + lq * 4 + j;
+                    if (nvalid < SCAN_BN && col >= nvalid) acc[m][n][j] = -INFINITY;
+                    mx = fmaxf(mx, acc[m][n][j]);
+                }
+            if (__ballot(mx >= tau[m]) == 0ull) continue;
+#pragma unroll
+            for (int n = 0; n < NF; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[m][n][j];
+                    unsigned long long mask = __ballot(v >= tau[m] && v > -INFINITY);
+                    while (mask) {
+                        const int l = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        const float sv = readlane_f32(v, l);
+                        const uint32_t gidx = (uint32_t)(n0 + n * 16 + (l >> 4) * 4 + j);
+                        const int rloc = m * 16 + (l & 15);
+                        const float cur = readlane_f32(tau[m], l);
+                        const float nt = list_insert<KSEL>(mylists + rloc * KSEL, make_key(sv, gidx), lane, cur);
+                        if (lr == (l & 15)) tau[m] = nt;
+                    }
+                }
+        }
+    }
+    // publish this split's candidates: part[q][split][KSEL]
+    for (int rloc = 0; rloc < 32; ++rloc) {
+        const int q = q0 + wave * 32 + rloc;
+        if (q >= p.Q) break;
+        if (lane < KSEL) p.part[((long)q * p.splits + sp) * KSEL + lane] = mylists[rloc * KSEL + lane];
+    }
+}
+
+// Splits chosen so that (query tiles x splits) fills the 256 CUs about once
+// or twice (one 96-128 KB workgroup per CU), while each split keeps enough
+// tiles to amortise the early, insertion-heavy part of the scan.
+int topk_scan_workspace_splits(int Q, long N) {
+    const int qtiles = (Q + SCAN_BM - 1) / SCAN_BM;
+    const long tiles = (N + SCAN_BN - 1) / SCAN_BN;
+    if (qtiles <= 0 || tiles <= 0) return 1;
+    const int cus = 256;
+    int best = 1;
+    double best_eff = -1.0;
+    for (int s = 1; s <= 256; ++s) {
+        if (s > tiles) break;
+        const long per = (tiles + s - 1) / s;
+        if (s > 1 && per < 16) break;                 // keep the insertion-heavy start amortised
+        const long wgs = (long)qtiles * s;
+        const long rounds = (wgs + cus - 1) / cus;
+        const double eff = (double)wgs / (double)(rounds * cus);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
+    }
+    return best;
+}
+
+int launch_topk_scan(const ScanArgs& a, hipStream_t st) {
+    REVO_REQUIRE(a.D % GEMM_BK == 0, "search: D must be a multiple of 64");
+    REVO_REQUIRE(a.ksel == 32 || a.ksel == 64, "search: ksel must be 32 or 64");
+    REVO_REQUIRE(a.N < (1ll << 32), "search: a shard holds at most 2^32 rows");
+    REVO_REQUIRE(a.ldq % 8 == 0 && a.ldg % 8 == 0, "search: row strides must be multiples of 8");
+    if (a.Q <= 0 || a.N <= 0) return 0;
+    dim3 grid((a.Q + SCAN_BM - 1) / SCAN_BM, a.splits), block(GEMM_THREADS);
+    if (a.ksel == 32) {
+        constexpr int LDS = SCAN_GEMM_LDS + SCAN_BM * 32 * 8;
+        static bool done = false;
+        if (!done) {
+            REVO_HIP_CHECK(hipFuncSetAttribute((const void*)topk_scan_kernel<32>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            done = true;
+        }
+        hipLaunchKernelGGL((topk_scan_kernel<32>), grid, block, LDS, st, a);
+    } else {
+        constexpr int LDS = SCAN_GEMM_LDS + SCAN_BM * 64 * 8;
+        static bool done = false;
+        if (!done) {
+            REVO_HIP_CHECK(hipFuncSetAttribute((const void*)topk_scan_kernel<64>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            done = true;
+        }
+        hipLaunchKernelGGL((topk_scan_kernel<64>), grid, block, LDS, st, a);
+    }
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ----------------------------------------------------------- the reduce ----
+template <int KSEL>
+__global__ __launch_bounds__(256) void topk_reduce_kernel(uint64_t* part, int Q, int splits) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    uint64_t* base = part + (long)q * splits * KSEL;
+    uint64_t run = lane < KSEL ? base[lane] : 0ull;
+    for (int s = 1; s < splits; ++s) {
+        const uint64_t* o = base + (long)s * KSEL;
+        uint64_t v;
+        if (KSEL == 32) {
+            v = lane < 32 ? run : o[63 - lane];          // best-first then worst-first: bitonic
+        } else {
+            const uint64_t x = o[63 - lane];
+            v = run > x ? run : x;                        // top 64 of both, bitonic
+        }
+        v = wave_bitonic_merge_desc(v, lane);
+        run = lane < KSEL ? v : 0ull;
+    }
+    if (lane < KSEL) base[lane] = run;
+}
+int launch_topk_reduce(uint64_t* part, int Q, int splits, int ksel, hipStream_t st) {
+    if (Q <= 0 || splits <= 1) return 0;
+    dim3 grid((Q + 3) / 4), block(256);
+    if (ksel == 32) hipLaunchKernelGGL((topk_reduce_kernel<32>), grid, block, 0, st, part, Q, splits);
+    else hipLaunchKernelGGL((topk_reduce_kernel<64>), grid, block, 0, st, part, Q, splits);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ----------------------------------------------------------- the finish ----
+__global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __restrict__ part, long part_stride, int ksel,
+                                                          const float* __restrict__ Qf, long ldqf,
+                                                          const float* __restrict__ Gf, long ldgf, int D, int Q, int k,
+                                                          int has_thr, float thr, long idx_offset,
+                                                          float* __restrict__ out_scores,
+                                                          long long* __restrict__ out_idx, int* __restrict__ out_counts) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const uint64_t key = lane < ksel ? part[(long)q * part_stride + lane] : 0ull;
+    const bool valid = key != 0ull;
+    const uint32_t idx = key_index(key);
+    float score = valid ? key_score(key) : -INFINITY;
+    if (Gf) {
+        // exact fp32 dot of the normalised fp32 query and gallery rows; fixed summation
+        // order: per-lane fma chain over elements lane*4 + 256*i, then a butterfly.
+        const float* qr = Qf + (long)q * ldqf;
+        const unsigned long long vmask = __ballot(valid);
+        const int nv = __popcll(vmask);   // valid entries are a prefix (lists are best-first)
+        for (int cnd = 0; cnd < nv; ++cnd) {
+            const uint32_t gi = __builtin_amdgcn_readlane(idx, cnd);
+            const float* gr = Gf + (long)gi * ldgf;
+            float acc = 0.f;
+            for (int c = lane * 4; c < D; c += 256) {
+                const f32x4 a = *(const f32x4*)(qr + c), b = *(const f32x4*)(gr + c);
+                acc = fmaf(a[0], b[0], acc);
+                acc = fmaf(a[1], b[1], acc);
+                acc = fmaf(a[2], b[2], acc);
+                acc = fmaf(a[3], b[3], acc);
+            }
+            acc = wave_sum(acc);
+            if (lane == cnd) score = acc;
+        }
+    }
+    uint64_t k2 = valid ? make_key(score, idx) : 0ull;
+    k2 = wave_sort_desc(k2, lane);
+    const bool ok = k2 != 0ull && lane < k && (!has_thr || key_score(k2) >= thr);
+    const int cnt = __popcll(__ballot(ok));   // passing entries are a prefix of the sorted order
+    if (lane < k) {
+        out_scores[(long)q * k + lane] = ok ? key_score(k2) : -INFINITY;
+        out_idx[(long)q * k + lane] = ok ? (long long)key_index(k2) + idx_offset : -1ll;
+    }
+    if (lane == 0) out_counts[q] = cnt;
+}
+int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const float* Qf, long ldqf, const float* Gf,
+                       long ldgf, int D, int Q, int k, int has_thr, float thr, long idx_offset, float* out_scores,
+                       long long* out_idx, int* out_counts, hipStream_t st) {
+    REVO_REQUIRE(k >= 1 && k <= ksel && ksel <= 64, "search: need 1 <= k <= ksel <= 64");
+    REVO_REQUIRE(!Gf || (D % 4 == 0 && ldqf % 4 == 0 && ldgf % 4 == 0), "search: fp32 rows must be 16-byte aligned");
+    if (Q <= 0) return 0;
+    hipLaunchKernelGGL(topk_finish_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, part, part_stride, ksel, Qf, ldqf, Gf,
+                       ldgf, D, Q, k, has_thr, thr, idx_offset, out_scores, out_idx, out_counts);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------- empty-gallery result ----
+__global__ void topk_fill_empty_kernel(float* s, long long* i, int* c, int Q, int k) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < Q * k) { s[t] = -INFINITY; i[t] = -1ll; }
+    if (t < Q) c[t] = 0;
+}
+int launch_topk_fill_empty(float* s, long long* i, int* c, int Q, int k, hipStream_t st) {
+    const int n = Q * k;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(topk_fill_empty_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s, i, c, Q, k);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------ the merge ----
+// [P][Q][k] per-shard results (global indices, -inf/-1 padded) -> [Q][k].
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ scores,
+                                                         const long long* __restrict__ idx, int P, int Q, int k,
+                                                         int has_thr, float thr, float* __restrict__ out_scores,
+                                                         long long* __restrict__ out_idx, int* __restrict__ out_counts) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const int total = P * k;
+    uint64_t run = 0ull;
+    for (int base = 0; base < total; base += 64) {
+        const int e = base + lane;
+        uint64_t v = 0ull;
+        if (e < total) {
+            const int pz = e / k, j = e - pz * k;
+            const long off = ((long)pz * Q + q) * k + j;
+            const long long gi = idx[off];
+            if (gi >= 0) v = make_key(scores[off], (uint32_t)gi);
+        }
+        v = wave_sort_desc(v, lane);
+        const uint64_t rev = shfl_xor_u64(v, 63);       // chunk worst-first
+        const uint64_t mx = run > rev ? run : rev;      // top 64 of both, bitonic
+        run = wave_bitonic_merge_desc(mx, lane);
+    }
+    const bool ok = run != 0ull && lane < k && (!has_thr || key_score(run) >= thr);
+    const int cnt = __popcll(__ballot(ok));
+    if (lane < k) {
+        out_scores[(long)q * k + lane] = ok ? key_score(run) : -INFINITY;
+        out_idx[(long)q * k + lane] = ok ? (long long)key_index(run) : -1ll;
+    }
+    if (lane == 0) out_counts[q] = cnt;
+}
+int launch_topk_merge(const float* scores, const long long* idx, int P, int Q, int k, int has_thr, float thr,
+                      float* out_scores, long long* out_idx, int* out_counts, hipStream_t st) {
+    REVO_REQUIRE(k >= 1 && k <= 64, "merge: need 1 <= k <= 64");
+    REVO_REQUIRE(P >= 1, "merge: need at least one part");
+    if (Q <= 0) return 0;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, scores, idx, P, Q, k, has_thr, thr,
+                       out_scores, out_idx, out_counts);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace revo

@@ -1,0 +1,261 @@
+"""Host side of the hot path: ``embed()`` / ``search()`` over librevo's C ABI.
+
+Python owns orchestration only (device tensors, streams, weight hand-over); every
+kernel on the path is HIP inside ``librevo.so``.  The entry points mirror what
+the reference does at
+
+* ``core_system.py:431-455`` ``process_image_direct_pe``  ->  :meth:`VitEngine.embed`
+* ``core_system.py:596-622`` collection create + upsert     ->  :class:`Gallery`
+* ``core_system.py:650-664`` ``search_similar`` / ``vector_db.search``  ->  :meth:`Gallery.search`
+"""
+import ctypes as C
+import json
+import threading
+
+import torch
+
+from . import _lib
+from .config import PEConfig, get_config
+from .weights import check_state_dict, synth_weights
+
+IMAGE_F32 = 0
+IMAGE_U8 = 1
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise _lib.RevoError(f"{name} must be a device tensor (the hot path has no CPU fallback)")
+
+
+class VitEngine:
+    """A PE vision tower resident on one GPU (weights bf16, fp32 residual stream)."""
+
+    def __init__(self, cfg: PEConfig, state_dict, device=0, max_batch=64):
+        self.cfg = cfg
+        self.device = torch.device("cuda", device) if not isinstance(device, torch.device) else device
+        self.max_batch = int(max_batch)
+        self._lock = threading.Lock()
+        lib = _lib.load()
+        check_state_dict(cfg, state_dict)
+        names = sorted(state_dict)
+        keep = []          # keep converted tensors alive until create returns
+        arr = (_lib.Tensor * len(names))()
+        for i, n in enumerate(names):
+            t = state_dict[n].detach().to(torch.float32).contiguous()
+            keep.append(t)
+            arr[i].name = n.encode()
+            arr[i].data = t.data_ptr()
+            arr[i].numel = t.numel()
+        c = _lib.VitCfg(cfg.image_size, cfg.patch_size, cfg.width, cfg.layers, cfg.heads, cfg.mlp_dim, cfg.out_dim,
+                        cfg.pool_heads, int(cfg.use_cls), int(cfg.use_ls), cfg.ln_eps, cfg.rope_theta)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()
+            _lib.check(lib.revo_vit_create(C.byref(c), arr, len(names), self.device.index or 0, self.max_batch,
+                                           C.byref(h)), "revo_vit_create")
+        self._h = h
+        self._lib = lib
+
+    @classmethod
+    def synthetic(cls, name_or_cfg="PE-Core-L14-336", seed=0, device=0, max_batch=64, **kw):
+        cfg = name_or_cfg if isinstance(name_or_cfg, PEConfig) else get_config(name_or_cfg)
+        dev = torch.device("cuda", device)
+        sd = synth_weights(cfg, seed=seed, device=dev, **kw)
+        return cls(cfg, sd, device=device, max_batch=max_batch)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.revo_vit_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the embed entry point ------------------------------------------------
+    def embed(self, images, normalize=True, out=None):
+        """images: uint8 or float32 ``[B,3,H,W]`` device tensor at the model
+        resolution (float input already normalised to [-1,1], i.e. what
+        ``self.preprocess`` yields at core_system.py:439).  Returns fp32
+        ``[B, out_dim]`` on the device, L2-normalised (core_system.py:447)."""
+        _require_cuda(images, "images")
+        cfg = self.cfg
+        if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != cfg.image_size or images.shape[3] != cfg.image_size:
+            raise ValueError(f"images must be [B,3,{cfg.image_size},{cfg.image_size}], got {tuple(images.shape)}")
+        if images.dtype == torch.uint8:
+            kind = IMAGE_U8
+        elif images.dtype == torch.float32:
+            kind = IMAGE_F32
+        else:
+            raise ValueError("images must be uint8 or float32")
+        images = images.contiguous()
+        B = images.shape[0]
+        if out is None:
+            out = torch.empty((B, cfg.out_dim), dtype=torch.float32, device=images.device)
+        with self._lock, torch.cuda.device(images.device):
+            st = _lib.current_stream()
+            for s in range(0, B, self.max_batch):
+                e = min(B, s + self.max_batch)
+                _lib.check(self._lib.revo_vit_forward(self._h, _lib.ptr(images[s:e]), kind, e - s, _lib.ptr(out[s:e]),
+                                                      int(bool(normalize)), st), "revo_vit_forward")
+        return out
+
+    # -- parity-test hook -----------------------------------------------------
+    def residual_after(self, images, n_layers):
+        """fp32 residual stream [B, S, W] after ln_pre and the first n blocks."""
+        B = images.shape[0]
+        assert B <= self.max_batch
+        kind = IMAGE_U8 if images.dtype == torch.uint8 else IMAGE_F32
+        x = torch.empty((B, self.cfg.seq, self.cfg.width), dtype=torch.float32, device=images.device)
+        dummy = torch.empty((B, self.cfg.out_dim), dtype=torch.float32, device=images.device)
+        with self._lock, torch.cuda.device(images.device):
+            st = _lib.current_stream()
+            _lib.check(self._lib.revo_vit_set_debug_layers(self._h, int(n_layers)))
+            try:
+                _lib.check(self._lib.revo_vit_forward(self._h, _lib.ptr(images.contiguous()), kind, B, _lib.ptr(dummy),
+                                                      0, st), "revo_vit_forward")
+                _lib.check(self._lib.revo_vit_read_residual(self._h, B, _lib.ptr(x), st))
+            finally:
+                self._lib.revo_vit_set_debug_layers(self._h, -1)
+        return x
+
+
+class Gallery:
+    """Device-resident cosine gallery: normalised rows as bf16 (scan copy) plus an
+    fp32 master copy used for exact re-scoring and persistence."""
+
+    def __init__(self, dim, capacity, device=0, keep_f32=True):
+        self.dim = int(dim)
+        self.capacity = int(capacity)
+        self.device = torch.device("cuda", device) if not isinstance(device, torch.device) else device
+        self._lock = threading.Lock()
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.revo_gallery_create(self.dim, self.capacity, self.device.index or 0, int(keep_f32),
+                                                     C.byref(h)), "revo_gallery_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.revo_gallery_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._lib.revo_gallery_size(self._h))
+
+    def clear(self):
+        _lib.check(self._lib.revo_gallery_clear(self._h))
+
+    def add(self, vectors, normalize=True):
+        """Append fp32 rows [n, dim] (device or host tensor).  Rows are normalised
+        at insert like qdrant's COSINE collections (core_system.py:600-603)."""
+        v = vectors.detach().to(torch.float32).contiguous()
+        if v.dim() != 2 or v.shape[1] != self.dim:
+            raise ValueError(f"vectors must be [n, {self.dim}], got {tuple(v.shape)}")
+        start = len(self)
+        with self._lock, torch.cuda.device(self.device):
+            _lib.check(self._lib.revo_gallery_append(self._h, _lib.ptr(v), v.shape[0], int(bool(normalize)),
+                                                     int(v.is_cuda), _lib.current_stream()), "revo_gallery_append")
+            if v.is_cuda:
+                torch.cuda.current_stream().synchronize()   # v may be a temporary
+        return start
+
+    def read(self, start=0, n=None):
+        n = len(self) - start if n is None else n
+        out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream().synchronize()
+            _lib.check(self._lib.revo_gallery_read(self._h, start, n, _lib.ptr(out), 1), "revo_gallery_read")
+        return out
+
+    def search(self, queries, k=5, score_threshold=None, index_offset=0):
+        """queries: fp32 [Q, dim] device tensor.  Returns (scores [Q,k] fp32,
+        indices [Q,k] int64, counts [Q] int32), best first, padded with -inf/-1
+        past ``counts`` (the reference's ``limit`` / ``score_threshold`` semantics,
+        core_system.py:659-664)."""
+        _require_cuda(queries, "queries")
+        q = queries.detach().to(torch.float32).contiguous()
+        if q.dim() == 1:
+            q = q[None]
+        if q.shape[1] != self.dim:
+            raise ValueError(f"queries must be [Q, {self.dim}], got {tuple(q.shape)}")
+        Q = q.shape[0]
+        scores = torch.empty((Q, k), dtype=torch.float32, device=q.device)
+        idx = torch.empty((Q, k), dtype=torch.int64, device=q.device)
+        counts = torch.empty((Q,), dtype=torch.int32, device=q.device)
+        with self._lock, torch.cuda.device(q.device):
+            _lib.check(self._lib.revo_search_topk(
+                self._h, _lib.ptr(q), Q, int(k), int(score_threshold is not None),
+                float(score_threshold if score_threshold is not None else 0.0), int(index_offset),
+                _lib.ptr(scores), _lib.ptr(idx), _lib.ptr(counts), _lib.current_stream()), "revo_search_topk")
+        return scores, idx, counts
+
+
+def merge_topk(part_scores, part_indices, k, score_threshold=None):
+    """Merge per-shard results [P,Q,k] (device) into [Q,k]; K14."""
+    _require_cuda(part_scores, "part_scores")
+    P, Q, kk = part_scores.shape
+    assert kk == k
+    ps = part_scores.contiguous()
+    pi = part_indices.contiguous()
+    scores = torch.empty((Q, k), dtype=torch.float32, device=ps.device)
+    idx = torch.empty((Q, k), dtype=torch.int64, device=ps.device)
+    counts = torch.empty((Q,), dtype=torch.int32, device=ps.device)
+    lib = _lib.load()
+    with torch.cuda.device(ps.device):
+        _lib.check(lib.revo_topk_merge(_lib.ptr(ps), _lib.ptr(pi), P, Q, k, int(score_threshold is not None),
+                                       float(score_threshold if score_threshold is not None else 0.0),
+                                       _lib.ptr(scores), _lib.ptr(idx), _lib.ptr(counts), _lib.current_stream()),
+                   "revo_topk_merge")
+    return scores, idx, counts
+
+
+# ---- module-level convenience API named by the north star ------------------
+_default_engine = None
+_default_gallery = None
+
+
+def set_default(engine=None, gallery=None):
+    global _default_engine, _default_gallery
+    if engine is not None:
+        _default_engine = engine
+    if gallery is not None:
+        _default_gallery = gallery
+
+
+def embed(images, engine=None):
+    eng = engine or _default_engine
+    if eng is None:
+        raise _lib.RevoError("embed(): no engine; create a VitEngine and call set_default(engine=...)")
+    return eng.embed(images)
+
+
+def search(queries, k=5, score_threshold=None, gallery=None):
+    gal = gallery or _default_gallery
+    if gal is None:
+        raise _lib.RevoError("search(): no gallery; create a Gallery and call set_default(gallery=...)")
+    return gal.search(queries, k=k, score_threshold=score_threshold)
+
+
+# ---- profiler ---------------------------------------------------------------
+def prof_enable(on=True):
+    _lib.load().revo_prof_enable(int(on))
+
+
+def prof_reset():
+    _lib.load().revo_prof_reset()
+
+
+def prof_report():
+    buf = C.create_string_buffer(1 << 16)
+    _lib.check(_lib.load().revo_prof_report(buf, len(buf)), "revo_prof_report")
+    return json.loads(buf.value.decode())

@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/revo.h
+declares (no compute calls: there is no GPU in this tier)."""
+import os
+import re
+
+import reverso_amd  # noqa: F401
+from reverso_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "revo.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(revo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"librevo.so does not export {n}"
+
+
+def test_binding_covers_header_exactly():
+    assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_version_and_error_string():
+    lib = _lib.load()
+    assert lib.revo_version() >= 100
+    assert isinstance(lib.revo_last_error(), bytes)
+
+
+def test_argument_validation_without_gpu():
+    # these return before touching the device
+    lib = _lib.load()
+    assert lib.revo_gallery_clear(None) != 0
+    assert b"null" in lib.revo_last_error()
+    assert lib.revo_gallery_size(None) == -1
+    assert lib.revo_vit_seq_len(None) == -1
+
+
+def test_product_has_no_oracle_import():
+    pkg = os.path.join(ROOT, "revers-o_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f), encoding="utf-8").read()
+                assert "import oracle" not in src and "from oracle" not in src, f

@@ -1,0 +1,113 @@
+"""Embed parity: the HIP forward (through the C ABI) against the CPU oracle and
+the committed golden vectors, layer by layer and end to end.
+
+Tolerances: the product computes matmuls in bf16 with fp32 accumulation and keeps
+the residual stream in fp32; the oracle is fp32 throughout.  Stated bounds:
+residual stream max|d| <= 3e-2 * max|x| per block, final embedding cosine >= 0.999
+and cosine scores against a gallery within 1e-3 (north_star)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import reverso_amd
+from reverso_amd import engine, weights
+from oracle import pe_vit
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden  # noqa: E402
+
+
+def _gold(name):
+    return np.load(os.path.join(HERE, "golden", name))
+
+
+@pytest.mark.parametrize("fname,cname", [("tiny_vit.npz", "PE-Tiny-T14-56"), ("tiny_vit_ls.npz", "PE-Tiny-T14-56-LS")])
+def test_tiny_vit_layer_by_layer(dev, fname, cname):
+    gold = _gold(fname)
+    cfg, sd, images = make_golden.tiny_case(cname)
+    eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=4)
+    img = images.to(dev)
+    for n, tap in ((0, "ln_pre"), (1, "block0"), (2, "block1")):
+        x = eng.residual_after(img, n).cpu().numpy()
+        ref = gold["tap_" + tap]
+        err = np.abs(x - ref).max()
+        assert err <= 3e-2 * np.abs(ref).max(), (tap, err, np.abs(ref).max())
+    emb = eng.embed(img).cpu().numpy()
+    ref = gold["embedding"]
+    cos = (emb * ref).sum(-1)
+    assert np.all(cos >= 0.999), cos
+    assert np.abs(np.linalg.norm(emb, axis=-1) - 1).max() < 1e-5
+    un = eng.embed(img, normalize=False).cpu().numpy()
+    refun = gold["tap_proj"]
+    assert np.abs(un - refun).max() <= 3e-2 * np.abs(refun).max()
+    eng.close()
+
+
+def test_uint8_input_matches_float_preprocess(dev):
+    cfg, sd, _ = make_golden.tiny_case()
+    eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=8)
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (5, 3, cfg.image_size, cfg.image_size), generator=g, dtype=torch.uint8)
+    e_u8 = eng.embed(u8.to(dev)).cpu()
+    e_f = eng.embed(pe_vit.preprocess_u8(u8).to(dev)).cpu()
+    assert torch.equal(e_u8, e_f)                       # same bf16 patch matrix either way
+    ref = pe_vit.embed(sd, cfg, pe_vit.preprocess_u8(u8))
+    assert ((e_u8 * ref).sum(-1) >= 0.999).all()
+    # batching: max_batch chunks and batch-1 calls give identical rows
+    eng2 = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=2)
+    e2 = eng2.embed(u8.to(dev)).cpu()
+    assert torch.equal(e2, e_u8)
+    e1 = torch.cat([eng.embed(u8[i:i + 1].to(dev)).cpu() for i in range(5)])
+    assert torch.equal(e1, e_u8)
+    eng.close()
+    eng2.close()
+
+
+def test_b16_single_block_golden(dev):
+    gold = _gold("b16_block.npz")
+    cfg, sd, images = make_golden.b16_block_case()
+    eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=1)
+    rows = gold["rows"].tolist()
+    x0 = eng.residual_after(images.to(dev), 0).cpu().numpy()[0, rows]
+    x1 = eng.residual_after(images.to(dev), 1).cpu().numpy()[0, rows]
+    assert np.abs(x0 - gold["ln_pre"]).max() <= 3e-2 * np.abs(gold["ln_pre"]).max()
+    assert np.abs(x1 - gold["block0"]).max() <= 3e-2 * np.abs(gold["block0"]).max()
+    emb = eng.embed(images.to(dev)).cpu().numpy()
+    assert (emb * gold["embedding"]).sum() >= 0.999
+    eng.close()
+
+
+def test_b16_full_depth_vs_oracle(dev):
+    """BASELINE.json configs[0] model (PE-Core-B16-224), 3 images, all 12 blocks."""
+    cfg = reverso_amd.get_config("PE-Core-B16-224")
+    sd = weights.synth_weights(cfg, seed=0, randomize_affine=True)
+    g = torch.Generator().manual_seed(1234)
+    u8 = torch.randint(0, 256, (3, 3, 224, 224), generator=g, dtype=torch.uint8)
+    ref = pe_vit.embed(sd, cfg, pe_vit.preprocess_u8(u8))
+    eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=4)
+    emb = eng.embed(u8.to(dev)).cpu()
+    cos = (emb * ref).sum(-1)
+    assert (cos >= 0.999).all(), cos
+    # cosine scores of the embeddings against a fixed random gallery agree to 1e-3
+    gal = torch.nn.functional.normalize(torch.randn(2000, cfg.out_dim, generator=g), dim=-1)
+    assert ((emb @ gal.T) - (ref @ gal.T)).abs().max().item() <= 1e-3
+    eng.close()
+
+
+def test_embed_rejects_bad_input(dev):
+    cfg, sd, _ = make_golden.tiny_case()
+    eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=2)
+    with pytest.raises(ValueError):
+        eng.embed(torch.zeros(1, 3, 64, 64, device=dev))
+    with pytest.raises(Exception):
+        eng.embed(torch.zeros(1, 3, 56, 56))          # host tensor: no CPU fallback
+    bad = dict(sd)
+    bad.pop("visual.proj")
+    with pytest.raises(KeyError):
+        engine.VitEngine(cfg, bad, device=0)
+    eng.close()

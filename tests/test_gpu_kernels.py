@@ -1,0 +1,178 @@
+"""Kernel-level parity: each HIP kernel, called through the C ABI (revo_op_*),
+against a plain PyTorch fp32 reference of the same op on the same inputs."""
+import math
+
+import pytest
+import torch
+
+import reverso_amd  # noqa: F401
+from reverso_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32 = 0, 1, 2, 3
+
+
+def _gemm(lib, epi, a, b, c, bias=None, gamma=None):
+    M, K = a.shape
+    N = b.shape[0]
+    _lib.check(lib.revo_op_gemm(epi, _lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), M, N, K, _lib.ptr(c),
+                                c.stride(0), _lib.ptr(bias), _lib.ptr(gamma), _lib.current_stream()), "gemm")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 1024), (300, 260, 128), (1154, 384, 128),
+                                   (37, 1024, 1024), (1, 128, 64), (577, 3072, 1024), (129, 132, 4096)])
+def test_gemm_f32(lib, dev, M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    b = torch.randn(N, K, generator=g).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    c = torch.full((M, N), float("nan"), device=dev)
+    _gemm(lib, EPI_F32, a, b, c, bias)
+    ref = a.float() @ b.float().T + bias
+    err = (c - ref).abs().max().item()
+    assert err <= 2e-3 * math.sqrt(K / 64), err
+
+
+def test_gemm_asymmetric_identity(lib, dev):
+    # A = I, asymmetric B: catches a transposed C write or a swapped fragment map
+    K = 128
+    a = torch.eye(K, device=dev).bfloat16()
+    b = (torch.arange(256 * K, device=dev).reshape(256, K) % 251).float().bfloat16()
+    c = torch.zeros(K, 256, device=dev)
+    _gemm(lib, EPI_F32, a, b, c)
+    assert torch.equal(c, b.float().T)
+
+
+def test_gemm_epilogues(lib, dev):
+    M, N, K = 333, 512, 256
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    b = (torch.randn(N, K, generator=g) * 0.1).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    gamma = torch.randn(N, generator=g).to(dev)
+    ref = a.float() @ b.float().T + bias
+    # bf16 + bias
+    c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    _gemm(lib, EPI_BF16, a, b, c, bias)
+    assert (c.float() - ref).abs().max().item() <= 0.02 * ref.abs().max().item()
+    assert torch.equal(c, ref.bfloat16()) or (c.float() - ref.bfloat16().float()).abs().max().item() <= 0.07
+    # exact-erf gelu
+    c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    _gemm(lib, EPI_BF16_GELU, a, b, c, bias)
+    gref = torch.nn.functional.gelu(ref)
+    assert (c.float() - gref).abs().max().item() <= 0.01 * max(1.0, gref.abs().max().item())
+    # residual with layer scale, in place on fp32
+    x0 = torch.randn(M, N, generator=g).to(dev)
+    x = x0.clone()
+    _gemm(lib, EPI_RESID_F32, a, b, x, bias, gamma)
+    rref = x0 + gamma * ref
+    assert (x - rref).abs().max().item() <= 2e-3
+    x = x0.clone()
+    _gemm(lib, EPI_RESID_F32, a, b, x, bias, None)
+    assert (x - (x0 + ref)).abs().max().item() <= 2e-3
+
+
+def test_gemm_rejects_bad_k(lib, dev):
+    a = torch.zeros(8, 48, device=dev).bfloat16()
+    b = torch.zeros(8, 48, device=dev).bfloat16()
+    c = torch.zeros(8, 8, device=dev)
+    rc = lib.revo_op_gemm(EPI_F32, _lib.ptr(a), 48, _lib.ptr(b), 48, 8, 8, 48, _lib.ptr(c), 8, None, None,
+                          _lib.current_stream())
+    assert rc != 0 and b"multiple of 64" in lib.revo_last_error()
+
+
+@pytest.mark.parametrize("W", [128, 192, 768, 1024, 1536])
+@pytest.mark.parametrize("out_bf16", [0, 1])
+def test_layernorm(lib, dev, W, out_bf16):
+    rows = 77
+    g = torch.Generator(device="cpu").manual_seed(W)
+    x = (torch.randn(rows, W, generator=g) * 3 + 1).to(dev)
+    w = torch.randn(W, generator=g).to(dev)
+    b = torch.randn(W, generator=g).to(dev)
+    out = torch.zeros(rows, W, device=dev, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    _lib.check(lib.revo_op_layernorm(_lib.ptr(x), W, _lib.ptr(w), _lib.ptr(b), 1e-5, rows, W, _lib.ptr(out), W,
+                                     out_bf16, _lib.current_stream()))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x, (W,), w, b, 1e-5)
+    tol = 0.04 if out_bf16 else 2e-5
+    assert (out.float() - ref).abs().max().item() <= tol
+
+
+def test_layernorm_constant_row_is_bias(lib, dev):
+    W = 1024
+    x = torch.full((4, W), 3.25, device=dev)
+    w = torch.randn(W, device=dev)
+    b = torch.randn(W, device=dev)
+    out = torch.zeros(4, W, device=dev)
+    _lib.check(lib.revo_op_layernorm(_lib.ptr(x), W, _lib.ptr(w), _lib.ptr(b), 1e-5, 4, W, _lib.ptr(out), W, 0,
+                                     _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, b.expand(4, W))
+
+
+def _rope_table(S, hd, g, cls, theta=10000.0):
+    from oracle import pe_vit
+
+    class C:
+        pass
+    c = C()
+    c.width, c.heads, c.image_size, c.patch_size, c.use_cls, c.rope_theta = hd, 1, g, 1, cls, theta
+    ang = pe_vit.rope_angles(c, torch.float64)          # [S, hd], pairs repeated
+    return ang
+
+
+def test_rope(lib, dev):
+    from oracle import pe_vit
+    B, g, H, hd = 2, 5, 3, 64
+    S, W = g * g + 1, 3 * 64
+    ang = _rope_table(S, hd, g, True)
+    cs = torch.stack([ang[:, 0::2].cos(), ang[:, 0::2].sin()], dim=-1).float().to(dev).contiguous()   # [S, hd/2, 2]
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    qkv = torch.randn(B * S, 3 * W, generator=gen).to(dev).bfloat16()
+    ref_in = qkv.float().cpu().double().reshape(B, S, 3, H, hd)
+    q = pe_vit.apply_rope(ref_in[:, :, 0].transpose(1, 2), ang).transpose(1, 2)
+    k = pe_vit.apply_rope(ref_in[:, :, 1].transpose(1, 2), ang).transpose(1, 2)
+    _lib.check(lib.revo_op_rope(_lib.ptr(qkv), 3 * W, _lib.ptr(cs), B * S, S, W, H, _lib.current_stream()))
+    torch.cuda.synchronize()
+    got = qkv.float().cpu().double().reshape(B, S, 3, H, hd)
+    assert (got[:, :, 0] - q).abs().max().item() <= 0.03
+    assert (got[:, :, 1] - k).abs().max().item() <= 0.03
+    assert torch.equal(got[:, :, 2], ref_in[:, :, 2])                       # v untouched
+    assert torch.equal(got[:, 0, :2], ref_in[:, 0, :2])                     # cls token: identity rotation
+
+
+@pytest.mark.parametrize("B,S,H", [(2, 577, 2), (1, 197, 3), (3, 17, 2), (1, 64, 1), (1, 65, 1), (2, 128, 2),
+                                   (1, 129, 1), (1, 1, 1)])
+def test_attention(lib, dev, B, S, H):
+    hd = 64
+    W = H * hd
+    g = torch.Generator(device="cpu").manual_seed(S * 31 + H)
+    qkv = torch.randn(B * S, 3 * W, generator=g).to(dev).bfloat16()
+    out = torch.full((B * S, W), float("nan"), device=dev, dtype=torch.bfloat16)
+    _lib.check(lib.revo_op_attention(_lib.ptr(qkv), 3 * W, _lib.ptr(out), W, B, S, H, hd, _lib.current_stream()))
+    torch.cuda.synchronize()
+    x = qkv.float().reshape(B, S, 3, H, hd)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    att = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1)
+    ref = (att @ v).transpose(1, 2).reshape(B * S, W)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 0.03, err
+
+
+def test_attention_peaked_softmax(lib, dev):
+    # one key dominates per query (forces the running max to jump late in the key sweep)
+    B, S, H, hd = 1, 577, 1, 64
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(B * S, 3, hd, generator=g)
+    x[:, 0] *= 0.1
+    x[500, 1] = x[:, 0].mean(0) * 0 + 8.0 * torch.sign(x[3, 0])   # key 500 aligned with query 3
+    qkv = x.reshape(B * S, 3 * hd).to(dev).bfloat16()
+    out = torch.zeros(B * S, hd, device=dev, dtype=torch.bfloat16)
+    _lib.check(lib.revo_op_attention(_lib.ptr(qkv), 3 * hd, _lib.ptr(out), hd, B, S, H, hd, _lib.current_stream()))
+    torch.cuda.synchronize()
+    xf = qkv.float().reshape(S, 3, hd)
+    att = torch.softmax(xf[:, 0] @ xf[:, 1].T * hd ** -0.5, dim=-1)
+    ref = att @ xf[:, 2]
+    assert (out.float() - ref).abs().max().item() <= 0.03

@@ -1,0 +1,120 @@
+"""CPU: the oracle against its committed golden vectors and against known-answer
+cases that need no oracle at all (SURVEY.md §7 stage 0)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+import reverso_amd
+from oracle import pe_vit, search as osearch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden  # noqa: E402
+
+
+def _load(name):
+    return np.load(os.path.join(HERE, "golden", name))
+
+
+def test_tiny_vit_matches_golden():
+    for fname, cname in (("tiny_vit.npz", "PE-Tiny-T14-56"), ("tiny_vit_ls.npz", "PE-Tiny-T14-56-LS")):
+        gold = _load(fname)
+        cfg, sd, images = make_golden.tiny_case(cname)
+        assert np.array_equal(images.numpy(), gold["images"])
+        wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+        assert abs(wsum - float(gold["weight_abs_sum"])) <= 1e-6 * wsum
+        taps = {}
+        with torch.no_grad():
+            emb = pe_vit.l2_normalize(pe_vit.encode_image(sd, cfg, images, taps))
+        for k, v in taps.items():
+            np.testing.assert_allclose(v.numpy(), gold["tap_" + k], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(emb.numpy(), gold["embedding"], rtol=0, atol=1e-6)
+        # fp64 evaluation of the same restatement agrees: the fp32 path is not ill-conditioned
+        e64 = pe_vit.embed(sd, cfg, images, dtype=torch.float64)
+        assert (e64.float() - emb).abs().max().item() < 1e-5
+
+
+def test_b16_block_matches_golden():
+    gold = _load("b16_block.npz")
+    cfg, sd, images = make_golden.b16_block_case()
+    assert abs(images.double().sum().item() - float(gold["image_sum"])) < 1e-6
+    taps = {}
+    with torch.no_grad():
+        emb = pe_vit.l2_normalize(pe_vit.encode_image(sd, cfg, images, taps))
+    rows = gold["rows"].tolist()
+    np.testing.assert_allclose(taps["ln_pre"][0, rows].numpy(), gold["ln_pre"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(taps["block0"][0, rows].numpy(), gold["block0"], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(emb.numpy(), gold["embedding"], atol=1e-6, rtol=0)
+
+
+def test_search_matches_golden():
+    gold = _load("search_4096x1024.npz")
+    gal, qr, perm = make_golden.search_case()
+    assert abs(gal.astype(np.float64).sum() - float(gold["gallery_sum"])) < 1e-6
+    for k in (1, 5, 10, 50):
+        for thr, tag in ((None, "none"), (0.7, "0p7")):
+            s, i, c = osearch.search(gal, qr, k, thr)
+            t = f"k{k}_thr{tag}"
+            assert np.array_equal(i, gold[t + "_indices"])
+            assert np.array_equal(c, gold[t + "_counts"])
+            np.testing.assert_allclose(s, gold[t + "_scores"], atol=1e-6, rtol=0)
+    # planted neighbours are found first; duplicate group comes back index-ascending
+    i10 = gold["k10_thrnone_indices"]
+    assert np.array_equal(i10[0], np.arange(100, 110))
+    assert all(i10[q, 0] == perm[q] for q in range(1, 7))
+    assert gold["k10_thr0p7_counts"][-1] == 0                 # unrelated query: empty result
+    assert np.array_equal(gold["merged_indices"], gold["k10_thrnone_indices"])   # shard+merge == unsharded
+    np.testing.assert_allclose(gold["merged_scores"], gold["k10_thrnone_scores"], atol=1e-6)
+
+
+def test_rope_identity_at_cls_and_norm_preserving():
+    cfg = reverso_amd.get_config("PE-Tiny-T14-56")
+    ang = pe_vit.rope_angles(cfg, torch.float64)
+    assert ang.shape == (cfg.seq, cfg.head_dim)
+    assert torch.all(ang[0] == 0)                              # cls sits at (0,0): unrotated
+    x = torch.randn(1, 2, cfg.seq, cfg.head_dim, dtype=torch.float64)
+    y = pe_vit.apply_rope(x, ang)
+    assert torch.equal(y[:, :, 0], x[:, :, 0])
+    torch.testing.assert_close(y.norm(dim=-1), x.norm(dim=-1))
+    # first patch is at (1,1): x-half and y-half carry the same angles
+    hd = cfg.head_dim
+    assert torch.equal(ang[1, : hd // 2], ang[1, hd // 2:])
+    # interleaved pairs share one frequency
+    assert torch.equal(ang[:, 0::2], ang[:, 1::2])
+
+
+def test_known_answer_search_cases():
+    D = 64
+    eye = np.eye(D, dtype=np.float32)
+    s, i, c = osearch.search(eye, eye[:3], 1)
+    assert np.array_equal(i[:, 0], [0, 1, 2]) and np.allclose(s[:, 0], 1.0)
+    s, i, c = osearch.search(np.concatenate([eye, -eye]), eye[:1], 2 * D)
+    assert i[0, 0] == 0 and i[0, -1] == D and np.isclose(s[0, -1], -1.0)      # negation scores -1, last
+    # permuting gallery rows permutes the indices
+    rng = np.random.default_rng(0)
+    g = rng.standard_normal((300, D)).astype(np.float32)
+    q = rng.standard_normal((4, D)).astype(np.float32)
+    p = rng.permutation(300)
+    s0, i0, _ = osearch.search(g, q, 7)
+    s1, i1, _ = osearch.search(g[p], q, 7)
+    assert np.array_equal(p[i1], i0) and np.allclose(s0, s1, atol=1e-6)
+    # empty gallery, k larger than the gallery
+    s, i, c = osearch.search(np.zeros((0, D), np.float32), q, 5)
+    assert np.all(c == 0) and np.all(i == -1)
+    s, i, c = osearch.search(g[:3], q, 5)
+    assert np.all(c == 3) and np.all(i[:, 3:] == -1) and np.all(np.isinf(s[:, 3:]))
+    # reference-style single query walk agrees with the batched oracle
+    gn = osearch.normalize_rows(g)
+    ref = osearch.search_one_reference_style(gn, q[0], 7, None)
+    assert [r[0] for r in ref] == i0[0].tolist()
+
+
+def test_layernorm_and_softmax_known_answers():
+    x = torch.full((2, 8), 3.0)
+    w, b = torch.randn(8), torch.randn(8)
+    assert torch.equal(pe_vit.layer_norm(x, w, b, 1e-5), b.expand(2, 8))
+    e = torch.randn(5, 16)
+    n = pe_vit.l2_normalize(e)
+    torch.testing.assert_close(n.norm(dim=-1), torch.ones(5))
