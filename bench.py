@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec for embed + top-k (PE-Core-L14-336, 1M x 1024 gallery).
+
+One step = one batch of synthetic 336x336 images per GPU through the HIP embed
+path, then cosine top-10 of every embedding against the row-sharded 1M x 1024
+gallery (all-gather of queries, per-shard scan, all-gather of per-shard top-k,
+merge).  Inputs are resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement): `value` is the
+whole-job images/s, `roofline` is the dominant kernel class (the ViT linear-layer
+MFMA GEMM) timed with HIP events on the launch stream over the timed steps,
+`cpu_baseline` is the CPU oracle on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import reverso_amd  # noqa: E402
+from reverso_amd import engine, sharded  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16, /opt/skills/guides/MI355X_MICROARCH.md:43
+HBM_PEAK_GBS = 8000.0               # MI355X HBM3E spec, MI355X_MICROARCH.md:36
+
+
+def layer_gemm_flops(cfg, batch):
+    """Algorithmic FLOPs (2*MAC) of the linear layers of the transformer body per forward."""
+    rows = batch * cfg.seq
+    W, M = cfg.width, cfg.mlp_dim
+    return cfg.layers * 2.0 * rows * (W * 3 * W + W * W + 2 * W * M)
+
+
+def cpu_baseline(cfg, gallery_rows, dim, k, n_images, search_rows):
+    """The CPU oracle run the way the reference runs: fp32, one image per forward
+    (core_system.py:439-442), one query per search over a float32 numpy gallery."""
+    import numpy as np
+    from oracle import pe_vit, search as osearch
+    from reverso_amd import weights
+    torch.manual_seed(0)
+    sd = weights.synth_weights(cfg, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    u8 = torch.randint(0, 256, (n_images, 3, cfg.image_size, cfg.image_size), generator=g, dtype=torch.uint8)
+    x = pe_vit.preprocess_u8(u8)
+    with torch.no_grad():
+        pe_vit.embed_batch1(sd, cfg, x[:1])                  # warm the thread pool
+        t0 = time.perf_counter()
+        emb = pe_vit.embed_batch1(sd, cfg, x)
+        t_embed = (time.perf_counter() - t0) / n_images
+    rng = np.random.default_rng(42)
+    gal = osearch.normalize_rows(rng.standard_normal((search_rows, dim), dtype=np.float32))
+    q = emb.numpy()
+    osearch.search_one_reference_style(gal, q[0], k)
+    t0 = time.perf_counter()
+    for i in range(n_images):
+        osearch.search_one_reference_style(gal, q[i % len(q)], k)
+    t_search = (time.perf_counter() - t0) / n_images * (gallery_rows / search_rows)
+    return {
+        "value": 1.0 / (t_embed + t_search), "unit": "images/s", "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": (f"{n_images} images embedded one per forward in fp32 (oracle/pe_vit.py), each searched alone over a "
+                   f"{search_rows}x{dim} float32 numpy gallery; search time scaled x{gallery_rows // search_rows} to "
+                   f"{gallery_rows} rows; host has {os.cpu_count()} logical cores"),
+        "embed_s_per_image": t_embed, "search_s_per_query": t_search,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step (BASELINE.json configs[1])")
+    ap.add_argument("--gallery", type=int, default=1_000_000, help="total gallery rows over all GPUs")
+    ap.add_argument("--variant", default="PE-Core-L14-336")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=6)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = reverso_amd.get_config(args.variant)
+    D = cfg.out_dim
+    B = args.batch
+    eng = engine.VitEngine.synthetic(cfg, seed=0, device=local_rank, max_batch=B)
+
+    # synthetic gallery shard, generated on the device (seed 42 + rank), rows normalised at insert
+    shard_rows = args.gallery // world + (1 if rank < args.gallery % world else 0)
+    gal = engine.Gallery(D, max(shard_rows, 1), device=local_rank)
+    gg = torch.Generator(device=dev).manual_seed(42 + rank)
+    for s in range(0, shard_rows, 131072):
+        n = min(131072, shard_rows - s)
+        gal.add(torch.randn(n, D, generator=gg, device=dev))
+    ss = sharded.ShardedSearch.from_gallery(gal)
+
+    ig = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randint(0, 256, (B, 3, cfg.image_size, cfg.image_size), generator=ig, device=dev,
+                           dtype=torch.uint8)
+
+    def step():
+        emb = eng.embed(images)                 # [B, D] L2-normalised fp32
+        q = ss.gather_queries(emb)              # [B*world, D]
+        return ss.search(q, args.k)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    engine.prof_reset()
+    engine.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    engine.prof_enable(False)
+    prof = engine.prof_report()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    # dominant kernel class: the four linear-layer GEMMs of every transformer block
+    gemm_classes = ("gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2")
+    gemm_ms = sum(prof.get(c, {}).get("ms", 0.0) for c in gemm_classes)
+    gemm_launches = sum(prof.get(c, {}).get("launches", 0) for c in gemm_classes)
+    flops_per_launch = layer_gemm_flops(cfg, B) / (4 * cfg.layers)
+    avg_ms = gemm_ms / max(gemm_launches, 1)
+    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "gemm128_kernel",
+                "avg_launch_ms": avg_ms, "launches": gemm_launches,
+                "algorithmic_flops_per_launch": flops_per_launch}
+    # the search scan is HBM bound at this query count: report it next to the GEMM
+    scan = prof.get("topk_scan", {})
+    if scan.get("launches"):
+        scan_ms = scan["ms"] / scan["launches"]
+        scan_bytes = shard_rows * D * 2 + B * world * D * 2 + B * world * args.k * 12
+        roofline["search_scan"] = {"bound": "hbm", "achieved": scan_bytes / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": scan_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "avg_launch_ms": scan_ms}
+    classes_ms = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(prof.items())}
+
+    if rank == 0:
+        res = {
+            "metric": "images/sec embed+top-k (PE-L14-336, 1M x 1024 gallery)", "value": value, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{cfg.name} embed of {B} synthetic {cfg.image_size}x{cfg.image_size} images per GPU "
+                                   f"+ cosine top-{args.k} over a {args.gallery}x{D} gallery row-sharded {world}-way",
+                       "batch_per_gpu": B, "gallery_rows": args.gallery, "dim": D, "k": args.k,
+                       "parallelism": f"dp{world} embed, gallery rows sharded {world}-way, all-gather top-k merge"},
+            "roofline": roofline,
+            "kernel_ms_per_step": classes_ms,
+            "embed_tflops": cfg.flops_per_image() * B * args.steps / dt / 1e12,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, args.gallery, D, args.k, args.cpu_images, min(args.gallery, 250_000))
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -63,6 +63,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch owns device memory and streams: its bundled HIP runtime must be the one
+    # librevo.so binds to (a stream handle is only meaningful inside one runtime), so
+    # make sure it is loaded first.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RevoError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
