@@ -400,7 +400,7 @@ extern "C" int32_t revo_vit_forward(revo_vit* v, const void* images, int32_t ima
         CHECK_RC(gemm("gemm_qkv", EPI_BF16, v->h, W, L.w_qkv, W, rows, 3 * W, W, v->qkv, 3 * W, L.b_qkv, nullptr, st));
         { ProfScope ps("rope", st); CHECK_RC(launch_rope(v->qkv, 3 * W, v->rope_cs, rows, S, W, c.heads, st)); }
         { ProfScope ps("attention", st);
-          CHECK_RC(launch_attention(v->qkv, 3 * W, v->att, W, B, S, c.heads, v->hd, st)); }
+          CHECK_RC(launch_attention_ex(v->qkv, 3 * W, v->att, W, B, S, c.heads, v->hd, c.use_cls, st)); }
         CHECK_RC(gemm("gemm_out", EPI_RESID_F32, v->att, W, L.w_o, W, rows, W, W, v->x, W, L.b_o, L.ls1, st));
         { ProfScope ps("layernorm", st);
           CHECK_RC(launch_layernorm(v->x, W, L.ln2w, L.ln2b, c.ln_eps, rows, W, v->h, W, 1, st)); }
@@ -589,6 +589,15 @@ extern "C" int32_t revo_op_gemm(int32_t epi, const void* a, int64_t lda, const v
     return gemm("gemm_op", epi, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, m, n, k, c, ldc, bias, gamma,
                 (hipStream_t)stream);
     API_END
+}
+extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
+    revo::gemm_set_debug(flags);
+    return 0;
+}
+extern "C" int32_t revo_op_set_gemm_tile(int32_t tile) {
+    REVO_REQUIRE(tile == 0 || tile == 128 || tile == 256, "set_gemm_tile: 0, 128 or 256");
+    revo::gemm_force_tile(tile);
+    return 0;
 }
 extern "C" int32_t revo_op_layernorm(const float* x, int64_t ldx, const float* w, const float* b, float eps,
                                      int32_t rows, int32_t width, void* out, int64_t ldo, int32_t out_is_bf16,

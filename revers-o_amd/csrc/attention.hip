@@ -22,16 +22,23 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* lo, const char* hi) {
     return __builtin_bit_cast(bf16x8, c);
 }
 
-template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld,
-                                                       bf16_t* __restrict__ out, long ldo, int S, int H, float c) {
+// Body attention.  NW waves per workgroup, 32 query rows per wave.  Query rows
+// [q_lo, S) and key rows [k_lo, S) are tiled; when k_lo == 1 the class-token key
+// (row 0) is folded in as a rank-1 prelude (m = s_cls, l = 1, O = v_cls) so that
+// L14's 576 patch keys are exactly 9 unmasked tiles.  The class-token QUERY row
+// (when q_lo == 1) is served by attn_row_kernel below.
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld,
+                                                          bf16_t* __restrict__ out, long ldo, int S, int H, float c,
+                                                          int q_lo, int k_lo) {
     static_assert(HD == 64, "body attention kernel is built for head_dim 64");
+    constexpr int NT = NW * 64;
     constexpr int KS = HD / 16;          // k-steps over d for S^T
     constexpr int DB = HD / 32;          // 32-wide d blocks of O^T
     constexpr int ROWB = HD * 2;         // bytes per K/V tile row (128)
-    constexpr int CH = HD / 8;           // 16-byte chunks per row (8)
     constexpr int TILE = 64 * ROWB;      // 8 KB
-    constexpr int NLD = (64 * CH) / 256; // chunks per thread per operand (2)
+    constexpr int NMOVE = (1024 + NT - 1) / NT;   // 16-byte chunks per thread per tile (K: ids 0..511, V: 512..1023)
+    constexpr float DEFER = 6.0f;        // skip the O rescale while the running max grows by < 2^6 (T13)
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE];   // K0 K1 V0 V1
 
     const int tid = threadIdx.x;
@@ -40,7 +47,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const int b = blockIdx.y / H, h = blockIdx.y - b * H;
     const int W = H * HD;
     const long rowbase = (long)b * S;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = q_lo + blockIdx.x * (NW * 32) + wave * 32;
     const bool wave_active = q0 < S;
     const int qrow = q0 + r;
     const int qrow_c = qrow < S ? qrow : S - 1;
@@ -55,79 +62,112 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
     }
 
-    // staging assignment: chunk id = tid + 256*i -> (key, ch)
-    int st_key[NLD], st_ch[NLD];
+    // ---- staging: chunk id = tid + NT*i; ids < 512 are K chunks, the rest V chunks
+    int st_goff[NMOVE];      // element offset inside a tile-relative row block: key*ld + ch*8 (+ K/V base)
+    int st_loff[NMOVE];      // LDS byte offset inside the (K0 K1 V0 V1) image for buffer 0
+    int st_key[NMOVE];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int id = tid + 256 * i;
-        st_key[i] = id / CH;
-        st_ch[i] = id - st_key[i] * CH;
+    for (int i = 0; i < NMOVE; ++i) {
+        const int id = tid + NT * i;
+        const int isv = id >> 9, rem = id & 511;
+        const int key = rem >> 3, ch = rem & 7;
+        st_key[i] = key;
+        st_goff[i] = ch * 8 + (isv ? 2 * W : W) + h * HD;
+        const int swz = isv ? (((key >> 1) & 1) << 2) : ((key >> 1) & 7);
+        st_loff[i] = isv * 2 * TILE + key * ROWB + ((ch ^ swz) << 4);
     }
-    uint4 kreg[NLD], vreg[NLD];
-    auto load_tile = [&](int t) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    u32x4 st_reg[NMOVE];
+#define ATT_LOAD_TILE(t)                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NMOVE; ++i) {                                   \
+        if (NT * i + NT <= 1024 || tid + NT * i < 1024) {                                 \
+            int key = k_lo + (t) * 64 + st_key[i];                                        \
+            key = key < S ? key : S - 1;                                                  \
+            st_reg[i] = *(const u32x4*)(qkv + (rowbase + key) * ld + st_goff[i]);         \
+        }                                                                                 \
+    }
+#define ATT_STORE_TILE(buf)                                                               \
+    _Pragma("unroll") for (int i = 0; i < NMOVE; ++i) {                                   \
+        if (NT * i + NT <= 1024 || tid + NT * i < 1024)                                   \
+            *(u32x4*)(lds + (buf) * TILE + st_loff[i]) = st_reg[i];                       \
+    }
+
+    // ---- per-lane LDS fragment addresses (buffer 0), swizzles resolved once
+    int kaddr[KS], vaddr[DB];
+    {
+        const int sw = (r >> 1) & 7;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            int key = t * 64 + st_key[i];
-            key = key < S ? key : S - 1;
-            const long off = (rowbase + key) * ld + st_ch[i] * 8;
-            kreg[i] = *(const uint4*)(kg + off);
-            vreg[i] = *(const uint4*)(vg + off);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        char* kb = lds + buf * TILE;
-        char* vb = lds + (2 + buf) * TILE;
+        for (int ks = 0; ks < KS; ++ks) kaddr[ks] = r * ROWB + (((2 * ks + hh) ^ sw) << 4);
+        const int g16 = lane >> 4, li = lane & 15;
+        const int tq = li >> 2, tp = li & 3;
+        const int sbit = (tq >> 1) & 1;      // V swizzle bit of keys 4*hh + tq (+ multiples of 8)
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int key = st_key[i], ch = st_ch[i];
-            *(uint4*)(kb + key * ROWB + ((ch ^ ((key >> 1) & 7)) << 4)) = kreg[i];
-            *(uint4*)(vb + key * ROWB + ((ch ^ (((key >> 1) & 1) << 2)) << 4)) = vreg[i];
-        }
-    };
+        for (int d = 0; d < DB; ++d)
+            vaddr[d] = 2 * TILE + (4 * hh + tq) * ROWB + ((((d ^ sbit) * 4 + (g16 & 1) * 2 + (tp >> 1))) << 4) + (tp & 1) * 8;
+    }
 
     f32x16 oacc[DB];
+    float m_run = -INFINITY, l_run = 0.f;
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
 
-    const int nt = (S + 63) / 64;
-    load_tile(0);
-    store_tile(0);
+    const int nkeys = S - k_lo;
+    const int nt = (nkeys + 63) / 64;
+    if (nt > 0) ATT_LOAD_TILE(0);
+
+    if (k_lo == 1 && wave_active) {
+        // rank-1 prelude with key row 0: this lane holds q[d] for d = 16*ks + 8*hh + j
+        const bf16_t* k0p = kg + rowbase * ld + 8 * hh;
+        float sdot = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const s16x8 kk = *(const s16x8*)(k0p + 16 * ks);
+            const s16x8 qq = __builtin_bit_cast(s16x8, qf[ks]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                sdot = fmaf(bf16_to_f32((bf16_t)qq[j]), bf16_to_f32((bf16_t)kk[j]), sdot);
+        }
+        sdot += __shfl_xor(sdot, 32, 64);
+        m_run = sdot * c;
+        l_run = hh == 0 ? 1.0f : 0.0f;       // the two halves' partial sums are added at the end
+        const bf16_t* v0p = vg + rowbase * ld;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const s16x4 vv = *(const s16x4*)(v0p + d * 32 + 8 * g + 4 * hh);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) oacc[d][4 * g + j] = bf16_to_f32((bf16_t)vv[j]);
+            }
+    }
+    if (nt > 0) ATT_STORE_TILE(0);
     __syncthreads();
-
-    // per-lane constant pieces of the transposed-read address
-    const int g16 = lane >> 4, li = lane & 15;
-    const int tq = li >> 2, tp = li & 3;
 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) load_tile(t + 1);
+        if (t + 1 < nt) ATT_LOAD_TILE(t + 1);
         if (wave_active) {
-            const char* kb = lds + buf * TILE;
-            const char* vb = lds + (2 + buf) * TILE;
+            const char* base = lds + buf * TILE;
             f32x16 sacc[2];
 #pragma unroll
             for (int kblk = 0; kblk < 2; ++kblk) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sacc[kblk][i] = 0.f;
-                const int key = kblk * 32 + r;
-                const char* krow = kb + key * ROWB;
-                const int sw = (r >> 1) & 7;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8 a = *(const bf16x8*)(krow + (((2 * ks + hh) ^ sw) << 4));
+                    const bf16x8 a = *(const bf16x8*)(base + kaddr[ks] + kblk * 32 * ROWB);
                     sacc[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], sacc[kblk], 0, 0, 0);
                 }
             }
-            if (t == nt - 1 && (S & 63)) {
+            if (t == nt - 1 && (nkeys & 63)) {
 #pragma unroll
                 for (int kblk = 0; kblk < 2; ++kblk)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int key = t * 64 + kblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                        if (key >= S) sacc[kblk][i] = -INFINITY;
+                        if (key >= nkeys) sacc[kblk][i] = -INFINITY;
                     }
             }
             float mx = -INFINITY;
@@ -135,25 +175,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             for (int kblk = 0; kblk < 2; ++kblk)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kblk][i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx * c);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+            if (!__all(mx <= m_run + DEFER)) {
+                // the running max moved by more than the deferral window somewhere in the wave: rescale
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+            }
             float ps = 0.f;
 #pragma unroll
             for (int kblk = 0; kblk < 2; ++kblk)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kblk][i], c, -m_new));
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kblk][i], c, -m_run));
                     sacc[kblk][i] = p;
                     ps += p;
                 }
-            l_run = fmaf(l_run, alpha, ps);
-#pragma unroll
-            for (int d = 0; d < DB; ++d)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
-
+            l_run += ps;
 #pragma unroll
             for (int kblk = 0; kblk < 2; ++kblk) {
 #pragma unroll
@@ -165,52 +208,159 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                     pk.w = pack_bf16x2(sacc[kblk][8 * s2 + 6], sacc[kblk][8 * s2 + 7]);
                     const bf16x8 pb = __builtin_bit_cast(bf16x8, pk);
                     // k index (h, j) of this step is key 16*s2 + 8*(j>>2) + 4*h + (j&3) of the block
-                    const int key_lo = kblk * 32 + 16 * s2 + 4 * hh + tq;
-                    const int key_hi = key_lo + 8;
 #pragma unroll
                     for (int d = 0; d < DB; ++d) {
-                        const int chunk = d * 4 + (g16 & 1) * 2 + (tp >> 1);
-                        const int within = (tp & 1) * 8;
-                        const char* alo = vb + key_lo * ROWB + ((chunk ^ (((key_lo >> 1) & 1) << 2)) << 4) + within;
-                        const char* ahi = vb + key_hi * ROWB + ((chunk ^ (((key_hi >> 1) & 1) << 2)) << 4) + within;
-                        const bf16x8 a = tr_pair(alo, ahi);
+                        const char* alo = base + vaddr[d] + (kblk * 32 + 16 * s2) * ROWB;
+                        const bf16x8 a = tr_pair(alo, alo + 8 * ROWB);
                         oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, oacc[d], 0, 0, 0);
                     }
                 }
             }
         }
-        if (t + 1 < nt) store_tile(buf ^ 1);
+        if (t + 1 < nt) ATT_STORE_TILE(buf ^ 1);
         __syncthreads();
     }
 
-    if (wave_active && qrow < S) {
+    if (wave_active) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = 1.0f / l_tot;
-        bf16_t* op = out + (rowbase + qrow) * ldo + h * HD;
+        if (qrow < S) {
+            const float inv = 1.0f / l_tot;
+            bf16_t* op = out + (rowbase + qrow) * ldo + h * HD;
 #pragma unroll
-        for (int d = 0; d < DB; ++d)
+            for (int d = 0; d < DB; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 o;
-                o.x = pack_bf16x2(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv);
-                o.y = pack_bf16x2(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
-                *(uint2*)(op + d * 32 + 8 * g + 4 * hh) = o;
+                for (int g = 0; g < 4; ++g) {
+                    uint2 o;
+                    o.x = pack_bf16x2(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv);
+                    o.y = pack_bf16x2(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+                    *(uint2*)(op + d * 32 + 8 * g + 4 * hh) = o;
+                }
+        }
+    }
+#undef ATT_LOAD_TILE
+#undef ATT_STORE_TILE
+}
+
+// One query row (the class token) of every (image, head) against all S keys:
+// one wave per (image, head), lanes own keys (lane, lane + 64, ...), the query and the
+// per-lane partial output live in registers; the 64 partial outputs are summed across
+// lanes through LDS.  S <= 64 * RMAX.
+template <int HD, int RMAX>
+__global__ __launch_bounds__(256) void attn_row_kernel(const bf16_t* __restrict__ qkv, long ld,
+                                                       bf16_t* __restrict__ out, long ldo, int S, int H, int BH,
+                                                       int qrow, float scale) {
+    __shared__ float part[4][64][HD + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= BH) return;
+    const int b = bh / H, h = bh - b * H;
+    const int W = H * HD;
+    const bf16_t* base = qkv + (long)b * S * ld + h * HD;
+    float q[HD];
+    {
+        const bf16_t* qp = base + (long)qrow * ld;
+#pragma unroll
+        for (int c8 = 0; c8 < HD / 8; ++c8) {
+            const s16x8 v = *(const s16x8*)(qp + c8 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[c8 * 8 + j] = bf16_to_f32((bf16_t)v[j]) * scale;
+        }
+    }
+    float sc[RMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+        const int s = lane + 64 * i;
+        sc[i] = -INFINITY;
+        if (s < S) {
+            const bf16_t* kr = base + W + (long)s * ld;
+            float acc = 0.f;
+#pragma unroll
+            for (int c8 = 0; c8 < HD / 8; ++c8) {
+                const s16x8 v = *(const s16x8*)(kr + c8 * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = fmaf(q[c8 * 8 + j], bf16_to_f32((bf16_t)v[j]), acc);
             }
-    } else if (wave_active) {
-        // keep the exchange convergent for lanes whose row is past S
-        (void)__shfl_xor(l_run, 32, 64);
+            sc[i] = acc;
+            mx = fmaxf(mx, acc);
+        }
+    }
+    mx = wave_max(mx);
+    float o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+        const int s = lane + 64 * i;
+        if (s < S) {
+            const float p = __expf(sc[i] - mx);
+            sum += p;
+            const bf16_t* vr = base + 2 * W + (long)s * ld;
+#pragma unroll
+            for (int c8 = 0; c8 < HD / 8; ++c8) {
+                const s16x8 v = *(const s16x8*)(vr + c8 * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[c8 * 8 + j] = fmaf(p, bf16_to_f32((bf16_t)v[j]), o[c8 * 8 + j]);
+            }
+        }
+    }
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int d = 0; d < HD; ++d) part[wave][lane][d] = o[d];
+    // wave-private LDS slab: LDS operations of one wave complete in order, no barrier needed
+    float acc = 0.f;
+    if (lane < HD) {
+#pragma unroll 8
+        for (int l = 0; l < 64; ++l) acc += part[wave][l][lane];
+        out[((long)b * S + qrow) * ldo + h * HD + lane] = f32_to_bf16(acc / sum);
     }
 }
 
-int launch_attention(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, int hd, hipStream_t st) {
+template <int NW>
+static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, float c, int q_lo,
+                           int k_lo, hipStream_t st) {
+    const int rows = S - q_lo;
+    dim3 grid((rows + NW * 32 - 1) / (NW * 32), B * H), block(NW * 64);
+    hipLaunchKernelGGL((attn_fwd_kernel<64, NW>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_lo, k_lo);
+}
+
+// has_cls: row 0 of every sequence is the class token (true for every PE-Core variant with use_cls)
+int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, int hd, int has_cls,
+                        hipStream_t st) {
     REVO_REQUIRE(hd == 64, "attention: only head_dim 64 is built (PE-Core B16/L14 body)");
     REVO_REQUIRE(ld % 8 == 0 && ldo % 4 == 0, "attention: strides must keep 16-byte alignment");
+    REVO_REQUIRE(S <= 1024 || !has_cls, "attention: class-token row kernel holds at most 1024 keys");
     if (B <= 0 || S <= 0) return 0;
-    const float c = (1.0f / sqrtf((float)hd)) * 1.44269504088896340736f;
-    dim3 grid((S + 127) / 128, B * H), block(256);
-    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c);
+    const float scale = 1.0f / sqrtf((float)hd);
+    const float c = scale * 1.44269504088896340736f;
+    // split off the class token when that makes the patch rows/keys tile better
+    auto cost = [](int n) { return ((n + 31) / 32) * ((n + 63) / 64); };   // wave-tiles x key tiles
+    const int lo = (has_cls && S > 1 && cost(S - 1) < cost(S)) ? 1 : 0;
+    const int rows = S - lo;
+    // waves per workgroup: the candidate with the fewest padded query rows (ties: more waves share a K/V tile)
+    int best = 4, best_pad = 1 << 30;
+    for (int nw : {8, 7, 6, 4}) {
+        const int per = nw * 32;
+        const int pad = (rows + per - 1) / per * per - rows;
+        if (pad < best_pad) { best_pad = pad; best = nw; }
+    }
+    switch (best) {
+        case 8: launch_attn_nw<8>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;
+        case 7: launch_attn_nw<7>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;
+        case 6: launch_attn_nw<6>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;
+        default: launch_attn_nw<4>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;
+    }
     REVO_HIP_CHECK(hipGetLastError());
+    if (lo) {
+        hipLaunchKernelGGL((attn_row_kernel<64, 16>), dim3((B * H + 3) / 4), dim3(256), 0, st, qkv, ld, out, ldo, S, H,
+                           B * H, 0, scale);
+        REVO_HIP_CHECK(hipGetLastError());
+    }
     return 0;
+}
+int launch_attention(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, int hd, hipStream_t st) {
+    return launch_attention_ex(qkv, ld, out, ldo, B, S, H, hd, 1, st);
 }
 
 // ------------------------------------------------------ attention pool -----

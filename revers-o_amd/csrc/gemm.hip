@@ -4,6 +4,7 @@
 // SURVEY.md §2b; replaces the F.linear / conv2d calls the upstream PE module
 // dispatches from encode_image (reference call site core_system.py:442).
 #include "gemm_core.h"
+#include "gemm256_core.h"
 #include "kernels.h"
 
 namespace revo {
@@ -77,6 +78,100 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int m_base, int
     }
 }
 
+// 32 rows (accumulator fragments 2*QT, 2*QT+1) of a wave's fp32 sub-tile: transpose through
+// the wave's LDS slab, then whole 256-byte row segments to/from global memory.
+template <int EPI, int QT>
+__device__ __forceinline__ void gemm256_epilogue_f32_quarter(const GemmArgs& p, char* slab, int m_base, int n_base,
+                                                             int lane, f32x4 (&acc)[8][4], const f32x4 (&bias4)[4],
+                                                             const f32x4 (&gamma4)[4]) {
+    constexpr int RS = 272;   // 64 fp32 + 16 bytes of padding per slab row
+    asm volatile("" : "+v"(lane) :: "memory");   // keep this quarter's address arithmetic inside it
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            f32x4 v = acc[QT * 2 + m][n] + bias4[n];
+            if (EPI == EPI_RESID_F32) v *= gamma4[n];
+            *(f32x4*)(slab + (m * 16 + lr) * RS + (n * 16 + lq * 4) * 4) = v;
+        }
+    const int gcol = n_base + (lane & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int rl = it * 4 + (lane >> 4);
+        f32x4 v = *(const f32x4*)(slab + rl * RS + (lane & 15) * 16);
+        const int grow = m_base + QT * 32 + rl;
+        if (grow < p.M && gcol < p.N) {
+            float* dst = (float*)p.C + (long)grow * p.ldc + gcol;
+            if (EPI == EPI_RESID_F32) v += *(const f32x4*)dst;
+            *(f32x4*)dst = v;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
+// Epilogue of the 256 x 256 kernel.  A lane's accumulator fragment is 4 columns of one
+// row, so storing it directly issues 32 narrow stores per lane that each touch 16 rows
+// (measured: ~7 us per tile, store-issue bound).  Instead every wave transposes its
+// 128 x 64 sub-tile through a wave-private LDS slab (free after the main loop) and
+// reads/writes global memory in whole 128-byte (bf16) or 256-byte (fp32) row segments,
+// 16 bytes per lane.  Bias, GELU and LayerScale are applied before the transpose, the
+// residual add after it (on the coalesced rows).
+template <int EPI>
+__device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* smem, int m_base, int n_base, int wave,
+                                                 int lane, f32x4 (&acc)[8][4]) {
+    static_assert(EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_F32 || EPI == EPI_RESID_F32, "");
+    // The main loop runs at the 256-VGPR limit: keep every epilogue value from being
+    // computed (or loaded) ahead of it by making the lane id opaque here.
+    asm volatile("" : "+v"(lane) :: "memory");
+    const int lq = lane >> 4;
+    char* slab = smem + wave * 16384;
+    f32x4 bias4[4], gamma4[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int col = n_base + n * 16 + lq * 4;
+        bias4[n] = (p.bias && col < p.N) ? *(const f32x4*)(p.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (EPI == EPI_RESID_F32)
+            gamma4[n] = (p.gamma && col < p.N) ? *(const f32x4*)(p.gamma + col) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    }
+    if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+        constexpr int RS = 144;   // 64 bf16 + 16 bytes of padding per slab row
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            asm volatile("" : "+v"(lane) :: "memory");
+            const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    f32x4 v = acc[half * 4 + m][n] + bias4[n];
+                    if (EPI == EPI_BF16_GELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                    }
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *(uint2*)(slab + (m * 16 + lr) * RS + (n * 16 + lq * 4) * 2) = o;
+                }
+            const int gcol = n_base + (lane & 7) * 8;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rl = it * 8 + (lane >> 3);
+                const uint4 v = *(const uint4*)(slab + rl * RS + (lane & 7) * 16);
+                const int grow = m_base + half * 64 + rl;
+                if (grow < p.M && gcol < p.N) *(uint4*)((bf16_t*)p.C + (long)grow * p.ldc + gcol) = v;
+            }
+            asm volatile("" ::: "memory");
+        }
+    } else {
+        gemm256_epilogue_f32_quarter<EPI, 0>(p, slab, m_base, n_base, lane, acc, bias4, gamma4);
+        gemm256_epilogue_f32_quarter<EPI, 1>(p, slab, m_base, n_base, lane, acc, bias4, gamma4);
+        gemm256_epilogue_f32_quarter<EPI, 2>(p, slab, m_base, n_base, lane, acc, bias4, gamma4);
+        gemm256_epilogue_f32_quarter<EPI, 3>(p, slab, m_base, n_base, lane, acc, bias4, gamma4);
+    }
+}
+
 // 128 x 128 x 64 tile, 4 waves as 2 (M) x 2 (N), each 64 x 64.
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm128_kernel(GemmArgs p) {
@@ -106,6 +201,48 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm128_kernel(GemmArgs p) {
     gemm_epilogue<EPI, MF, NF>(p, m0 + wr * 64, n0 + wc * 64, lane, acc);
 }
 
+// 256 x 256 x 64 tile, 8 waves as 2 (M) x 4 (N), each 128 x 64; see gemm256_core.h.
+// DBG (compile time, scripts/gemm_ksweep.py only): 1 = no epilogue stores, 2 = no main loop.
+template <int EPI, int DBG>
+__global__ __launch_bounds__(G256_THREADS, 2) void gemm256_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = (p.N + 255) / 256;
+    const int tiles_m = (p.M + 255) / 256;
+    const int s = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = s / tiles_n, tn = s - tm * tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+
+    G256Operand A, B;
+    g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane);
+    g256_operand_init(B, p.B, p.ldb, p.N, n0, wave, lane);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (!(DBG & 2)) {
+        g256_issue_prologue(A, B, smem, p.K, wave);
+        gemm256_mainloop(A, B, smem, p.K, wave, lane, acc);
+    }
+    if (DBG & 1) {
+        if (acc[0][0][0] != 12345.678f) return;     // timing-only build: keep acc live, store nothing
+    }
+    if constexpr (EPI == EPI_PATCH) {
+        gemm_epilogue<EPI, 8, 4>(p, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, lane, acc);
+    } else {
+        // bf16 rows are written in 16-byte column chunks: needs N % 8 == 0 and ldc % 8 == 0 (else direct stores)
+        // (a runtime condition for every variant: with the direct epilogue compiled out, hipcc 7.2
+        //  allocates the fp32 variants' main loop so badly that the accumulators spill)
+        const bool wide = (p.N & 7) == 0 && (p.ldc & 7) == 0;
+        if (wide) gemm256_epilogue<EPI>(p, smem, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, wave, lane, acc);
+        else gemm_epilogue<EPI, 8, 4>(p, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, lane, acc);
+    }
+}
+
 static const char* check_args(const GemmArgs& a) {
     if (a.K <= 0 || a.K % GEMM_BK) return "gemm: K must be a positive multiple of 64";
     if (a.N % 4) return "gemm: N must be a multiple of 4";
@@ -116,8 +253,46 @@ static const char* check_args(const GemmArgs& a) {
     return nullptr;
 }
 
+template <int EPI, int DBG>
+static int launch_256d(const GemmArgs& a, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<EPI, DBG>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+        attr_done = true;
+    }
+    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, DBG>), dim3(tiles), dim3(G256_THREADS), G256_LDS, st, a);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+static int g_dbg = 0;          // timing experiments only (EPI_BF16): 1 = no epilogue stores, 2 = no main loop
+void gemm_set_debug(int d) { g_dbg = d; }
+template <int EPI>
+static int launch_256(const GemmArgs& a, hipStream_t st) {
+    if (EPI == EPI_BF16 && g_dbg) {
+        switch (g_dbg) {
+            case 1: return launch_256d<EPI_BF16, 1>(a, st);
+            case 2: return launch_256d<EPI_BF16, 2>(a, st);
+            default: return launch_256d<EPI_BF16, 3>(a, st);
+        }
+    }
+    return launch_256d<EPI, 0>(a, st);
+}
+
+static int g_force_tile = 0;   // 0 = heuristic, 128 / 256 = forced (tests, A/B timing)
+void gemm_force_tile(int t) { g_force_tile = t; }
+
+static bool use_256(const GemmArgs& a) {
+    if (256l * a.lda * 2 >= (1l << 31) || 256l * a.ldb * 2 >= (1l << 31)) return false;   // 32-bit DMA offsets per tile window
+    if (g_force_tile == 256) return true;
+    if (g_force_tile == 128) return false;
+    return a.M >= 1024 && a.N >= 256;
+}
+
 template <int EPI>
 static int launch_t(const GemmArgs& a, hipStream_t st) {
+    if (use_256(a)) return launch_256<EPI>(a, st);
     constexpr int LDS = 2 * (128 + 128) * 128;
     static bool attr_done = false;
     if (!attr_done) {

@@ -1,0 +1,241 @@
+// 256 x 256 x 64 bf16 MFMA main loop, 8 waves (2 M x 4 N, 128 x 64 per wave),
+// one workgroup per CU (128 KiB LDS), shared by the ViT linear layers and the
+// query x gallery scan.   C[M,N] = A[M,K] . B[N,K]^T, both operands K-contiguous.
+//
+// Schedule (per K-tile t living in LDS stage t&1; fragments: A-lo/A-hi = the wave's
+// first/second 64 rows, B-lo/B-hi = its first/second 32 columns):
+//
+//            MFMA cluster (16x)     LDS reads issued          LDS-DMA issued
+//   even P0  A-lo x B-lo           A-hi(t)                   B half 0 of t+1 -> other stage
+//        P1  A-hi x B-lo           B-hi(t)                   B half 1 of t+1 -> other stage
+//        P2  A-hi x B-hi           -            [barrier]    A half 0 of t+2 -> this stage
+//        P3  A-lo x B-hi           first operands of t+1     A half 1 of t+2 -> this stage
+//                                  (after vmcnt(4)+barrier)
+//   odd tiles run the mirrored order (A-hi first) so that the registers a cluster
+//   frees are the ones the next reads fill: every ds_read is issued one cluster
+//   ahead of its use, and the DMA queue never drains inside the loop (counted
+//   vmcnt(4) once per K-tile leaves two half-tiles in flight across the barrier).
+//
+// LDS image per stage: A[256 rows][128 B] | B[256 rows][128 B]; 16-byte chunks are
+// XOR-swizzled with ((row>>1)&7) on the DMA *source* address and on the fragment
+// read (the DMA destination is lane-linear).  Rows past the matrix edge are
+// fetched through a bounds-checked buffer descriptor and read as zeros.
+#pragma once
+#include "common.h"
+
+namespace revo {
+
+constexpr int G256_THREADS = 512;
+constexpr int G256_STAGE = 65536;       // bytes per stage: A 32 KiB + B 32 KiB
+constexpr int G256_LDS = 2 * G256_STAGE;
+
+struct G256Operand {
+    __amdgpu_buffer_rsrc_t rsrc[4];   // one bounds-checked window per 64-row block of the tile (SGPRs)
+    uint32_t voff;                    // byte offset of this lane's 16-byte chunk inside a block at k = 0
+};
+
+// base: first element of the operand, rows: its row count, row0: first row of this tile.
+// Block j's descriptor covers rows [row0 + 64 j, min(row0 + 64 j + 64, rows)): a lane whose
+// row lies past the matrix edge addresses beyond num_records and the DMA writes zeros.
+// One VGPR of addressing per operand; every window is < 4 GiB whatever the operand size.
+__device__ __forceinline__ void g256_operand_init(G256Operand& op, const bf16_t* base, long ld, long rows, int row0,
+                                                  int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        long left = rows - (row0 + 64 * j);
+        left = left < 0 ? 0 : (left > 64 ? 64 : left);
+        op.rsrc[j] = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)(row0 + 64 * j) * ld), 0,
+                                                       (int)(left * ld * 2), 0x00020000);
+    }
+    const int r = wave * 8 + (lane >> 3);                  // row inside a 64-row block
+    const int c = (lane & 7) ^ ((r >> 1) & 7);             // (row>>1)&7 is the same in every 64-row block
+    op.voff = (uint32_t)(r * ld * 2 + c * 16);
+}
+
+// one half-tile (128 rows x 64 k): two 16-byte-per-lane DMA instructions per thread
+__device__ __forceinline__ void g256_issue_half(const G256Operand& op, int half, int kbyte, char* region, int wave) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        char* dst = region + half * 16384 + i * 8192 + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(op.rsrc[half * 2 + i], (__attribute__((address_space(3))) void*)dst, 16,
+                                                 op.voff, kbyte, 0, 0);
+    }
+}
+
+struct G256Frags {
+    bf16x8 alo[4][2], ahi[4][2], blo[2][2], bhi[2][2];   // [fragment][k sub-step]
+};
+
+// Per-lane LDS byte offsets of the fragment reads: [stage][k sub-step], for the wave's first
+// A row / first B row.  Everything else is an immediate (m * 2048, +64 rows = 8192, ...), so
+// the whole main loop addresses LDS through these eight registers (made opaque so that the
+// compiler does not re-derive a register per immediate and spill at the 256-VGPR limit).
+struct G256Addr {
+    uint32_t a[2][2], b[2][2];
+};
+__device__ __forceinline__ void g256_addr_init(G256Addr& ad, int wave, int lane) {
+    const int sw = (lane >> 1) & 7, lr = lane & 15, lq = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const uint32_t x = (uint32_t)(((kk * 4 + lq) ^ sw) << 4);
+            ad.a[s][kk] = (uint32_t)(s * G256_STAGE + (wr * 128 + lr) * 128) + x;
+            ad.b[s][kk] = (uint32_t)(s * G256_STAGE + 32768 + (wc * 64 + lr) * 128) + x;
+            asm volatile("" : "+v"(ad.a[s][kk]), "+v"(ad.b[s][kk]));
+        }
+}
+typedef __attribute__((address_space(3))) const bf16x8* lds_frag_ptr;
+// ROWS: 0 = A-lo / B-lo, 64 = A-hi (rows +64), 32 = B-hi (rows +32)
+template <int ROWS>
+__device__ __forceinline__ void g256_read_a(bf16x8 (&dst)[4][2], const uint32_t (&base)[2]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) dst[m][kk] = *(lds_frag_ptr)(uintptr_t)(base[kk] + (ROWS + m * 16) * 128);
+}
+template <int ROWS>
+__device__ __forceinline__ void g256_read_b(bf16x8 (&dst)[2][2], const uint32_t (&base)[2]) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) dst[n][kk] = *(lds_frag_ptr)(uintptr_t)(base[kk] + (ROWS + n * 16) * 128);
+}
+
+// acc[m][n]: lane l owns row m*16 + (l&15), columns n*16 + (l>>4)*4 + {0..3} (operands swapped in the MFMA)
+template <int M0, int N0>
+__device__ __forceinline__ void g256_cluster(const bf16x8 (&a)[4][2], const bf16x8 (&b)[2][2], f32x4 (&acc)[8][4]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                acc[M0 + m][N0 + n] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[n][kk], a[m][kk], acc[M0 + m][N0 + n], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+}
+
+#define G256_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// DMA for the first 1.5 K-tiles of an output tile (tile 0 complete, A of tile 1).  May be
+// issued while the previous output tile's epilogue is still running: the LDS image is free
+// once gemm256_mainloop has returned (it ends with a barrier behind every wave's last read).
+__device__ __forceinline__ void g256_issue_prologue(const G256Operand& A, const G256Operand& B, char* smem, int K,
+                                                    int wave) {
+    g256_issue_half(A, 0, 0, smem, wave);
+    g256_issue_half(A, 1, 0, smem, wave);
+    g256_issue_half(B, 0, 0, smem + 32768, wave);
+    g256_issue_half(B, 1, 0, smem + 32768, wave);
+    if (K > 64) {
+        g256_issue_half(A, 0, 128, smem + G256_STAGE, wave);
+        g256_issue_half(A, 1, 128, smem + G256_STAGE, wave);
+    }
+}
+
+// K % 64 == 0, K >= 64.  acc must be zero-initialised (or hold the running sum) by the caller,
+// and g256_issue_prologue(A, B, ...) must have been issued by this wave (any vector-memory
+// operations issued after it only make the first wait below more conservative).
+__device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G256Operand& B, char* smem, int K,
+                                                 int wave, int lane, f32x4 (&acc)[8][4]) {
+    const int nt = K >> 6;
+    G256Frags f;
+    G256Addr ad;
+    g256_addr_init(ad, wave, lane);
+
+    if (nt > 1) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    g256_read_a<0>(f.alo, ad.a[0]);
+    g256_read_b<0>(f.blo, ad.b[0]);
+    G256_FENCE();
+
+    for (int t = 0; t < nt; t += 2) {
+        // ------------------------------------------------------------ even tile t, stage 0
+        {
+            char* cur = smem;
+            char* oth = smem + G256_STAGE;
+            const bool n1 = t + 1 < nt, n2 = t + 2 < nt;
+            // P0
+            g256_read_a<64>(f.ahi, ad.a[0]);
+            if (n1) g256_issue_half(B, 0, (t + 1) * 128, oth + 32768, wave);
+            G256_FENCE();
+            g256_cluster<0, 0>(f.alo, f.blo, acc);
+            G256_FENCE();
+            // P1
+            g256_read_b<32>(f.bhi, ad.b[0]);
+            if (n1) g256_issue_half(B, 1, (t + 1) * 128, oth + 32768, wave);
+            G256_FENCE();
+            g256_cluster<4, 0>(f.ahi, f.blo, acc);
+            G256_FENCE();
+            // P2: every wave has retired its A reads of this stage -> refill its A halves
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (n2) g256_issue_half(A, 0, (t + 2) * 128, cur, wave);
+            G256_FENCE();
+            g256_cluster<4, 2>(f.ahi, f.bhi, acc);
+            G256_FENCE();
+            // P3: publish tile t+1, start reading it
+            if (n2) g256_issue_half(A, 1, (t + 2) * 128, cur, wave);
+            if (n1) {
+                if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                g256_read_a<64>(f.ahi, ad.a[1]);          // odd tiles start with A-hi
+                g256_read_b<0>(f.blo, ad.b[1]);
+            }
+            G256_FENCE();
+            g256_cluster<0, 2>(f.alo, f.bhi, acc);
+            G256_FENCE();
+        }
+        if (t + 1 >= nt) break;
+        // ------------------------------------------------------------ odd tile t+1, stage 1
+        {
+            char* cur = smem + G256_STAGE;
+            char* oth = smem;
+            const int u = t + 1;
+            const bool n1 = u + 1 < nt, n2 = u + 2 < nt;
+            // P0'
+            g256_read_a<0>(f.alo, ad.a[1]);
+            if (n1) g256_issue_half(B, 0, (u + 1) * 128, oth + 32768, wave);
+            G256_FENCE();
+            g256_cluster<4, 0>(f.ahi, f.blo, acc);
+            G256_FENCE();
+            // P1'
+            g256_read_b<32>(f.bhi, ad.b[1]);
+            if (n1) g256_issue_half(B, 1, (u + 1) * 128, oth + 32768, wave);
+            G256_FENCE();
+            g256_cluster<0, 0>(f.alo, f.blo, acc);
+            G256_FENCE();
+            // P2'
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (n2) g256_issue_half(A, 0, (u + 2) * 128, cur, wave);
+            G256_FENCE();
+            g256_cluster<0, 2>(f.alo, f.bhi, acc);
+            G256_FENCE();
+            // P3'
+            if (n2) g256_issue_half(A, 1, (u + 2) * 128, cur, wave);
+            if (n1) {
+                if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                g256_read_a<0>(f.alo, ad.a[0]);               // even tiles start with A-lo
+                g256_read_b<0>(f.blo, ad.b[0]);
+            }
+            G256_FENCE();
+            g256_cluster<4, 2>(f.ahi, f.bhi, acc);
+            G256_FENCE();
+        }
+    }
+    // all waves are past their last LDS read before the caller reuses the LDS image
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+}  // namespace revo

@@ -24,6 +24,8 @@ struct GemmArgs {
     int S, G2, cls;              //                           (EPI_PATCH)
 };
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
+void gemm_set_debug(int d);
+void gemm_force_tile(int t);   // 0 = heuristic, 128 or 256 = forced
 
 // --------------------------------------------------------- elementwise -----
 // out = LayerNorm(x) * w + b over rows of width W (fp32 statistics, two-pass).
@@ -47,6 +49,9 @@ int launch_transpose_f32_to_bf16(const float* src, int rows, int cols, bf16_t* d
 // ----------------------------------------------------------- attention -----
 // qkv [B*S][ld] bf16 (q | k | v thirds, heads contiguous inside a third) -> out [B*S][ldo] bf16
 int launch_attention(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, int hd, hipStream_t st);
+// has_cls: row 0 is the class token and may be scheduled apart from the patch rows (same result)
+int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, int hd, int has_cls,
+                        hipStream_t st);
 // single-probe attention pool: q [W] fp32 (already projected and scaled), kv [B*S][ld] bf16 (k | v halves)
 int launch_pool_attention(const float* q, const bf16_t* kv, long ld, bf16_t* out, long ldo, int B, int S, int H,
                           int hd, hipStream_t st);

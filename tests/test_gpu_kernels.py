@@ -13,6 +13,14 @@ pytestmark = pytest.mark.gpu
 EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32 = 0, 1, 2, 3
 
 
+@pytest.fixture(params=[128, 256], autouse=True)
+def gemm_tile(request, lib):
+    """Every test in this file runs once per GEMM tile configuration."""
+    _lib.check(lib.revo_op_set_gemm_tile(request.param))
+    yield request.param
+    _lib.check(lib.revo_op_set_gemm_tile(0))
+
+
 def _gemm(lib, epi, a, b, c, bias=None, gamma=None):
     M, K = a.shape
     N = b.shape[0]
@@ -22,7 +30,8 @@ def _gemm(lib, epi, a, b, c, bias=None, gamma=None):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 1024), (300, 260, 128), (1154, 384, 128),
-                                   (37, 1024, 1024), (1, 128, 64), (577, 3072, 1024), (129, 132, 4096)])
+                                   (37, 1024, 1024), (1, 128, 64), (577, 3072, 1024), (129, 132, 4096),
+                                   (2308, 1024, 1024), (1030, 516, 192), (256, 256, 64), (257, 260, 128)])
 def test_gemm_f32(lib, dev, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
     a = torch.randn(M, K, generator=g).to(dev).bfloat16()
