@@ -1,0 +1,458 @@
+"""``SimpleReverso`` façade over the MI355X-native embed + search path.
+
+Same class name, method names, argument meaning, return shapes and ``❌ / ⚠️``
+string conventions as the reference's ``core_system.py`` (class at ``:44``), so the
+reference's ``ui.py`` / ``main.py`` run on top of it unchanged.
+What differs underneath:
+
+* ``encode_image`` (``:341``, ``:442``) is the HIP forward in ``librevo.so``;
+* the vector store (``QdrantClient``, ``:100``, ``:521``, ``:600-622``, ``:659-664``) is a
+  device-resident gallery with bit-exact fp32 re-scored top-k;
+* ``create_database`` embeds in batches (decode threads overlap the device) instead
+  of one image per forward (``:541-591``), and its checkpoint/resume works;
+* GroundedSAM (``:205-318``) is third-party and out of scope: a detector callable can be
+  injected (``detector=``); without one every image is one full-frame region, which
+  is also what the reference's embedding of a region amounts to (``:406`` "Use global
+  for now": every region receives the global embedding).
+
+There is no CPU fallback: constructing the class without a GPU raises.
+"""
+import os
+import shutil
+import threading
+import uuid
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+from PIL import Image, ImageDraw, ImageFont
+
+from . import preprocess as pp
+from . import store as st
+from .config import DEFAULT_VARIANT, available_configs, get_config
+from .engine import VitEngine
+from .weights import load_state_dict, synth_weights
+
+DB_ROOT = "./simple_reverso_db"
+IMAGE_EXTENSIONS = ['.jpg', '.jpeg', '.png', '.bmp', '.tiff', '.webp']
+
+
+class Regions:
+    """Minimal stand-in for ``supervision.Detections`` (xyxy, mask, confidence, class_id)."""
+
+    def __init__(self, xyxy, mask=None, confidence=None, class_id=None, class_names=None):
+        self.xyxy = np.asarray(xyxy, dtype=np.float32).reshape(-1, 4)
+        self.mask = mask
+        n = len(self.xyxy)
+        self.confidence = np.ones(n, np.float32) if confidence is None else np.asarray(confidence, np.float32)
+        self.class_id = np.zeros(n, np.int64) if class_id is None else np.asarray(class_id, np.int64)
+        self.class_names = class_names or ["object"]
+
+    def __len__(self):
+        return len(self.xyxy)
+
+
+class SimpleReverso:
+    """Simplified visual investigation system (MI355X-native hot path)."""
+
+    def __init__(self, model_name=DEFAULT_VARIANT, checkpoint=None, device=0, db_root=DB_ROOT, max_batch=64,
+                 detector=None, decode_workers=8, synthetic_seed=0):
+        print("🚀 Initializing Simple Revers-o...")
+        self.db_root = db_root
+        self.max_batch = int(max_batch)
+        self.detector = detector
+        self._decode_pool = ThreadPoolExecutor(max_workers=int(decode_workers))
+        self._lock = threading.RLock()      # ui.py drives one shared instance from worker threads
+        self.device = self.setup_device(device)
+        self.pe_model, self.preprocess = self.load_pe_model(model_name, checkpoint, synthetic_seed)
+        self.grounded_sam = None
+        self.vector_db = None
+        self.current_database = None
+        self.detected_regions = []
+        self.region_embeddings = None
+        self.query_embedding_for_search = None
+        self._stop_requested = False
+        self._last_processed_file = None
+        self._partial_embeddings = []
+        self._partial_metadata = []
+        print("✅ Simple Revers-o ready!")
+
+    # ------------------------------------------------------------- DB admin --
+    def list_databases(self):
+        """core_system.py:74-88"""
+        if not os.path.exists(self.db_root):
+            return []
+        return [n for n in os.listdir(self.db_root)
+                if os.path.isdir(os.path.join(self.db_root, n)) and n != "checkpoints"]
+
+    def load_database(self, database_name):
+        """core_system.py:90-119"""
+        if not database_name:
+            return "❌ Please provide a database name"
+        db_path = os.path.join(self.db_root, database_name)
+        if not os.path.exists(db_path):
+            return f"❌ Database not found: {database_name}"
+        try:
+            if not os.path.exists(os.path.join(db_path, "meta.json")):
+                return f"❌ Collection not found in database: {database_name}"
+            with self._lock:
+                if self.vector_db is not None:
+                    self.vector_db.close()
+                self.vector_db = st.GalleryStore.load(db_path, device=self.device.index or 0)
+                self.current_database = self.vector_db.collection
+            return f"✅ Loaded database: {database_name}"
+        except Exception as e:
+            return f"❌ Error loading database: {str(e)}"
+
+    def delete_database(self, database_name):
+        """core_system.py:121-135"""
+        if not database_name:
+            return "❌ Please provide a database name"
+        db_path = os.path.join(self.db_root, database_name)
+        if not os.path.exists(db_path):
+            return f"❌ Database not found: {database_name}"
+        try:
+            shutil.rmtree(db_path)
+            return f"✅ Deleted database: {database_name}"
+        except Exception as e:
+            return f"❌ Error deleting database: {str(e)}"
+
+    def unlock_database(self, database_name):
+        """core_system.py:137-154"""
+        if not database_name:
+            return "❌ Please provide a database name"
+        db_path = os.path.join(self.db_root, database_name)
+        if not os.path.exists(db_path):
+            return f"❌ Database not found: {database_name}"
+        lock_file = os.path.join(db_path, ".lock")
+        if os.path.exists(lock_file):
+            try:
+                os.remove(lock_file)
+                return f"✅ Removed lock file from database: {database_name}"
+            except Exception as e:
+                return f"❌ Error removing lock file: {str(e)}"
+        return f"ℹ️ No lock file found for database: {database_name}"
+
+    # -------------------------------------------------------- model lifecycle --
+    def setup_device(self, device=0):
+        """core_system.py:156-167 — ROCm reports as ``cuda``; no MPS / CPU path here."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("revers-o_amd needs an MI355X (ROCm) device: the hot path has no CPU fallback")
+        dev = torch.device("cuda", int(device))
+        print(f"🔥 Using ROCm device: {dev} ({torch.cuda.get_device_name(dev)})")
+        return dev
+
+    def load_pe_model(self, target_model=DEFAULT_VARIANT, checkpoint=None, synthetic_seed=0):
+        """core_system.py:169-203: target model first, else the first available config."""
+        print(f"📚 Loading {target_model}...")
+        configs = available_configs()
+        print(f"Available PE configs: {configs}")
+        try:
+            cfg = get_config(target_model)
+        except KeyError:
+            cfg = get_config(configs[0])
+            print(f"🔄 Using available: {configs[0]}")
+        checkpoint = checkpoint or os.environ.get("REVERSO_PE_CHECKPOINT")
+        if checkpoint:
+            sd = load_state_dict(checkpoint)
+            print(f"✅ Loaded {cfg.name} weights from {checkpoint}")
+        else:
+            # no network here: pretrained weights (pe.CLIP.from_config(..., pretrained=True), :181)
+            # must be supplied as a file; without one the tower is random-initialised.
+            print("⚠️ No checkpoint given (REVERSO_PE_CHECKPOINT): using seeded random-init weights")
+            sd = synth_weights(cfg, seed=synthetic_seed, device=self.device)
+        engine = VitEngine(cfg, sd, device=self.device.index or 0, max_batch=self.max_batch)
+        size = cfg.image_size
+        print("⚡ bf16 MFMA matmuls, fp32 residual stream")
+        return engine, (lambda image: pp.resize_u8(image, size))
+
+    # ------------------------------------------------------------- detection --
+    def detect_regions(self, image, text_prompt=None):
+        """core_system.py:237-318.  Delegates to the injected detector; without one the
+        whole frame is the single region."""
+        self.detected_regions = []
+        self.region_embeddings = None
+        self.query_embedding_for_search = None
+        pil = pp.to_pil(image)
+        if self.detector is not None:
+            det = self.detector(pil, text_prompt or "object")
+            self.detected_regions = det
+            return len(det)
+        w, h = pil.size
+        self.detected_regions = Regions([[0, 0, w, h]], mask=None, class_names=["full_image"])
+        return 1
+
+    def _region_metadata(self, pil, regions):
+        """Per-region metadata exactly as core_system.py:363-425 builds it (cap 50, empty masks
+        skipped, missing masks -> full-image bbox); returns (kept indices, metadata)."""
+        names = getattr(regions, "class_names", None) or ["object"]
+        kept, metas = [], []
+        for i in range(min(len(regions), 50)):
+            conf = float(regions.confidence[i]) if i < len(regions.confidence) else 0.0
+            cid = int(regions.class_id[i]) if i < len(regions.class_id) else -1
+            mask = regions.mask[i] if getattr(regions, "mask", None) is not None and i < len(regions.mask) else None
+            if mask is None:
+                metas.append({"region_id": str(uuid.uuid4()), "bbox": [0, 0, pil.width, pil.height], "area_ratio": 1.0,
+                              "detection_index": i, "confidence": conf,
+                              "detected_class": names[cid] if 0 <= cid < len(names) else "unknown",
+                              "mask_status": "missing_or_unavailable"})
+                kept.append(i)
+                continue
+            m = np.asarray(mask)
+            m = (m > 0.5).astype(np.uint8) if np.issubdtype(m.dtype, np.floating) else m.astype(np.uint8)
+            if m.sum() == 0:
+                print(f"⚠️ Empty mask for region {i}, skipping")
+                continue
+            ys, xs = np.where(m)
+            metas.append({"region_id": str(uuid.uuid4()),
+                          "bbox": [int(xs.min()), int(ys.min()), int(xs.max()), int(ys.max())],
+                          "area_ratio": float(m.sum() / m.size), "detection_index": i, "confidence": conf,
+                          "detected_class": names[cid] if 0 <= cid < len(names) else "object",
+                          "mask_status": "processed"})
+            kept.append(i)
+        return kept, metas
+
+    # ----------------------------------------------------------------- embed --
+    def _embed_pils(self, pils):
+        """list of PIL images -> fp32 CPU tensor [n, D] (L2-normalised)."""
+        size = self.pe_model.cfg.image_size
+        u8 = torch.stack(list(self._decode_pool.map(lambda im: pp.resize_u8(im, size), pils)))
+        with self._lock:
+            emb = self.pe_model.embed(u8.to(self.device, non_blocking=True))
+        return emb.cpu()
+
+    def extract_embeddings(self, image):
+        """core_system.py:320-429: one forward of the full image, every kept region receives
+        the global embedding (:406) with its own mask-derived metadata."""
+        if not self.detected_regions or len(self.detected_regions) == 0:
+            print("❌ No regions detected")
+            return [], []
+        pil = pp.to_pil(image)
+        g = self._embed_pils([pil])[0]
+        kept, metas = self._region_metadata(pil, self.detected_regions)
+        embeddings = [g.clone() for _ in kept]
+        self.region_embeddings = embeddings
+        print(f"🎯 Extracted {len(embeddings)} region embeddings")
+        return embeddings, metas
+
+    def process_image_direct_pe(self, image):
+        """core_system.py:431-455"""
+        pil = pp.to_pil(image)
+        e = self._embed_pils([pil])[0]
+        if e.dim() != 1:
+            raise ValueError(f"Unexpected feature shape: {tuple(e.shape)}")
+        self.region_embeddings = [e]
+        meta = {"region_id": str(uuid.uuid4()), "bbox": [0, 0, pil.width, pil.height], "area_ratio": 1.0,
+                "detection_index": 0, "confidence": 1.0, "detected_class": "full_image"}
+        return [e.clone()], [meta]
+
+    def request_stop(self):
+        """core_system.py:457-459"""
+        self._stop_requested = True
+
+    # ------------------------------------------------------- gallery build ----
+    def create_database(self, folder_path, database_name, text_prompt="person . car . building", use_direct_pe=False,
+                        progress_callback=None, resume_from_checkpoint=False, include_subfolders=False):
+        """core_system.py:461-648, with batched embedding and a working checkpoint."""
+        status_messages = []
+
+        def log_status(message, progress_value=None):
+            status_messages.append(message)
+            if progress_callback:
+                progress_callback(message, progress_value)
+            return "\n".join(status_messages)
+
+        os.makedirs(self.db_root, exist_ok=True)
+        db_path = os.path.join(self.db_root, database_name)
+        ckpt_base = os.path.join(self.db_root, "checkpoints", f"{database_name}_checkpoint")
+        processed_files = set()
+        if resume_from_checkpoint and os.path.exists(ckpt_base + ".json"):
+            try:
+                processed_files, self._partial_embeddings, self._partial_metadata = st.load_checkpoint(ckpt_base)
+                log_status(f"📋 Resuming from checkpoint: {len(processed_files)} files already processed")
+            except Exception as e:
+                log_status(f"⚠️ Error loading checkpoint: {str(e)}. Starting fresh.")
+                processed_files, self._partial_embeddings, self._partial_metadata = set(), [], []
+
+        log_status(f"📁 Creating database '{database_name}' from {folder_path}")
+        image_files = []
+        if include_subfolders:
+            for root, _, files in os.walk(folder_path):
+                image_files += [os.path.join(root, f) for f in files
+                                if any(f.lower().endswith(e) for e in IMAGE_EXTENSIONS)]
+        else:
+            image_files = [os.path.join(folder_path, f) for f in os.listdir(folder_path)
+                           if any(f.lower().endswith(e) for e in IMAGE_EXTENSIONS)]
+        image_files.sort()
+        if not image_files:
+            return log_status(f"❌ No images found in {folder_path}")
+        if resume_from_checkpoint:
+            image_files = [f for f in image_files if f not in processed_files]
+            if not image_files:
+                return log_status("✅ All files already processed. Database is complete.")
+        log_status(f"📊 Found {len(image_files)} images to process", 0.1)
+        if include_subfolders:
+            log_status("📂 Including images from subfolders")
+        log_status(f"🔧 Processing mode: {'Direct PE' if use_direct_pe else 'Detector + PE'}")
+        log_status(f"📂 Database will be stored at: {db_path}")
+
+        processed = failed = 0
+
+        def checkpoint():
+            try:
+                st.save_checkpoint(ckpt_base, processed_files, self._partial_embeddings, self._partial_metadata,
+                                   database_name, folder_path)
+            except Exception as e:
+                log_status(f"⚠️ Error saving checkpoint: {str(e)}")
+
+        def open_rgb(path):
+            try:
+                return Image.open(path).convert("RGB")
+            except Exception as e:           # per-image failure: logged and skipped (core_system.py:585-591)
+                return e
+
+        try:
+            B = self.max_batch
+            for s in range(0, len(image_files), B):
+                if self._stop_requested:
+                    log_status("🛑 Stop requested. Saving progress...")
+                    checkpoint()
+                    return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
+                paths = image_files[s:s + B]
+                pils = list(self._decode_pool.map(open_rgb, paths))
+                good = [(p, im) for p, im in zip(paths, pils) if not isinstance(im, Exception)]
+                embs = self._embed_pils([im for _, im in good]) if good else None
+                gi = 0
+                for j, (path, im) in enumerate(zip(paths, pils)):
+                    i = s + j
+                    filename = os.path.basename(path)
+                    log_status(f"🔄 Processing {i + 1}/{len(image_files)}: {filename}", 0.1 + 0.7 * (i / len(image_files)))
+                    processed_files.add(path)
+                    if isinstance(im, Exception):
+                        log_status(f"❌ Error processing {filename}: {str(im)}")
+                        failed += 1
+                        continue
+                    e = embs[gi]
+                    gi += 1
+                    if use_direct_pe:
+                        metas = [{"region_id": str(uuid.uuid4()), "bbox": [0, 0, im.width, im.height], "area_ratio": 1.0,
+                                  "detection_index": 0, "confidence": 1.0, "detected_class": "full_image"}]
+                        log_status(f"✅ Extracted global embedding for {filename}")
+                    else:
+                        n_reg = self.detect_regions(im, text_prompt)
+                        if n_reg == 0:
+                            log_status(f"⚠️ No regions found in {filename}, skipping")
+                            failed += 1
+                            continue
+                        _, metas = self._region_metadata(im, self.detected_regions)
+                        log_status(f"✅ Found {n_reg} regions, extracted {len(metas)} embeddings in {filename}")
+                    for m in metas:
+                        m["image_source"] = path
+                        m["filename"] = filename
+                        m["original_region_id"] = m.get("region_id", str(uuid.uuid4()))
+                        m["region_id"] = str(uuid.uuid4())
+                    self._partial_embeddings.extend(e.clone() for _ in metas)
+                    self._partial_metadata.extend(metas)
+                    processed += 1
+                    self._last_processed_file = path
+                    if processed % 10 == 0 or i == len(image_files) - 1:
+                        checkpoint()
+
+            if not self._partial_embeddings:
+                return log_status("❌ No embeddings extracted from any images")
+
+            vector_dim = self._partial_embeddings[0].shape[0]
+            collection_name = f"simple_reverso_{database_name}"
+            with self._lock:
+                if os.path.isdir(db_path):
+                    shutil.rmtree(db_path)                          # recreate_collection: start fresh
+                store = st.GalleryStore(vector_dim, device=self.device.index or 0,
+                                        capacity=len(self._partial_embeddings), collection=collection_name, path=db_path)
+                log_status(f"📦 Recreated collection: {collection_name}", 0.8)
+                n = len(self._partial_embeddings)
+                batch = 100
+                for j in range(0, n, batch):
+                    if self._stop_requested:
+                        log_status("🛑 Stop requested during database storage. Progress saved.")
+                        checkpoint()
+                        store.close()
+                        return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
+                    vec = torch.stack(self._partial_embeddings[j:j + batch])
+                    metas = self._partial_metadata[j:j + batch]
+                    store.upsert(vec, [m["region_id"] for m in metas], metas)
+                    log_status(f"💾 Stored batch {j // batch + 1}/{(n + batch - 1) // batch} ({len(metas)} points)",
+                               0.8 + 0.1 * (j / n))
+                store.save()
+                if self.vector_db is not None:
+                    self.vector_db.close()
+                self.vector_db = store
+                self.current_database = collection_name
+            if os.path.exists(ckpt_base + ".json"):
+                st.remove_checkpoint(ckpt_base)
+                log_status("🧹 Cleaned up checkpoint file")
+            log_status("\n📊 Final Summary:", 0.9)
+            log_status(f"✅ Successfully processed: {processed} images")
+            if failed > 0:
+                log_status(f"⚠️ Failed to process: {failed} images")
+            log_status(f"🔍 Total embeddings stored: {len(self._partial_embeddings)}")
+            log_status(f"🎯 Database '{database_name}' ready for searching!", 1.0)
+        finally:
+            self._stop_requested = False
+            self._partial_embeddings = []
+            self._partial_metadata = []
+        return "\n".join(status_messages)
+
+    # ---------------------------------------------------------------- search --
+    def search_similar(self, similarity_threshold=0.7, max_results=5):
+        """core_system.py:650-717: first region embedding as the query, limit + score
+        threshold, results best first with the same text and thumbnail formatting."""
+        if not self.region_embeddings:
+            return "❌ No query embeddings available. Please detect/process an image first.", []
+        if not self.vector_db or not self.current_database:
+            return "❌ No database loaded. Please create or load a database first.", []
+        query = self.region_embeddings[0]
+        with self._lock:
+            hits = self.vector_db.search(query, limit=int(max_results), score_threshold=float(similarity_threshold))
+        if not hits:
+            return f"❌ No similar regions found above threshold {similarity_threshold}", []
+        text = f"🎯 Found {len(hits)} similar regions:\n\n"
+        items = []
+        for i, r in enumerate(hits):
+            payload = r.payload
+            filename = payload.get("filename", "Unknown")
+            image_path = payload.get("image_source", "")
+            text += f"{i + 1}. {filename} (Similarity: {r.score:.3f})\n"
+            text += f"   Source: {image_path}\n"
+            text += f"   📍 Bounding box: {str(payload.get('bbox', '[0,0,0,0]'))}\n\n"
+            img = None
+            if os.path.exists(image_path):
+                try:
+                    img = Image.open(image_path).convert("RGB")
+                    draw = ImageDraw.Draw(img)
+                    try:
+                        font = ImageFont.truetype("Arial.ttf", max(15, int(min(img.height, img.width) * 0.05)))
+                    except IOError:
+                        font = ImageFont.load_default()
+                    label = f"Score: {r.score:.3f}"
+                    box = draw.textbbox((5, 5), label, font=font)
+                    draw.rectangle([box[0] - 2, box[1] - 2, box[2] + 2, box[3] + 2], fill="black")
+                    draw.text((5, 5), label, fill="white", font=font)
+                    img.thumbnail((400, 400), Image.Resampling.LANCZOS)
+                except Exception as e:
+                    print(f"❌ Error loading/processing image {image_path}: {e}")
+                    img = None
+            items.append({"image": img, "score": r.score, "filename": filename, "bbox": payload.get("bbox")})
+        return text, items
+
+    def visualize_detections(self, image, selected_region_index=None):
+        """core_system.py:719-757 draws mask contours with OpenCV (UI cosmetics, out of scope);
+        boxes are outlined with PIL so the UI keeps working."""
+        pil = pp.to_pil(image).copy()
+        if not self.detected_regions or len(self.detected_regions) == 0:
+            return pil
+        draw = ImageDraw.Draw(pil)
+        for i, box in enumerate(self.detected_regions.xyxy):
+            sel = i == selected_region_index
+            draw.rectangle([float(v) for v in box], outline=(0, 255, 0) if sel else (255, 0, 0), width=3 if sel else 1)
+            draw.text((float(box[0]) + 3, float(box[1]) + 3), f"{i + 1}", fill=(0, 0, 0) if sel else (255, 0, 0))
+        return pil

@@ -70,8 +70,9 @@ class ShardedSearch:
         if self.world == 1:
             return self.merge(s[None], i[None], k, threshold)
         Q = queries.shape[0]
-        ps = torch.empty((self.world, Q, k), dtype=s.dtype, device=s.device)
-        pi = torch.empty((self.world, Q, k), dtype=i.dtype, device=i.device)
+        # concatenated along dim 0 (the layout both RCCL and gloo accept), viewed as [world, Q, k]
+        ps = torch.empty((self.world * Q, k), dtype=s.dtype, device=s.device)
+        pi = torch.empty((self.world * Q, k), dtype=i.dtype, device=i.device)
         dist.all_gather_into_tensor(ps, s.contiguous(), group=self.group)
         dist.all_gather_into_tensor(pi, i.contiguous(), group=self.group)
-        return self.merge(ps, pi, k, threshold)
+        return self.merge(ps.view(self.world, Q, k), pi.view(self.world, Q, k), k, threshold)

@@ -1,0 +1,136 @@
+"""End to end through the SimpleReverso façade: BASELINE.json configs[0]
+(PE-Core-B16-224 on 32 local JPEGs, brute-force cosine top-5) against the CPU oracle
+run on the same decoded pixels; persistence, resume and the reference's result
+formatting."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image, ImageDraw
+
+import reverso_amd
+from reverso_amd import preprocess as pp
+from reverso_amd import weights
+from reverso_amd.core_system import SimpleReverso
+from oracle import pe_vit, search as osearch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_jpegs(folder, n=32, seed=0):
+    rng = np.random.default_rng(seed)
+    os.makedirs(folder, exist_ok=True)
+    paths = []
+    for i in range(n):
+        w, h = int(rng.integers(180, 400)), int(rng.integers(160, 360))
+        base = rng.integers(0, 256, (3,))
+        yy, xx = np.mgrid[0:h, 0:w]
+        arr = np.stack([(base[c] + (xx * rng.integers(1, 4) + yy * rng.integers(1, 4)) // 2) % 256 for c in range(3)], -1)
+        im = Image.fromarray(arr.astype(np.uint8))
+        d = ImageDraw.Draw(im)
+        for _ in range(4):
+            x0, y0 = int(rng.integers(0, w - 20)), int(rng.integers(0, h - 20))
+            d.ellipse([x0, y0, x0 + int(rng.integers(10, 120)), y0 + int(rng.integers(10, 120))],
+                      fill=tuple(int(v) for v in rng.integers(0, 256, 3)))
+        p = os.path.join(folder, f"img_{i:03d}.jpg")
+        im.save(p, quality=90)
+        paths.append(p)
+    return paths
+
+
+@pytest.fixture(scope="module")
+def system(tmp_path_factory, dev):
+    root = tmp_path_factory.mktemp("facade")
+    folder = str(root / "images")
+    paths = _make_jpegs(folder)
+    (root / "images" / "broken.jpg").write_bytes(b"not a jpeg")
+    r = SimpleReverso(model_name="PE-Core-B16-224", db_root=str(root / "simple_reverso_db"), max_batch=8)
+    return r, folder, paths, root
+
+
+def test_config1_b16_32_jpegs_top5(system):
+    r, folder, paths, root = system
+    seen = []
+    msg = r.create_database(folder, "cfg1", use_direct_pe=True, progress_callback=lambda m, v=None: seen.append((m, v)))
+    assert "✅ Successfully processed: 32 images" in msg and "⚠️ Failed to process: 1 images" in msg
+    assert "❌ Error processing broken.jpg" in msg and "🎯 Database 'cfg1' ready for searching!" in msg
+    assert seen[-1][1] == 1.0 and r.current_database == "simple_reverso_cfg1" and len(r.vector_db) == 32
+    assert r.list_databases() == ["cfg1"]
+
+    # oracle on the same decoded + resized pixels, fp32, one image per forward like the reference
+    cfg = reverso_amd.get_config("PE-Core-B16-224")
+    sd = weights.synth_weights(cfg, seed=0)
+    files = sorted(paths)
+    u8 = torch.stack([pp.resize_u8(p, 224) for p in files])
+    ref = pe_vit.embed_batch1(sd, cfg, pe_vit.preprocess_u8(u8)).numpy()
+    stored = r.vector_db.gallery.read().cpu().numpy()
+    order = [r.vector_db.payloads[i]["filename"] for i in range(32)]
+    assert order == [os.path.basename(p) for p in files]
+    assert ((stored * ref).sum(-1) >= 0.999).all()
+
+    # query = one gallery image, reference flow: process_image_direct_pe then search_similar
+    q = 7
+    embs, metas = r.process_image_direct_pe(files[q])
+    assert metas[0]["detected_class"] == "full_image" and metas[0]["bbox"][:2] == [0, 0]
+    text, items = r.search_similar(similarity_threshold=0.0, max_results=5)
+    assert text.startswith("🎯 Found 5 similar regions:") and len(items) == 5
+    assert items[0]["filename"] == os.path.basename(files[q]) and abs(items[0]["score"] - 1.0) < 1e-5
+    assert items[0]["image"] is not None and max(items[0]["image"].size) <= 400
+    assert all(items[i]["score"] >= items[i + 1]["score"] for i in range(4))
+    # scores agree with the fp32 oracle for the same files to 1e-3
+    rs, ri, rc = osearch.search(ref, ref[q:q + 1], 32)
+    oracle_score = {order[int(i)]: float(s) for s, i in zip(rs[0], ri[0])}
+    for it in items:
+        assert abs(it["score"] - oracle_score[it["filename"]]) <= 1e-3
+    # the product's own search over its stored vectors is exact against the oracle over the same vectors
+    hits = r.vector_db.search(embs[0], limit=5)
+    s2, i2, _ = osearch.search(stored, embs[0].numpy()[None], 5)
+    assert [h.payload["filename"] for h in hits] == [order[int(i)] for i in i2[0]]
+    # threshold above every non-identical score: only the image itself
+    text, items = r.search_similar(similarity_threshold=0.99999, max_results=5)
+    assert len(items) >= 1 and items[0]["filename"] == os.path.basename(files[q])
+    text, items = r.search_similar(similarity_threshold=1.5, max_results=5)
+    assert items == [] and text == "❌ No similar regions found above threshold 1.5"
+
+
+def test_persistence_and_reload(system):
+    r, folder, paths, root = system
+    before = r.vector_db.gallery.read().cpu()
+    assert r.load_database("cfg1") == "✅ Loaded database: cfg1"
+    after = r.vector_db.gallery.read().cpu()
+    assert torch.equal(before, after) and len(r.vector_db.payloads) == 32
+    r.process_image_direct_pe(sorted(paths)[3])
+    _, items = r.search_similar(0.0, 3)
+    assert items[0]["filename"] == "img_003.jpg"
+
+
+def test_detector_mode_and_resume(system):
+    r, folder, paths, root = system
+    # no detector injected: one full-frame region per image, same vectors as direct PE
+    n = r.detect_regions(paths[0], "person . car")
+    assert n == 1
+    embs, metas = r.extract_embeddings(paths[0])
+    assert len(embs) == 1 and metas[0]["mask_status"] == "missing_or_unavailable"
+    d_embs, _ = r.process_image_direct_pe(paths[0])
+    assert torch.equal(embs[0], d_embs[0])
+    # stop after the first batch, then resume: the final gallery equals an uninterrupted build
+    calls = {"n": 0}
+
+    def cb(m, v=None):
+        calls["n"] += 1
+        if m.startswith("🔄 Processing 9/"):
+            r.request_stop()
+    msg = r.create_database(folder, "resumed", use_direct_pe=True, progress_callback=cb)
+    assert "⏸️ Processing stopped" in msg
+    msg = r.create_database(folder, "resumed", use_direct_pe=True, resume_from_checkpoint=True)
+    assert "📋 Resuming from checkpoint" in msg and "🧹 Cleaned up checkpoint file" in msg
+    a = r.vector_db.gallery.read().cpu()
+    names = [p["filename"] for p in r.vector_db.payloads]
+    assert sorted(names) == sorted(os.path.basename(p) for p in paths) and len(names) == 32
+    assert r.load_database("cfg1").startswith("✅")
+    b = r.vector_db.gallery.read().cpu()
+    ref_names = [p["filename"] for p in r.vector_db.payloads]
+    perm = [ref_names.index(nm) for nm in names]
+    assert torch.equal(a, b[perm])
+    assert r.create_database(str(root), "empty", use_direct_pe=True).endswith(f"❌ No images found in {root}")

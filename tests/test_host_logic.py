@@ -1,0 +1,162 @@
+"""CPU: host-side logic above the C ABI (no device calls): database admin strings,
+checkpoint round trip, region metadata, preprocessing, the sharded-search protocol
+on gloo with world_size 2 (the oracle is injected as the compute step)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import reverso_amd  # noqa: F401
+from reverso_amd import preprocess as pp
+from reverso_amd import store as st
+from oracle import search as osearch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bare_facade(tmp_path):
+    from reverso_amd.core_system import SimpleReverso
+    import threading
+    r = object.__new__(SimpleReverso)            # no device: only the host-side methods are exercised
+    r.db_root = str(tmp_path / "simple_reverso_db")
+    r._lock = threading.RLock()
+    r.vector_db = None
+    r.current_database = None
+    r.region_embeddings = None
+    r._stop_requested = False
+    return r
+
+
+def test_database_admin_strings(tmp_path):
+    r = _bare_facade(tmp_path)
+    assert r.list_databases() == []
+    assert r.load_database("") == "❌ Please provide a database name"
+    assert r.load_database("nope") == "❌ Database not found: nope"
+    assert r.delete_database("nope") == "❌ Database not found: nope"
+    assert r.unlock_database("") == "❌ Please provide a database name"
+    os.makedirs(os.path.join(r.db_root, "alpha"))
+    os.makedirs(os.path.join(r.db_root, "checkpoints"))
+    assert r.list_databases() == ["alpha"]
+    assert r.load_database("alpha") == "❌ Collection not found in database: alpha"
+    assert r.unlock_database("alpha").startswith("ℹ️ No lock file found")
+    open(os.path.join(r.db_root, "alpha", ".lock"), "w").close()
+    assert r.unlock_database("alpha") == "✅ Removed lock file from database: alpha"
+    assert r.delete_database("alpha") == "✅ Deleted database: alpha"
+    # guards of search_similar (core_system.py:652-653)
+    assert r.search_similar()[0].startswith("❌ No query embeddings available")
+    r.region_embeddings = [torch.zeros(4)]
+    assert r.search_similar()[0].startswith("❌ No database loaded")
+    r.request_stop()
+    assert r._stop_requested
+
+
+def test_checkpoint_round_trip(tmp_path):
+    base = str(tmp_path / "checkpoints" / "db_checkpoint")
+    embs = [torch.randn(16) for _ in range(5)]
+    metas = [{"region_id": str(i), "bbox": [0, 0, i, i], "filename": f"{i}.jpg"} for i in range(5)]
+    st.save_checkpoint(base, {"a.jpg", "b.jpg"}, embs, metas, "db", "/tmp/x")
+    files, e2, m2 = st.load_checkpoint(base)
+    assert files == {"a.jpg", "b.jpg"} and m2 == metas
+    assert all(torch.equal(a, b) for a, b in zip(embs, e2))
+    st.remove_checkpoint(base)
+    assert not os.path.exists(base + ".json") and not os.path.exists(base + ".npy")
+    st.save_checkpoint(base, set(), [], [], "db", "/tmp/x")       # empty checkpoint is valid
+    assert st.load_checkpoint(base) == (set(), [], [])
+
+
+def test_region_metadata_rules(tmp_path):
+    from reverso_amd.core_system import Regions
+    from PIL import Image
+    r = _bare_facade(tmp_path)
+    pil = Image.new("RGB", (40, 30))
+    mask = np.zeros((3, 30, 40), dtype=bool)
+    mask[0, 5:10, 8:20] = True            # ordinary mask
+    # mask[1] stays empty -> skipped (core_system.py:402-404)
+    mask[2, 0:30, 0:40] = True
+    reg = Regions([[8, 5, 19, 9], [0, 0, 1, 1], [0, 0, 39, 29]], mask=mask, confidence=[0.9, 0.8, 0.7],
+                  class_id=[0, 1, 5], class_names=["person", "car"])
+    kept, metas = r._region_metadata(pil, reg)
+    assert kept == [0, 2]
+    assert metas[0]["bbox"] == [8, 5, 19, 9] and metas[0]["detected_class"] == "person"
+    assert abs(metas[0]["area_ratio"] - 60 / 1200) < 1e-9 and metas[0]["mask_status"] == "processed"
+    assert metas[1]["detected_class"] == "object" and metas[1]["area_ratio"] == 1.0
+    kept, metas = r._region_metadata(pil, Regions([[0, 0, 40, 30]]))      # no masks: full-image fallback
+    assert metas[0]["bbox"] == [0, 0, 40, 30] and metas[0]["mask_status"] == "missing_or_unavailable"
+    many = Regions(np.zeros((60, 4)))
+    assert len(r._region_metadata(pil, many)[0]) == 50                      # cap (core_system.py:363)
+
+
+def test_preprocess_matches_reference_transform():
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    arr = rng.integers(0, 256, (50, 70, 3), dtype=np.uint8)
+    u8 = pp.resize_u8(arr, 28)
+    assert u8.shape == (3, 28, 28) and u8.dtype == torch.uint8
+    ref = np.asarray(Image.fromarray(arr).convert("RGB").resize((28, 28), Image.BILINEAR)).transpose(2, 0, 1)
+    assert np.array_equal(u8.numpy(), ref)
+    x = pp.normalize_u8(u8)
+    assert torch.allclose(x, (torch.from_numpy(ref).float() / 255 - 0.5) / 0.5)
+    assert float(x.min()) >= -1 and float(x.max()) <= 1
+    same = pp.resize_u8(Image.fromarray(arr[:28, :28]), 28)                 # already at size: untouched
+    assert np.array_equal(same.numpy(), arr[:28, :28].transpose(2, 0, 1))
+    assert pp.batch_u8([arr, arr], 28).shape == (2, 3, 28, 28)
+
+
+# --------------------------------------------------------------- gloo, world 2 ---
+def _shard_worker(rank, world, port, tmp, N, D, Q, k):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from reverso_amd import sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7)
+    gal = osearch.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+    gal[10:14] = gal[10]                                # a tie group that straddles nothing but must stay ordered
+    qs = osearch.normalize_rows(rng.standard_normal((Q, D), dtype=np.float32))
+    sizes = [N // world + (1 if r < N % world else 0) for r in range(world)]
+    lo = sum(sizes[:rank])
+    mine = gal[lo:lo + sizes[rank]]
+
+    def local_search(q, kk, thr, off):
+        s, i, c = osearch.search(mine, q.numpy(), kk, thr, normalize=False)
+        return torch.from_numpy(s), torch.from_numpy(np.where(i >= 0, i + off, -1)), torch.from_numpy(c)
+
+    def merge(ps, pi, kk, thr):
+        s, i, c = osearch.merge_topk(ps.numpy(), pi.numpy(), kk, thr)
+        return torch.from_numpy(s), torch.from_numpy(i), torch.from_numpy(c)
+
+    ss = sharded.ShardedSearch(local_search, merge, sizes[rank])
+    assert ss.offset == lo and ss.total_rows == N
+    # data-parallel queries: each rank contributes its slice, gather gives everyone all of them
+    per = Q // world
+    allq = ss.gather_queries(torch.from_numpy(qs[rank * per:(rank + 1) * per]))
+    assert np.array_equal(allq.numpy(), qs[: per * world])
+    out = {}
+    for thr in (None, 0.05):
+        s, i, c = ss.search(allq, k, thr)
+        out[str(thr)] = (s.numpy(), i.numpy(), c.numpy())
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), **{f"{t}_{n}": v for t, (a, b, c) in out.items()
+                                                        for n, v in (("s", a), ("i", b), ("c", c))})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_search_protocol_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    N, D, Q, k, world = 1001, 64, 6, 7, 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_shard_worker, args=(world, port, str(tmp_path), N, D, Q, k), nprocs=world, join=True)
+    rng = np.random.default_rng(7)
+    gal = osearch.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+    gal[10:14] = gal[10]
+    qs = osearch.normalize_rows(rng.standard_normal((Q, D), dtype=np.float32))
+    for thr in (None, 0.05):
+        rs, ri, rc = osearch.search(gal, qs, k, thr, normalize=False)
+        for rank in range(world):
+            got = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+            assert np.array_equal(got[f"{thr}_i"], ri)
+            assert np.array_equal(got[f"{thr}_c"], rc)
+            np.testing.assert_allclose(got[f"{thr}_s"], rs, atol=1e-6)
