@@ -438,11 +438,12 @@ struct revo_gallery {
     bf16_t* gb = nullptr;      // [capacity][D] normalised rows, scan copy
     float* gf = nullptr;       // [capacity][D] normalised rows, fp32 master (re-score + persistence)
     // per-call workspace, grown on demand
-    float* qf = nullptr; bf16_t* qb = nullptr; int q_cap = 0;
+    float* qf = nullptr; bf16_t* qb = nullptr; float* tau0 = nullptr; int q_cap = 0;
     uint64_t* part = nullptr; size_t part_cap = 0;
     float* stage = nullptr; size_t stage_cap = 0;
     ~revo_gallery() {
         (void)hipFree(gb); (void)hipFree(gf); (void)hipFree(qf); (void)hipFree(qb); (void)hipFree(part);
+        (void)hipFree(tau0);
         (void)hipFree(stage);
     }
 };
@@ -540,25 +541,63 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
     const int D = g->D;
     // over-selection: the bf16 scan keeps ksel >= k + margin candidates, the fp32 re-score decides
     const int ksel = (k <= 16) ? 32 : 64;
-    const int splits = topk_scan_workspace_splits(Q, g->size);
+    const long N = g->size;
     if (g->q_cap < Q) {
         REVO_HIP_CHECK(hipStreamSynchronize(st));
-        (void)hipFree(g->qf); (void)hipFree(g->qb); g->qf = nullptr; g->qb = nullptr; g->q_cap = 0;
+        (void)hipFree(g->qf); (void)hipFree(g->qb); (void)hipFree(g->tau0);
+        g->qf = nullptr; g->qb = nullptr; g->tau0 = nullptr; g->q_cap = 0;
         REVO_HIP_CHECK(hipMalloc((void**)&g->qf, (size_t)Q * D * 4));
         REVO_HIP_CHECK(hipMalloc((void**)&g->qb, (size_t)Q * D * 2));
+        REVO_HIP_CHECK(hipMalloc((void**)&g->tau0, (size_t)Q * 4));
         g->q_cap = Q;
     }
-    const size_t part_need = (size_t)Q * splits * ksel * 8;
-    if (g->part_cap < part_need) {
-        REVO_HIP_CHECK(hipStreamSynchronize(st));
-        (void)hipFree(g->part); g->part = nullptr; g->part_cap = 0;
-        REVO_HIP_CHECK(hipMalloc((void**)&g->part, part_need));
-        g->part_cap = part_need;
-    }
+    auto need_part = [&](size_t bytes) -> int {
+        if (g->part_cap < bytes) {
+            REVO_HIP_CHECK(hipStreamSynchronize(st));
+            (void)hipFree(g->part); g->part = nullptr; g->part_cap = 0;
+            REVO_HIP_CHECK(hipMalloc((void**)&g->part, bytes));
+            g->part_cap = bytes;
+        }
+        return 0;
+    };
     { ProfScope ps("search_prep", st);
       CHECK_RC(launch_l2norm_rows(queries, D, g->qf, D, g->qb, D, Q, D, st)); }
+
+    if (ksel == 32 && N >= 16384) {
+        // ---- 256 x 256 scan.  Pre-pass: a plain GEMM of the queries against the first n_pre rows and a
+        // per-row selection seed the admission scores; the fused scan covers rows [n_pre, N).
+        long n_pre = ((512l << 20) / (4l * Q)) / 256 * 256;
+        n_pre = n_pre > 8192 ? 8192 : (n_pre < 1024 ? 1024 : n_pre);
+        const int splits = topk_scan256_splits(Q, N - n_pre);
+        const int lists = splits + 1;
+        const size_t part_bytes = (size_t)Q * lists * ksel * 8;
+        const size_t pre_off = (part_bytes + 255) / 256 * 256;
+        CHECK_RC(need_part(pre_off + (size_t)Q * n_pre * 4));
+        uint64_t* part = g->part;
+        float* pre_scores = (float*)((char*)g->part + pre_off);
+        {
+            ProfScope ps("topk_prepass", st);
+            GemmArgs ga{};
+            ga.A = g->qb; ga.lda = D; ga.B = g->gb; ga.ldb = D; ga.M = Q; ga.N = (int)n_pre; ga.K = D;
+            ga.C = pre_scores; ga.ldc = n_pre;
+            CHECK_RC(launch_gemm(EPI_F32, ga, st));
+            REVO_HIP_CHECK(hipMemsetAsync(part, 0, part_bytes, st));
+            CHECK_RC(launch_topk_select_rows(pre_scores, n_pre, (int)n_pre, Q, part, (long)lists * ksel, splits,
+                                             g->tau0, st));
+        }
+        { ProfScope ps("topk_scan", st);
+          CHECK_RC(launch_topk_scan256(g->qb, D, g->gb, D, Q, N, D, n_pre, splits, part, lists, g->tau0, st)); }
+        { ProfScope ps("topk_reduce", st); CHECK_RC(launch_topk_reduce(part, Q, lists, ksel, st)); }
+        { ProfScope ps("topk_finish", st);
+          CHECK_RC(launch_topk_finish(part, (long)lists * ksel, ksel, g->qf, D, g->keep_f32 ? g->gf : nullptr, D, D, Q,
+                                      k, has_thr, thr, index_offset, scores, (long long*)indices, counts, st)); }
+        return 0;
+    }
+    // ---- small galleries (and k > 16): 128 x 128 scan with per-wave LDS lists
+    const int splits = topk_scan_workspace_splits(Q, N);
+    CHECK_RC(need_part((size_t)Q * splits * ksel * 8));
     ScanArgs a{};
-    a.Qb = g->qb; a.ldq = D; a.Gb = g->gb; a.ldg = D; a.Q = Q; a.N = g->size; a.D = D; a.ksel = ksel;
+    a.Qb = g->qb; a.ldq = D; a.Gb = g->gb; a.ldg = D; a.Q = Q; a.N = N; a.D = D; a.ksel = ksel;
     a.splits = splits; a.part = g->part;
     { ProfScope ps("topk_scan", st); CHECK_RC(launch_topk_scan(a, st)); }
     { ProfScope ps("topk_reduce", st); CHECK_RC(launch_topk_reduce(g->part, Q, splits, ksel, st)); }

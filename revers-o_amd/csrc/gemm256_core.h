@@ -155,7 +155,9 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
     g256_read_b<0>(f.blo, ad.b[0]);
     G256_FENCE();
 
-    for (int t = 0; t < nt; t += 2) {
+    // two K-tiles per trip; an odd trailing tile is peeled so the loop has a single exit
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
         // ------------------------------------------------------------ even tile t, stage 0
         {
             char* cur = smem;
@@ -193,7 +195,6 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             g256_cluster<0, 2>(f.alo, f.bhi, acc);
             G256_FENCE();
         }
-        if (t + 1 >= nt) break;
         // ------------------------------------------------------------ odd tile t+1, stage 1
         {
             char* cur = smem + G256_STAGE;
@@ -230,6 +231,45 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             }
             G256_FENCE();
             g256_cluster<4, 2>(f.ahi, f.bhi, acc);
+            G256_FENCE();
+        }
+    }
+    if (t < nt) {
+        // ------------------------------------------------------------ even tile t, stage 0
+        {
+            char* cur = smem;
+            char* oth = smem + G256_STAGE;
+            const bool n1 = t + 1 < nt, n2 = t + 2 < nt;
+            // P0
+            g256_read_a<64>(f.ahi, ad.a[0]);
+            if (n1) g256_issue_half(B, 0, (t + 1) * 128, oth + 32768, wave);
+            G256_FENCE();
+            g256_cluster<0, 0>(f.alo, f.blo, acc);
+            G256_FENCE();
+            // P1
+            g256_read_b<32>(f.bhi, ad.b[0]);
+            if (n1) g256_issue_half(B, 1, (t + 1) * 128, oth + 32768, wave);
+            G256_FENCE();
+            g256_cluster<4, 0>(f.ahi, f.blo, acc);
+            G256_FENCE();
+            // P2: every wave has retired its A reads of this stage -> refill its A halves
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (n2) g256_issue_half(A, 0, (t + 2) * 128, cur, wave);
+            G256_FENCE();
+            g256_cluster<4, 2>(f.ahi, f.bhi, acc);
+            G256_FENCE();
+            // P3: publish tile t+1, start reading it
+            if (n2) g256_issue_half(A, 1, (t + 2) * 128, cur, wave);
+            if (n1) {
+                if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                g256_read_a<64>(f.ahi, ad.a[1]);          // odd tiles start with A-hi
+                g256_read_b<0>(f.blo, ad.b[1]);
+            }
+            G256_FENCE();
+            g256_cluster<0, 2>(f.alo, f.bhi, acc);
             G256_FENCE();
         }
     }

@@ -74,6 +74,15 @@ int launch_topk_reduce(uint64_t* part, int Q, int splits, int ksel, hipStream_t 
 int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const float* Qf, long ldqf, const float* Gf,
                        long ldgf, int D, int Q, int k, int has_thr, float thr, long idx_offset, float* out_scores,
                        long long* out_idx, int* out_counts, hipStream_t st);
+// 256 x 256 tile scan with queue + drain selection (topk256.hip); KSEL = 32
+int topk_scan256_splits(int Q, long rows);
+int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
+                        int splits, uint64_t* part, int lists_per_query, const float* tau0, hipStream_t st);
+int launch_topk_seed(const uint64_t* pre, long pre_stride, uint64_t* part, long part_row_stride, int slot, int Q,
+                     float* tau0, hipStream_t st);
+// pre-pass of the 256 x 256 scan: KSEL best columns of every row of a [Q][n] fp32 score matrix
+int launch_topk_select_rows(const float* scores, long ld, int n, int Q, uint64_t* part, long part_row_stride, int slot,
+                            float* tau0, hipStream_t st);
 // all-padding result for an empty gallery
 int launch_topk_fill_empty(float* s, long long* i, int* c, int Q, int k, hipStream_t st);
 // merge P per-shard result lists [P][Q][k] -> [Q][k]

@@ -299,6 +299,46 @@ int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const f
     return 0;
 }
 
+// ------------------------------------------- pre-pass: top-KSEL of score rows ----
+// scores [Q][n] fp32 (a plain GEMM of the queries against the first n gallery rows) ->
+// the KSEL best (score, column) keys of every row, best first, written to
+// part[q][slot][KSEL], and tau0[q] = the KSEL-th score (-inf if fewer than KSEL columns).
+// One wave per query; a 64-column chunk is sorted and merged only if it can change the result.
+template <int KSEL>
+__global__ __launch_bounds__(256) void topk_select_rows_kernel(const float* __restrict__ scores, long lds_, int n,
+                                                               int Q, uint64_t* __restrict__ part, long part_row_stride,
+                                                               int slot, float* __restrict__ tau0) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const float* row = scores + (long)q * lds_;
+    uint64_t run = 0ull;
+    float tau = -INFINITY;
+    for (int base = 0; base < n; base += 64) {
+        const int c = base + lane;
+        const float s = c < n ? row[c] : -INFINITY;
+        if (__ballot(s >= tau && c < n) == 0ull) continue;
+        uint64_t v = c < n ? make_key(s, (uint32_t)c) : 0ull;
+        v = wave_sort_desc(v, lane);
+        const uint64_t rev = shfl_xor_u64(v, 63);
+        const uint64_t mx = run > rev ? run : rev;
+        run = wave_bitonic_merge_desc(mx, lane);
+        if (lane >= KSEL) run = 0ull;
+        const uint64_t last = readlane_u64(run, KSEL - 1);
+        tau = last ? key_score(last) : -INFINITY;
+    }
+    if (lane < KSEL) part[(long)q * part_row_stride + (long)slot * KSEL + lane] = run;
+    if (lane == 0) tau0[q] = tau;
+}
+int launch_topk_select_rows(const float* scores, long ld, int n, int Q, uint64_t* part, long part_row_stride, int slot,
+                            float* tau0, hipStream_t st) {
+    if (Q <= 0) return 0;
+    hipLaunchKernelGGL((topk_select_rows_kernel<32>), dim3((Q + 3) / 4), dim3(256), 0, st, scores, ld, n, Q, part,
+                       part_row_stride, slot, tau0);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------- empty-gallery result ----
 __global__ void topk_fill_empty_kernel(float* s, long long* i, int* c, int Q, int k) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,319 @@
+// Query x gallery scan on the 256 x 256 MFMA main loop (gemm256_core.h) with the top-k
+// candidate selection fused behind it: the form used for every gallery that is not tiny.
+//
+// One workgroup = 256 queries x one contiguous slice of the gallery, walked in 256-row
+// tiles.  After each tile a lane compares its 128 scores with the admission score of its
+// 8 query rows (running KSEL-th best: a lower bound of the final one, so nothing that can
+// end up in the top KSEL is ever dropped).  Survivors are rare after the first tiles; they
+// are appended to a 2048-entry LDS queue as 64-bit entries  row | score | ~index.  When the
+// queue passes half full the workgroup drains it: a bitonic sort of the queue groups the
+// entries by query row (best first), and each row's best <= KSEL entries are merged into
+// that row's candidate list, which lives in global memory (L2 resident, touched only at
+// drains) because the 128 KiB main-loop image leaves no room for 256 lists in LDS.  The
+// admission scores are seeded by a pre-pass over the first rows of the gallery (topk.hip),
+// so even the first tile admits only a handful of entries per row.
+// The next tile's first DMA is issued before the selection runs, so its HBM latency is
+// hidden behind the compares.
+#include "gemm256_core.h"
+#include "kernels.h"
+
+namespace revo {
+
+constexpr int S256_QCAP = 2048;          // queue entries
+constexpr int S256_DRAIN = 1024;         // drain once this many are queued
+constexpr int S256_KSEL = 32;
+constexpr int S256_LDS = G256_LDS + S256_QCAP * 8 + 256 * 4 * 3 + 64 + 8 * 64 * 8;
+
+__device__ __forceinline__ uint64_t s256_entry(int row, float score, uint32_t relidx) {
+    return ((uint64_t)row << 56) | ((uint64_t)f32_orderable(score) << 24) | (uint64_t)((~relidx) & 0xffffffu);
+}
+__device__ __forceinline__ uint64_t s256_entry_to_key(uint64_t e, uint32_t idx_base) {
+    const uint32_t rel = (~(uint32_t)e) & 0xffffffu;
+    const uint32_t ord = (uint32_t)(e >> 24);
+    return ((uint64_t)ord << 32) | (uint64_t)(~(idx_base + rel));
+}
+
+__device__ __forceinline__ uint64_t s256_shfl_xor(uint64_t v, int m) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, m, 64), hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t s256_shfl_up1(uint64_t v) {
+    const uint32_t lo = __shfl_up((uint32_t)v, 1, 64), hi = __shfl_up((uint32_t)(v >> 32), 1, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+struct S256Lds {
+    uint64_t* queue;     // [S256_QCAP]
+    float* tau;          // [256] admission score per query row of the tile
+    int* start;          // [256]
+    int* end;            // [256]
+    int* ctrl;           // [0] queue count (may exceed the capacity: overflow), [1..] spare
+    uint64_t* scratch;   // [8][64] wave-private
+};
+
+// All 512 threads.  Sort the queue (row, score, index descending), merge every row's best
+// entries into its global list, refresh the admission scores, empty the queue.
+__device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* part, long part_row_stride, int q0, int qvalid,
+                                        uint32_t idx_base, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    __syncthreads();
+    int n = L.ctrl[0];
+    n = n < S256_QCAP ? n : S256_QCAP;
+    int np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    for (int i = n + tid; i < np2; i += 512) L.queue[i] = 0ull;
+    if (tid < 256) { L.start[tid] = 0; L.end[tid] = 0; }
+    __syncthreads();
+    // bitonic sort, descending, np2 entries: comparator c touches (lo, lo | j)
+    for (int k2 = 2; k2 <= np2; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int c = tid; c < (np2 >> 1); c += 512) {
+                const int lo = ((c & ~(j - 1)) << 1) | (c & (j - 1));
+                const int hi = lo | j;
+                const uint64_t a = L.queue[lo], b = L.queue[hi];
+                const bool desc = (lo & k2) == 0;
+                if (desc ? (a < b) : (a > b)) { L.queue[lo] = b; L.queue[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // row boundaries (entries of one row are contiguous, best first)
+    for (int i = tid; i < n; i += 512) {
+        const int r = (int)(L.queue[i] >> 56);
+        if (i == 0 || (int)(L.queue[i - 1] >> 56) != r) L.start[r] = i;
+        if (i == n - 1 || (int)(L.queue[i + 1] >> 56) != r) L.end[r] = i + 1;
+    }
+    __syncthreads();
+    uint64_t* ws = L.scratch + wave * 64;
+    for (int r = wave; r < qvalid; r += 8) {
+        const int s0 = L.start[r];
+        int c = L.end[r] - s0;
+        if (c <= 0) continue;
+        c = c < S256_KSEL ? c : S256_KSEL;
+        uint64_t* list = part + (long)(q0 + r) * part_row_stride;
+        uint64_t v;
+        if (lane < 32) {
+            v = list[lane];
+        } else {
+            const int jx = 63 - lane;                       // lane 63 takes the row's best queued entry
+            v = jx < c ? s256_entry_to_key(L.queue[s0 + jx], idx_base) : 0ull;
+        }
+        // lanes 0..31 best-first, lanes 32..63 worst-first: bitonic -> sorted best-first
+#pragma unroll
+        for (int j = 32; j > 0; j >>= 1) {
+            const uint64_t o = s256_shfl_xor(v, j);
+            v = ((lane & j) == 0) ? (v > o ? v : o) : (v < o ? v : o);
+        }
+        // drop duplicates (a tile is re-scanned after a queue overflow) and compact
+        const uint64_t prev = s256_shfl_up1(v);
+        const bool keep = v != 0ull && (lane == 0 || v != prev);
+        const unsigned long long km = __ballot(keep);
+        const int pos = __popcll(km & ((1ull << lane) - 1ull));
+        ws[lane] = 0ull;
+        if (keep) ws[pos] = v;            // LDS operations of one wave complete in order
+        const uint64_t outv = ws[lane];
+        if (lane < S256_KSEL) list[lane] = outv;
+        const uint64_t last = __builtin_amdgcn_readlane((uint32_t)(outv >> 32), S256_KSEL - 1);
+        if (lane == 0 && last != 0u) {
+            const float t = orderable_f32((uint32_t)last);
+            if (t > L.tau[r]) L.tau[r] = t;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) L.ctrl[0] = 0;
+    __syncthreads();
+}
+
+struct Scan256Args {
+    const bf16_t* Qb; long ldq;
+    const bf16_t* Gb; long ldg;
+    int Q; long N; int D;
+    long n_begin;                 // rows [0, n_begin) are covered by the pre-pass
+    int splits;
+    uint64_t* part;               // [Q][lists_per_query][KSEL]; this kernel owns slots [0, splits)
+    int lists_per_query;
+    const float* tau0;            // [Q] seed admission scores (-inf when the pre-pass found < KSEL rows)
+};
+
+__global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    S256Lds L;
+    L.queue = (uint64_t*)(smem + G256_LDS);
+    L.tau = (float*)(smem + G256_LDS + S256_QCAP * 8);
+    L.start = (int*)(L.tau + 256);
+    L.end = L.start + 256;
+    L.ctrl = L.end + 256;
+    L.scratch = (uint64_t*)(L.ctrl + 16);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane = tid & 63;
+    const int q0 = blockIdx.x * 256;
+    const int sp = blockIdx.y;
+    const int qvalid = (p.Q - q0) < 256 ? (p.Q - q0) : 256;
+
+    const long span = p.N - p.n_begin;
+    const long tiles = (span + 255) / 256;
+    const long per = (tiles + p.splits - 1) / p.splits;
+    const long t0 = sp * per;
+    const long t1 = (t0 + per) < tiles ? (t0 + per) : tiles;
+    const long row_begin = p.n_begin + t0 * 256;            // first gallery row of this slice
+    const uint32_t idx_base = (uint32_t)row_begin;
+    uint64_t* mypart = p.part + (long)sp * S256_KSEL;
+    const long part_row_stride = (long)p.lists_per_query * S256_KSEL;
+
+    if (tid < 256) L.tau[tid] = tid < qvalid ? p.tau0[q0 + tid] : INFINITY;
+    if (tid == 0) L.ctrl[0] = 0;
+    __syncthreads();
+    if (t0 >= t1) return;
+
+    G256Operand A, B;
+    g256_operand_init(A, p.Qb, p.ldq, p.Q, q0, wave, lane);
+    g256_operand_init(B, p.Gb + row_begin * p.ldg, p.ldg, p.N - row_begin, 0, wave, lane);
+    g256_issue_prologue(A, B, smem, p.D, wave);
+
+    long t = t0;
+    while (t < t1) {
+        const long n0 = p.n_begin + t * 256;
+        {
+            f32x4 acc[8][4];
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            gemm256_mainloop(A, B, smem, p.D, wave, lane, acc);
+
+            if (t + 1 < t1) {
+                // next gallery tile: rebased descriptors (any gallery size), DMA in flight during the selection
+                g256_operand_init(B, p.Gb + (n0 + 256) * p.ldg, p.ldg, p.N - (n0 + 256), 0, wave, lane);
+                g256_issue_prologue(A, B, smem, p.D, wave);
+            }
+            asm volatile("" : "+v"(lane) :: "memory");
+            // (a runtime branch right behind the main loop: without one hipcc 7.2 allocates the
+            //  loop so that the accumulators spill -- same workaround as in gemm256_kernel)
+            if (p.lists_per_query <= 0) continue;
+            const int lr = lane & 15, lq = lane >> 4;
+            const int rbase = (wave >> 2) * 128 + lr;            // + m * 16
+            const int cbase = (wave & 3) * 64 + lq * 4;          // + n * 16 + j
+            const long left = p.N - n0;
+            const uint32_t rel0 = (uint32_t)(n0 - row_begin);
+            bool any = false;
+            float taum[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                taum[m] = L.tau[rbase + m * 16];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (left < 256 && cbase + n * 16 + j >= left) acc[m][n][j] = -INFINITY;
+                        mx = fmaxf(mx, acc[m][n][j]);
+                    }
+                any |= mx >= taum[m];
+            }
+            if (__ballot(any) != 0ull) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = acc[m][n][j];
+                            const bool hit = v >= taum[m] && v > -INFINITY;
+                            const unsigned long long hm = __ballot(hit);
+                            if (hm) {
+                                int base = 0;
+                                if (lane == 0) base = atomicAdd(&L.ctrl[0], __popcll(hm));
+                                base = __builtin_amdgcn_readfirstlane(base);
+                                const int pos = base + __popcll(hm & ((1ull << lane) - 1ull));
+                                if (hit && pos < S256_QCAP)
+                                    L.queue[pos] = s256_entry(rbase + m * 16, v, rel0 + cbase + n * 16 + j);
+                            }
+                        }
+                }
+            }
+        }
+        // the accumulators are dead from here on (the drain is a real call)
+        __syncthreads();
+        const int qc = L.ctrl[0];
+        if (qc > S256_QCAP) {
+            // overflow: entries past the capacity were dropped.  Merge what was queued (the admission
+            // scores rise), then compute this tile again; re-queued duplicates vanish in the list merge.
+            s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's DMA must not land on top
+            __syncthreads();
+            g256_operand_init(B, p.Gb + n0 * p.ldg, p.ldg, p.N - n0, 0, wave, lane);
+            g256_issue_prologue(A, B, smem, p.D, wave);
+            continue;
+        }
+        if (qc >= S256_DRAIN || t + 1 >= t1) s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid);
+        ++t;
+    }
+}
+
+int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
+                        int splits, uint64_t* part, int lists_per_query, const float* tau0, hipStream_t st) {
+    REVO_REQUIRE(D % 64 == 0 && ldq % 8 == 0 && ldg % 8 == 0, "search: D must be a multiple of 64");
+    REVO_REQUIRE(N < (1ll << 32), "search: a shard holds at most 2^32 rows");
+    REVO_REQUIRE(256l * ldg * 2 < (1l << 31) && 256l * ldq * 2 < (1l << 31), "search: row too long for the DMA window");
+    const long tiles = (N - n_begin + 255) / 256;
+    const long per = (tiles + splits - 1) / splits;
+    REVO_REQUIRE(per * 256 <= (1l << 24), "search: a gallery slice holds at most 2^24 rows; use more splits");
+    if (Q <= 0 || N <= n_begin) return 0;
+    static bool done = false;
+    if (!done) {
+        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)topk_scan256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           S256_LDS));
+        done = true;
+    }
+    Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, part, lists_per_query, tau0};
+    hipLaunchKernelGGL(topk_scan256_kernel, dim3((Q + 255) / 256, splits), dim3(G256_THREADS), S256_LDS, st, a);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// tau0[q] = score of the KSEL-th entry of the pre-pass list (or -inf), and the list itself is
+// copied into slot `slot` of the query's lists.
+__global__ void topk_seed_kernel(const uint64_t* __restrict__ pre, long pre_stride, uint64_t* __restrict__ part,
+                                 long part_row_stride, int slot, int Q, float* __restrict__ tau0) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    if (lane < S256_KSEL) {
+        const uint64_t v = pre[(long)q * pre_stride + lane];
+        part[(long)q * part_row_stride + (long)slot * S256_KSEL + lane] = v;
+        if (lane == S256_KSEL - 1) tau0[q] = v ? key_score(v) : -INFINITY;
+    }
+}
+int launch_topk_seed(const uint64_t* pre, long pre_stride, uint64_t* part, long part_row_stride, int slot, int Q,
+                     float* tau0, hipStream_t st) {
+    if (Q <= 0) return 0;
+    hipLaunchKernelGGL(topk_seed_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, pre, pre_stride, part, part_row_stride,
+                       slot, Q, tau0);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// (query tiles x splits) should fill 256 CUs in whole rounds; slices of >= 32 tiles amortise the drains
+int topk_scan256_splits(int Q, long rows) {
+    const int qtiles = (Q + 255) / 256;
+    const long tiles = (rows + 255) / 256;
+    if (tiles <= 0) return 1;
+    int best = 1;
+    double best_score = -1.0;
+    for (int s = 1; s <= 512; ++s) {
+        if (s > tiles) break;
+        const long per = (tiles + s - 1) / s;
+        if (s > 1 && per < 8) break;
+        const long wgs = (long)qtiles * s;
+        const long rounds = (wgs + 255) / 256;
+        const double eff = (double)wgs / (double)(rounds * 256);
+        // prefer full rounds; among equals prefer fewer, longer slices (fewer lists, fewer drains)
+        const double score = eff - 1e-4 * s;
+        if (score > best_score) { best_score = score; best = s; }
+    }
+    return best;
+}
+
+}  // namespace revo

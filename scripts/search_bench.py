@@ -1,0 +1,35 @@
+"""Search micro-benchmark (K12/K13): time of Gallery.search and of its kernels, with the
+MFMA / HBM roofline figures of SURVEY.md §8(d).   python scripts/search_bench.py [N] [Q ...]"""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, reverso_amd
+from reverso_amd import engine
+dev = torch.device("cuda", 0)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+Qs = [int(a) for a in sys.argv[2:]] or [1, 64, 256, 10000]
+D, k = 1024, 10
+G = engine.Gallery(D, N, device=0)
+g = torch.Generator(device=dev).manual_seed(42)
+for s in range(0, N, 131072):
+    G.add(torch.randn(min(131072, N - s), D, generator=g, device=dev))
+for Q in Qs:
+    q = torch.randn(Q, D, generator=g, device=dev)
+    for _ in range(2): G.search(q, k)
+    torch.cuda.synchronize()
+    iters = 10 if Q <= 256 else 3
+    engine.prof_reset(); engine.prof_enable(True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): G.search(q, k)
+    e1.record(); torch.cuda.synchronize()
+    engine.prof_enable(False)
+    prof = engine.prof_report()
+    ms = e0.elapsed_time(e1) / iters
+    scan = prof["topk_scan"]["ms"] / prof["topk_scan"]["launches"]
+    flops = 2.0 * Q * N * D
+    byts = N * D * 2 + Q * D * 2 + Q * k * 12
+    print(json.dumps({"Q": Q, "N": N, "search_ms": round(ms, 4), "scan_ms": round(scan, 4),
+                      "scan_TFLOPs": round(flops / scan / 1e9, 1), "scan_frac_mfma": round(flops / scan / 1e9 / 2500, 4),
+                      "scan_GBs": round(byts / scan / 1e6, 1), "scan_frac_hbm": round(byts / scan / 1e6 / 8000, 4),
+                      "queries_per_s": round(Q / ms * 1e3, 1),
+                      "other_ms": {k2: round(v["ms"] / v["launches"], 4) for k2, v in prof.items() if k2 != "topk_scan"}}), flush=True)

@@ -86,6 +86,38 @@ def test_ragged_sizes_vs_oracle(dev, N, D, Q, k):
     G.close()
 
 
+def test_adversarial_order_forces_queue_overflow(dev):
+    """Scores rise with the row index, so nearly every row of every tile beats the running
+    admission score: the selection queue overflows and tiles are re-scanned; results stay exact."""
+    N, D, Q, k = 40000, 64, 300, 10
+    rng = np.random.default_rng(5)
+    qr = rng.standard_normal((Q, D), dtype=np.float32)
+    base = qr.mean(0)
+    ramp = np.linspace(0.0, 4.0, N, dtype=np.float32)[:, None]
+    gal = base[None] * ramp + rng.standard_normal((N, D), dtype=np.float32)
+    G = engine.Gallery(D, N, device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    _check(G.search(torch.from_numpy(qr).to(dev), k), osearch.search(gal, qr, k), atol=1e-5)
+    G.close()
+
+
+@pytest.mark.parametrize("N,Q", [(16384, 1), (16385, 257), (70001, 64), (250000, 513)])
+def test_large_scan_path_vs_oracle(dev, N, Q):
+    D, k = 128, 10
+    rng = np.random.default_rng(N + Q)
+    gal = rng.standard_normal((N, D), dtype=np.float32)
+    gal[N // 3: N // 3 + 40] = gal[N // 3]                 # a tie group longer than the candidate list
+    qr = rng.standard_normal((Q, D), dtype=np.float32)
+    qr[0] = gal[N // 3]
+    G = engine.Gallery(D, N, device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    out = G.search(torch.from_numpy(qr).to(dev), k, None)
+    _check(out, osearch.search(gal, qr, k), atol=1e-5)
+    assert out[1][0].cpu().tolist() == list(range(N // 3, N // 3 + 10))
+    _check(G.search(torch.from_numpy(qr).to(dev), k, 0.3), osearch.search(gal, qr, k, 0.3), atol=1e-5)
+    G.close()
+
+
 def test_empty_gallery_and_append_in_pieces(dev):
     G = engine.Gallery(64, 100, device=0)
     q = torch.randn(3, 64, device=dev)
