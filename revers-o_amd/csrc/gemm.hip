@@ -206,10 +206,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm128_kernel(GemmArgs p) {
 template <int EPI, int DBG>
 __global__ __launch_bounds__(G256_THREADS, 2) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // 2-D XCD map: blocks b, b+8, ... share an XCD (and its 4 MiB L2).  XCD (xi, xj) of a
+    // gx x gy arrangement owns the M-tile stripe xi and the N-tile stripe xj, so a weight
+    // stripe stays L2 resident while the XCD sweeps its activation rows (p.gy is chosen by
+    // the launcher so that the stripe fits); inside the region N runs fastest.
     const int tiles_n = (p.N + 255) / 256;
     const int tiles_m = (p.M + 255) / 256;
-    const int s = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = s / tiles_n, tn = s - tm * tiles_n;
+    const int gy = p.gy, gx = 8 / gy;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xi = xcd / gy, xj = xcd - xi * gy;
+    const int pm = (tiles_m + gx - 1) / gx, pn = (tiles_n + gy - 1) / gy;
+    const int m_lo = xi * pm, n_lo = xj * pn;
+    const int m_cnt = (tiles_m - m_lo) < pm ? (tiles_m - m_lo) : pm;
+    const int n_cnt = (tiles_n - n_lo) < pn ? (tiles_n - n_lo) : pn;
+    if (m_cnt <= 0 || n_cnt <= 0 || slot >= m_cnt * n_cnt) return;
+    const int tm = m_lo + slot / n_cnt, tn = n_lo + slot % n_cnt;
     const int m0 = tm * 256, n0 = tn * 256;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -253,6 +264,8 @@ static const char* check_args(const GemmArgs& a) {
     return nullptr;
 }
 
+static int g_force_gy = 0;     // timing experiments only: force the XCD arrangement (1, 2, 4, 8)
+void gemm_force_gy(int gy) { g_force_gy = gy; }
 template <int EPI, int DBG>
 static int launch_256d(const GemmArgs& a, hipStream_t st) {
     static bool attr_done = false;
@@ -261,8 +274,17 @@ static int launch_256d(const GemmArgs& a, hipStream_t st) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
         attr_done = true;
     }
-    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-    hipLaunchKernelGGL((gemm256_kernel<EPI, DBG>), dim3(tiles), dim3(G256_THREADS), G256_LDS, st, a);
+    // XCD arrangement (measured on MI355X, scripts/gemm_gy.py): with few N tiles every XCD sweeps
+    // all of N for its M stripe (gy = 1); from 12 N tiles on, four N stripes keep a weight stripe
+    // L2 resident and cut the fabric traffic (qkv 933 -> 1122, fc1 859 -> 920, 8192^3 1322 -> 1453 TF)
+    GemmArgs b = a;
+    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
+    int gy = tiles_n >= 12 ? 4 : (tiles_n >= 8 ? 2 : 1);
+    if (g_force_gy) gy = g_force_gy;
+    b.gy = gy;
+    const int gx = 8 / gy;
+    const int region = ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, DBG>), dim3(8 * region), dim3(G256_THREADS), G256_LDS, st, b);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

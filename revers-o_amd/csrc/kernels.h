@@ -22,9 +22,11 @@ struct GemmArgs {
     const float* gamma;          // [N] LayerScale or null   (EPI_RESID_F32)
     const float* pos;            // [S][N]                    (EPI_PATCH)
     int S, G2, cls;              //                           (EPI_PATCH)
+    int gy;                      // XCD arrangement of the 256 x 256 kernel (set by the launcher)
 };
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
 void gemm_set_debug(int d);
+void gemm_force_gy(int gy);
 void gemm_force_tile(int t);   // 0 = heuristic, 128 or 256 = forced
 
 // --------------------------------------------------------- elementwise -----
