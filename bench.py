@@ -152,8 +152,20 @@ def main():
     flops_per_launch = layer_gemm_flops(cfg, B) / (4 * cfg.layers)
     avg_ms = gemm_ms / max(gemm_launches, 1)
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    # HBM-side bytes per launch of that kernel class from the committed rocprofv3 PMC passes
+    # (separate --pmc runs of this same command; FETCH_SIZE doubled per the gfx950 correction):
+    # profiles/roofline_traffic.json, produced by scripts/pmc_summary.py.  null when the
+    # workload differs from the profiled one.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
+            tj = json.load(f)
+        if tj.get("variant") == cfg.name and tj.get("batch") == B:
+            traffic = tj.get("gemm_bytes_per_launch")
+    except Exception:
+        traffic = None
     roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "gemm128_kernel",
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "kernel": "gemm256_kernel",
                 "avg_launch_ms": avg_ms, "launches": gemm_launches,
                 "algorithmic_flops_per_launch": flops_per_launch}
     # the search scan is HBM bound at this query count: report it next to the GEMM
