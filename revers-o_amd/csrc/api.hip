@@ -397,8 +397,19 @@ extern "C" int32_t revo_vit_forward(revo_vit* v, const void* images, int32_t ima
         const LayerW& L = v->layers[i];
         { ProfScope ps("layernorm", st);
           CHECK_RC(launch_layernorm(v->x, W, L.ln1w, L.ln1b, c.ln_eps, rows, W, v->h, W, 1, st)); }
-        CHECK_RC(gemm("gemm_qkv", EPI_BF16, v->h, W, L.w_qkv, W, rows, 3 * W, W, v->qkv, 3 * W, L.b_qkv, nullptr, st));
-        { ProfScope ps("rope", st); CHECK_RC(launch_rope(v->qkv, 3 * W, v->rope_cs, rows, S, W, c.heads, st)); }
+        if (gemm_uses_wide_epilogue(rows, 3 * W, W, W, 3 * W)) {
+            // K4 + K5: bias and the 2-D rotary embedding of q and k in the GEMM epilogue
+            GemmArgs a{};
+            a.A = v->h; a.lda = W; a.B = L.w_qkv; a.ldb = W; a.M = rows; a.N = 3 * W; a.K = W; a.C = v->qkv;
+            a.ldc = 3 * W; a.bias = L.b_qkv; a.rope_cs = v->rope_cs; a.rope_S = S; a.rope_hd = v->hd;
+            a.rope_cols = 2 * W;
+            ProfScope ps("gemm_qkv", st);
+            CHECK_RC(launch_gemm(EPI_BF16_ROPE, a, st));
+        } else {
+            CHECK_RC(gemm("gemm_qkv", EPI_BF16, v->h, W, L.w_qkv, W, rows, 3 * W, W, v->qkv, 3 * W, L.b_qkv, nullptr, st));
+            ProfScope ps("rope", st);
+            CHECK_RC(launch_rope(v->qkv, 3 * W, v->rope_cs, rows, S, W, c.heads, st));
+        }
         { ProfScope ps("attention", st);
           CHECK_RC(launch_attention_ex(v->qkv, 3 * W, v->att, W, B, S, c.heads, v->hd, c.use_cls, st)); }
         CHECK_RC(gemm("gemm_out", EPI_RESID_F32, v->att, W, L.w_o, W, rows, W, W, v->x, W, L.b_o, L.ls1, st));

@@ -120,7 +120,8 @@ __device__ __forceinline__ void gemm256_epilogue_f32_quarter(const GemmArgs& p, 
 template <int EPI>
 __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* smem, int m_base, int n_base, int wave,
                                                  int lane, f32x4 (&acc)[8][4]) {
-    static_assert(EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_F32 || EPI == EPI_RESID_F32, "");
+    static_assert(EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_F32 || EPI == EPI_RESID_F32 ||
+                  EPI == EPI_BF16_ROPE, "");
     // The main loop runs at the 256-VGPR limit: keep every epilogue value from being
     // computed (or loaded) ahead of it by making the lane id opaque here.
     asm volatile("" : "+v"(lane) :: "memory");
@@ -134,7 +135,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* smem, 
         if (EPI == EPI_RESID_F32)
             gamma4[n] = (p.gamma && col < p.N) ? *(const f32x4*)(p.gamma + col) : (f32x4){1.f, 1.f, 1.f, 1.f};
     }
-    if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+    if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE) {
         constexpr int RS = 144;   // 64 bf16 + 16 bytes of padding per slab row
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -155,11 +156,33 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* smem, 
                     *(uint2*)(slab + (m * 16 + lr) * RS + (n * 16 + lq * 4) * 2) = o;
                 }
             const int gcol = n_base + (lane & 7) * 8;
+            // RoPE (K5) on the coalesced rows: a lane holds 4 interleaved pairs of one token
+            int tok = 0;
+            const float2* cs = nullptr;
+            if (EPI == EPI_BF16_ROPE) {
+                tok = (m_base + half * 64 + (lane >> 3)) % p.rope_S;      // one division per 64 rows; then +8 per step
+                cs = p.rope_cs + ((gcol % p.rope_hd) >> 1);
+            }
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int rl = it * 8 + (lane >> 3);
-                const uint4 v = *(const uint4*)(slab + rl * RS + (lane & 7) * 16);
+                uint4 v = *(const uint4*)(slab + rl * RS + (lane & 7) * 16);
                 const int grow = m_base + half * 64 + rl;
+                if (EPI == EPI_BF16_ROPE) {
+                    if (gcol < p.rope_cols) {
+                        const float2* t = cs + (long)tok * (p.rope_hd >> 1);
+                        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float x0 = bf16_to_f32((bf16_t)(w[j] & 0xffff)), x1 = bf16_to_f32((bf16_t)(w[j] >> 16));
+                            const float2 c = t[j];
+                            w[j] = pack_bf16x2(x0 * c.x - x1 * c.y, x1 * c.x + x0 * c.y);
+                        }
+                        v = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                    tok += 8;
+                    if (tok >= p.rope_S) tok -= p.rope_S;
+                }
                 if (grow < p.M && gcol < p.N) *(uint4*)((bf16_t*)p.C + (long)grow * p.ldc + gcol) = v;
             }
             asm volatile("" ::: "memory");
@@ -250,7 +273,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256_kernel(GemmArgs p) {
         //  allocates the fp32 variants' main loop so badly that the accumulators spill)
         const bool wide = (p.N & 7) == 0 && (p.ldc & 7) == 0;
         if (wide) gemm256_epilogue<EPI>(p, smem, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, wave, lane, acc);
-        else gemm_epilogue<EPI, 8, 4>(p, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, lane, acc);
+        else gemm_epilogue<EPI == EPI_BF16_ROPE ? EPI_BF16 : EPI, 8, 4>(p, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64,
+                                                                         lane, acc);
     }
 }
 
@@ -312,6 +336,12 @@ static bool use_256(const GemmArgs& a) {
     return a.M >= 1024 && a.N >= 256;
 }
 
+bool gemm_uses_wide_epilogue(int M, int N, long lda, long ldb, long ldc) {
+    GemmArgs a{};
+    a.M = M; a.N = N; a.lda = lda; a.ldb = ldb;
+    return use_256(a) && (N & 7) == 0 && (ldc & 7) == 0;
+}
+
 template <int EPI>
 static int launch_t(const GemmArgs& a, hipStream_t st) {
     if (use_256(a)) return launch_256<EPI>(a, st);
@@ -339,6 +369,12 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
         case EPI_RESID_F32: return launch_t<EPI_RESID_F32>(a, st);
         case EPI_F32: return launch_t<EPI_F32>(a, st);
         case EPI_PATCH: return launch_t<EPI_PATCH>(a, st);
+        case EPI_BF16_ROPE:
+            if (!gemm_uses_wide_epilogue(a.M, a.N, a.lda, a.ldb, a.ldc)) {
+                revo_set_error("gemm: the fused RoPE epilogue needs the 256 x 256 kernel (caller must check)");
+                return -2;
+            }
+            return launch_256<EPI_BF16_ROPE>(a, st);
     }
     revo_set_error("gemm: unknown epilogue");
     return -2;

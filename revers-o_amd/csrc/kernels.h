@@ -11,6 +11,7 @@ enum GemmEpi {
     EPI_RESID_F32 = 2,  // C f32 += gamma * (acc + bias)        (residual stream, in place)
     EPI_F32 = 3,        // C f32 = acc + bias
     EPI_PATCH = 4,      // C f32[(m/G2)*S + cls + m%G2] = acc + pos[cls + m%G2]
+    EPI_BF16_ROPE = 5,  // EPI_BF16 + axial 2-D RoPE on columns [0, rope_cols) (q and k thirds of qkv); 256 kernel only
 };
 
 struct GemmArgs {
@@ -23,7 +24,11 @@ struct GemmArgs {
     const float* pos;            // [S][N]                    (EPI_PATCH)
     int S, G2, cls;              //                           (EPI_PATCH)
     int gy;                      // XCD arrangement of the 256 x 256 kernel (set by the launcher)
+    const float2* rope_cs;       // [rope_S][rope_hd/2] (cos, sin)      (EPI_BF16_ROPE)
+    int rope_S, rope_hd, rope_cols;
 };
+// true when launch_gemm would run the 256 x 256 kernel with the row-coalesced epilogue for these sizes
+bool gemm_uses_wide_epilogue(int M, int N, long lda, long ldb, long ldc);
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
 void gemm_set_debug(int d);
 void gemm_force_gy(int gy);

@@ -83,19 +83,23 @@ def test_b16_single_block_golden(dev):
 
 
 def test_b16_full_depth_vs_oracle(dev):
-    """BASELINE.json configs[0] model (PE-Core-B16-224), 3 images, all 12 blocks."""
+    """BASELINE.json configs[0] model (PE-Core-B16-224), 6 images (1182 rows: the 256 x 256 GEMM with the
+    fused RoPE epilogue), all 12 blocks."""
     cfg = reverso_amd.get_config("PE-Core-B16-224")
     sd = weights.synth_weights(cfg, seed=0, randomize_affine=True)
     g = torch.Generator().manual_seed(1234)
-    u8 = torch.randint(0, 256, (3, 3, 224, 224), generator=g, dtype=torch.uint8)
+    u8 = torch.randint(0, 256, (6, 3, 224, 224), generator=g, dtype=torch.uint8)
     ref = pe_vit.embed(sd, cfg, pe_vit.preprocess_u8(u8))
-    eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=4)
+    eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=8)
     emb = eng.embed(u8.to(dev)).cpu()
     cos = (emb * ref).sum(-1)
     assert (cos >= 0.999).all(), cos
     # cosine scores of the embeddings against a fixed random gallery agree to 1e-3
     gal = torch.nn.functional.normalize(torch.randn(2000, cfg.out_dim, generator=g), dim=-1)
     assert ((emb @ gal.T) - (ref @ gal.T)).abs().max().item() <= 1e-3
+    # the same images one at a time take the 128 x 128 GEMM and the separate RoPE kernel: same answer
+    one = torch.cat([eng.embed(u8[i:i + 1].to(dev)).cpu() for i in range(6)])
+    assert ((one * emb).sum(-1) >= 0.99995).all()
     eng.close()
 
 
