@@ -643,6 +643,7 @@ extern "C" int32_t revo_op_gemm(int32_t epi, const void* a, int64_t lda, const v
 extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
     revo::gemm_set_debug(flags & 3);
     revo::gemm_force_gy((flags >> 4) & 15);
+    revo::attention_force_nw((flags >> 8) & 15);
     return 0;
 }
 extern "C" int32_t revo_op_set_gemm_tile(int32_t tile) {

@@ -325,6 +325,8 @@ static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, in
     hipLaunchKernelGGL((attn_fwd_kernel<64, NW>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_lo, k_lo);
 }
 
+static int g_attn_force_nw = 0;   // timing experiments only
+void attention_force_nw(int nw) { g_attn_force_nw = nw; }
 // has_cls: row 0 of every sequence is the class token (true for every PE-Core variant with use_cls)
 int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, int hd, int has_cls,
                         hipStream_t st) {
@@ -338,13 +340,16 @@ int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B
     auto cost = [](int n) { return ((n + 31) / 32) * ((n + 63) / 64); };   // wave-tiles x key tiles
     const int lo = (has_cls && S > 1 && cost(S - 1) < cost(S)) ? 1 : 0;
     const int rows = S - lo;
-    // waves per workgroup: the candidate with the fewest padded query rows (ties: more waves share a K/V tile)
-    int best = 4, best_pad = 1 << 30;
+    // Waves per workgroup.  A workgroup's time per key tile is set by the staging / barrier /
+    // softmax latency chain, not by how many of its waves hold query rows (measured, L14: 8 waves
+    // 0.216 ms, 6 waves 0.244 ms, 4 waves 0.248 ms although 8 waves pad 576 rows to 768), so take
+    // the fewest workgroups per (image, head) and, among equals, the most waves (16 waves per CU).
+    int best = 4, best_blocks = 1 << 30;
     for (int nw : {8, 7, 6, 4}) {
-        const int per = nw * 32;
-        const int pad = (rows + per - 1) / per * per - rows;
-        if (pad < best_pad) { best_pad = pad; best = nw; }
+        const int blocks = (rows + nw * 32 - 1) / (nw * 32);
+        if (blocks < best_blocks) { best_blocks = blocks; best = nw; }
     }
+    if (g_attn_force_nw) best = g_attn_force_nw;
     switch (best) {
         case 8: launch_attn_nw<8>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;
         case 7: launch_attn_nw<7>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;

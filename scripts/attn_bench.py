@@ -12,6 +12,7 @@ qkv = torch.randn(B * S, 3 * W, device=dev).bfloat16()
 out = torch.zeros(B * S, W, device=dev, dtype=torch.bfloat16)
 st = _lib.current_stream()
 def go(): _lib.check(lib.revo_op_attention(_lib.ptr(qkv), 3 * W, _lib.ptr(out), W, B, S, H, hd, st))
+nw = int(os.environ.get("ATTN_NW", "0")); lib.revo_op_set_gemm_debug(nw << 8)
 for _ in range(3): go()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
