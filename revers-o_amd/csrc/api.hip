@@ -449,7 +449,7 @@ struct revo_gallery {
     bf16_t* gb = nullptr;      // [capacity][D] normalised rows, scan copy
     float* gf = nullptr;       // [capacity][D] normalised rows, fp32 master (re-score + persistence)
     // per-call workspace, grown on demand
-    float* qf = nullptr; bf16_t* qb = nullptr; float* tau0 = nullptr; int q_cap = 0;
+    float* qf = nullptr; bf16_t* qb = nullptr; uint32_t* tau0 = nullptr; int q_cap = 0;
     uint64_t* part = nullptr; size_t part_cap = 0;
     float* stage = nullptr; size_t stage_cap = 0;
     ~revo_gallery() {

@@ -16,7 +16,8 @@
 //   ahead of its use, and the DMA queue never drains inside the loop (counted
 //   vmcnt(4) once per K-tile leaves two half-tiles in flight across the barrier).
 //
-// LDS image per stage: A[256 rows][128 B] | B[256 rows][128 B]; 16-byte chunks are
+// LDS image: A stage 0 | A stage 1 | B stage 0 | B stage 1, each [256 rows][128 B] (the two stages of
+// an operand are 32 KiB apart, inside the 16-bit immediate of ds_read); 16-byte chunks are
 // XOR-swizzled with ((row>>1)&7) on the DMA *source* address and on the fragment
 // read (the DMA destination is lane-linear).  Rows past the matrix edge are
 // fetched through a bounds-checked buffer descriptor and read as zeros.
@@ -26,8 +27,9 @@
 namespace revo {
 
 constexpr int G256_THREADS = 512;
-constexpr int G256_STAGE = 65536;       // bytes per stage: A 32 KiB + B 32 KiB
-constexpr int G256_LDS = 2 * G256_STAGE;
+constexpr int G256_LDS = 131072;        // A stage 0 | A stage 1 | B stage 0 | B stage 1, 32 KiB each
+#define G256_A(smem, s) ((smem) + (s) * 32768)
+#define G256_B(smem, s) ((smem) + 65536 + (s) * 32768)
 
 struct G256Operand {
     __amdgpu_buffer_rsrc_t rsrc[4];   // one bounds-checked window per 64-row block of the tile (SGPRs)
@@ -68,39 +70,39 @@ struct G256Frags {
 
 // Per-lane LDS byte offsets of the fragment reads: [stage][k sub-step], for the wave's first
 // A row / first B row.  Everything else is an immediate (m * 2048, +64 rows = 8192, ...), so
-// the whole main loop addresses LDS through these eight registers (made opaque so that the
+// the whole main loop addresses LDS through these four registers (made opaque so that the
 // compiler does not re-derive a register per immediate and spill at the 256-VGPR limit).
 struct G256Addr {
-    uint32_t a[2][2], b[2][2];
+    uint32_t a[2], b[2];    // [k sub-step], stage 0; stage 1 is +32768 (an immediate)
 };
 __device__ __forceinline__ void g256_addr_init(G256Addr& ad, int wave, int lane) {
     const int sw = (lane >> 1) & 7, lr = lane & 15, lq = lane >> 4;
     const int wr = wave >> 2, wc = wave & 3;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const uint32_t x = (uint32_t)(((kk * 4 + lq) ^ sw) << 4);
-            ad.a[s][kk] = (uint32_t)(s * G256_STAGE + (wr * 128 + lr) * 128) + x;
-            ad.b[s][kk] = (uint32_t)(s * G256_STAGE + 32768 + (wc * 64 + lr) * 128) + x;
-            asm volatile("" : "+v"(ad.a[s][kk]), "+v"(ad.b[s][kk]));
-        }
+    for (int kk = 0; kk < 2; ++kk) {
+        const uint32_t x = (uint32_t)(((kk * 4 + lq) ^ sw) << 4);
+        ad.a[kk] = (uint32_t)((wr * 128 + lr) * 128) + x;
+        ad.b[kk] = (uint32_t)(65536 + (wc * 64 + lr) * 128) + x;
+        asm volatile("" : "+v"(ad.a[kk]), "+v"(ad.b[kk]));
+    }
 }
 typedef __attribute__((address_space(3))) const bf16x8* lds_frag_ptr;
 // ROWS: 0 = A-lo / B-lo, 64 = A-hi (rows +64), 32 = B-hi (rows +32)
-template <int ROWS>
+template <int ROWS, int STAGE>
 __device__ __forceinline__ void g256_read_a(bf16x8 (&dst)[4][2], const uint32_t (&base)[2]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) dst[m][kk] = *(lds_frag_ptr)(uintptr_t)(base[kk] + (ROWS + m * 16) * 128);
+        for (int kk = 0; kk < 2; ++kk)
+            dst[m][kk] = *(lds_frag_ptr)(uintptr_t)(base[kk] + STAGE * 32768 + (ROWS + m * 16) * 128);
 }
-template <int ROWS>
+template <int ROWS, int STAGE>
 __device__ __forceinline__ void g256_read_b(bf16x8 (&dst)[2][2], const uint32_t (&base)[2]) {
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) dst[n][kk] = *(lds_frag_ptr)(uintptr_t)(base[kk] + (ROWS + n * 16) * 128);
+        for (int kk = 0; kk < 2; ++kk)
+            dst[n][kk] = *(lds_frag_ptr)(uintptr_t)(base[kk] + STAGE * 32768 + (ROWS + n * 16) * 128);
 }
 
 // acc[m][n]: lane l owns row m*16 + (l&15), columns n*16 + (l>>4)*4 + {0..3} (operands swapped in the MFMA)
@@ -125,13 +127,13 @@ __device__ __forceinline__ void g256_cluster(const bf16x8 (&a)[4][2], const bf16
 // once gemm256_mainloop has returned (it ends with a barrier behind every wave's last read).
 __device__ __forceinline__ void g256_issue_prologue(const G256Operand& A, const G256Operand& B, char* smem, int K,
                                                     int wave) {
-    g256_issue_half(A, 0, 0, smem, wave);
-    g256_issue_half(A, 1, 0, smem, wave);
-    g256_issue_half(B, 0, 0, smem + 32768, wave);
-    g256_issue_half(B, 1, 0, smem + 32768, wave);
+    g256_issue_half(A, 0, 0, G256_A(smem, 0), wave);
+    g256_issue_half(A, 1, 0, G256_A(smem, 0), wave);
+    g256_issue_half(B, 0, 0, G256_B(smem, 0), wave);
+    g256_issue_half(B, 1, 0, G256_B(smem, 0), wave);
     if (K > 64) {
-        g256_issue_half(A, 0, 128, smem + G256_STAGE, wave);
-        g256_issue_half(A, 1, 128, smem + G256_STAGE, wave);
+        g256_issue_half(A, 0, 128, G256_A(smem, 1), wave);
+        g256_issue_half(A, 1, 128, G256_A(smem, 1), wave);
     }
 }
 
@@ -151,8 +153,8 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    g256_read_a<0>(f.alo, ad.a[0]);
-    g256_read_b<0>(f.blo, ad.b[0]);
+    g256_read_a<0, 0>(f.alo, ad.a);
+    g256_read_b<0, 0>(f.blo, ad.b);
     G256_FENCE();
 
     // two K-tiles per trip; an odd trailing tile is peeled so the loop has a single exit
@@ -160,36 +162,34 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
     for (; t + 1 < nt; t += 2) {
         // ------------------------------------------------------------ even tile t, stage 0
         {
-            char* cur = smem;
-            char* oth = smem + G256_STAGE;
             const bool n1 = t + 1 < nt, n2 = t + 2 < nt;
             // P0
-            g256_read_a<64>(f.ahi, ad.a[0]);
-            if (n1) g256_issue_half(B, 0, (t + 1) * 128, oth + 32768, wave);
+            g256_read_a<64, 0>(f.ahi, ad.a);
+            if (n1) g256_issue_half(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             g256_cluster<0, 0>(f.alo, f.blo, acc);
             G256_FENCE();
             // P1
-            g256_read_b<32>(f.bhi, ad.b[0]);
-            if (n1) g256_issue_half(B, 1, (t + 1) * 128, oth + 32768, wave);
+            g256_read_b<32, 0>(f.bhi, ad.b);
+            if (n1) g256_issue_half(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             g256_cluster<4, 0>(f.ahi, f.blo, acc);
             G256_FENCE();
             // P2: every wave has retired its A reads of this stage -> refill its A halves
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (n2) g256_issue_half(A, 0, (t + 2) * 128, cur, wave);
+            if (n2) g256_issue_half(A, 0, (t + 2) * 128, G256_A(smem, 0), wave);
             G256_FENCE();
             g256_cluster<4, 2>(f.ahi, f.bhi, acc);
             G256_FENCE();
             // P3: publish tile t+1, start reading it
-            if (n2) g256_issue_half(A, 1, (t + 2) * 128, cur, wave);
+            if (n2) g256_issue_half(A, 1, (t + 2) * 128, G256_A(smem, 0), wave);
             if (n1) {
                 if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                g256_read_a<64>(f.ahi, ad.a[1]);          // odd tiles start with A-hi
-                g256_read_b<0>(f.blo, ad.b[1]);
+                g256_read_a<64, 1>(f.ahi, ad.a);          // odd tiles start with A-hi
+                g256_read_b<0, 1>(f.blo, ad.b);
             }
             G256_FENCE();
             g256_cluster<0, 2>(f.alo, f.bhi, acc);
@@ -197,37 +197,35 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
         }
         // ------------------------------------------------------------ odd tile t+1, stage 1
         {
-            char* cur = smem + G256_STAGE;
-            char* oth = smem;
             const int u = t + 1;
             const bool n1 = u + 1 < nt, n2 = u + 2 < nt;
             // P0'
-            g256_read_a<0>(f.alo, ad.a[1]);
-            if (n1) g256_issue_half(B, 0, (u + 1) * 128, oth + 32768, wave);
+            g256_read_a<0, 1>(f.alo, ad.a);
+            if (n1) g256_issue_half(B, 0, (u + 1) * 128, G256_B(smem, 0), wave);
             G256_FENCE();
             g256_cluster<4, 0>(f.ahi, f.blo, acc);
             G256_FENCE();
             // P1'
-            g256_read_b<32>(f.bhi, ad.b[1]);
-            if (n1) g256_issue_half(B, 1, (u + 1) * 128, oth + 32768, wave);
+            g256_read_b<32, 1>(f.bhi, ad.b);
+            if (n1) g256_issue_half(B, 1, (u + 1) * 128, G256_B(smem, 0), wave);
             G256_FENCE();
             g256_cluster<0, 0>(f.alo, f.blo, acc);
             G256_FENCE();
             // P2'
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (n2) g256_issue_half(A, 0, (u + 2) * 128, cur, wave);
+            if (n2) g256_issue_half(A, 0, (u + 2) * 128, G256_A(smem, 1), wave);
             G256_FENCE();
             g256_cluster<0, 2>(f.alo, f.bhi, acc);
             G256_FENCE();
             // P3'
-            if (n2) g256_issue_half(A, 1, (u + 2) * 128, cur, wave);
+            if (n2) g256_issue_half(A, 1, (u + 2) * 128, G256_A(smem, 1), wave);
             if (n1) {
                 if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                g256_read_a<0>(f.alo, ad.a[0]);               // even tiles start with A-lo
-                g256_read_b<0>(f.blo, ad.b[0]);
+                g256_read_a<0, 0>(f.alo, ad.a);               // even tiles start with A-lo
+                g256_read_b<0, 0>(f.blo, ad.b);
             }
             G256_FENCE();
             g256_cluster<4, 2>(f.ahi, f.bhi, acc);
@@ -237,36 +235,34 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
     if (t < nt) {
         // ------------------------------------------------------------ even tile t, stage 0
         {
-            char* cur = smem;
-            char* oth = smem + G256_STAGE;
             const bool n1 = t + 1 < nt, n2 = t + 2 < nt;
             // P0
-            g256_read_a<64>(f.ahi, ad.a[0]);
-            if (n1) g256_issue_half(B, 0, (t + 1) * 128, oth + 32768, wave);
+            g256_read_a<64, 0>(f.ahi, ad.a);
+            if (n1) g256_issue_half(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             g256_cluster<0, 0>(f.alo, f.blo, acc);
             G256_FENCE();
             // P1
-            g256_read_b<32>(f.bhi, ad.b[0]);
-            if (n1) g256_issue_half(B, 1, (t + 1) * 128, oth + 32768, wave);
+            g256_read_b<32, 0>(f.bhi, ad.b);
+            if (n1) g256_issue_half(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             g256_cluster<4, 0>(f.ahi, f.blo, acc);
             G256_FENCE();
             // P2: every wave has retired its A reads of this stage -> refill its A halves
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (n2) g256_issue_half(A, 0, (t + 2) * 128, cur, wave);
+            if (n2) g256_issue_half(A, 0, (t + 2) * 128, G256_A(smem, 0), wave);
             G256_FENCE();
             g256_cluster<4, 2>(f.ahi, f.bhi, acc);
             G256_FENCE();
             // P3: publish tile t+1, start reading it
-            if (n2) g256_issue_half(A, 1, (t + 2) * 128, cur, wave);
+            if (n2) g256_issue_half(A, 1, (t + 2) * 128, G256_A(smem, 0), wave);
             if (n1) {
                 if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                g256_read_a<64>(f.ahi, ad.a[1]);          // odd tiles start with A-hi
-                g256_read_b<0>(f.blo, ad.b[1]);
+                g256_read_a<64, 1>(f.ahi, ad.a);          // odd tiles start with A-hi
+                g256_read_b<0, 1>(f.blo, ad.b);
             }
             G256_FENCE();
             g256_cluster<0, 2>(f.alo, f.bhi, acc);

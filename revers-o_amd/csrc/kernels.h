@@ -85,12 +85,10 @@ int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const f
 // 256 x 256 tile scan with queue + drain selection (topk256.hip); KSEL = 32
 int topk_scan256_splits(int Q, long rows);
 int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
-                        int splits, uint64_t* part, int lists_per_query, const float* tau0, hipStream_t st);
-int launch_topk_seed(const uint64_t* pre, long pre_stride, uint64_t* part, long part_row_stride, int slot, int Q,
-                     float* tau0, hipStream_t st);
+                        int splits, uint64_t* part, int lists_per_query, uint32_t* tau_g, hipStream_t st);
 // pre-pass of the 256 x 256 scan: KSEL best columns of every row of a [Q][n] fp32 score matrix
 int launch_topk_select_rows(const float* scores, long ld, int n, int Q, uint64_t* part, long part_row_stride, int slot,
-                            float* tau0, hipStream_t st);
+                            uint32_t* tau0, hipStream_t st);
 // all-padding result for an empty gallery
 int launch_topk_fill_empty(float* s, long long* i, int* c, int Q, int k, hipStream_t st);
 // merge P per-shard result lists [P][Q][k] -> [Q][k]

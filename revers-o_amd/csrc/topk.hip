@@ -307,7 +307,7 @@ int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const f
 template <int KSEL>
 __global__ __launch_bounds__(256) void topk_select_rows_kernel(const float* __restrict__ scores, long lds_, int n,
                                                                int Q, uint64_t* __restrict__ part, long part_row_stride,
-                                                               int slot, float* __restrict__ tau0) {
+                                                               int slot, uint32_t* __restrict__ tau0) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
@@ -328,10 +328,10 @@ __global__ __launch_bounds__(256) void topk_select_rows_kernel(const float* __re
         tau = last ? key_score(last) : -INFINITY;
     }
     if (lane < KSEL) part[(long)q * part_row_stride + (long)slot * KSEL + lane] = run;
-    if (lane == 0) tau0[q] = tau;
+    if (lane == 0) tau0[q] = f32_orderable(tau);     // shared admission score, order-preserving u32
 }
 int launch_topk_select_rows(const float* scores, long ld, int n, int Q, uint64_t* part, long part_row_stride, int slot,
-                            float* tau0, hipStream_t st) {
+                            uint32_t* tau0, hipStream_t st) {
     if (Q <= 0) return 0;
     hipLaunchKernelGGL((topk_select_rows_kernel<32>), dim3((Q + 3) / 4), dim3(256), 0, st, scores, ld, n, Q, part,
                        part_row_stride, slot, tau0);

@@ -20,9 +20,9 @@
 namespace revo {
 
 constexpr int S256_QCAP = 2048;          // queue entries
-constexpr int S256_DRAIN = 1024;         // drain once this many are queued
+constexpr int S256_DRAIN = 1792;         // drain once this many are queued (256 slots of slack for the next tile)
 constexpr int S256_KSEL = 32;
-constexpr int S256_LDS = G256_LDS + S256_QCAP * 8 + 256 * 4 * 3 + 64 + 8 * 64 * 8;
+constexpr int S256_LDS = G256_LDS + S256_QCAP * 8 + 256 * 4 * 3 + 64 + 8 * 64 * 8 + 256 * 8;
 
 __device__ __forceinline__ uint64_t s256_entry(int row, float score, uint32_t relidx) {
     return ((uint64_t)row << 56) | ((uint64_t)f32_orderable(score) << 24) | (uint64_t)((~relidx) & 0xffffffu);
@@ -49,12 +49,13 @@ struct S256Lds {
     int* end;            // [256]
     int* ctrl;           // [0] queue count (may exceed the capacity: overflow), [1..] spare
     uint64_t* scratch;   // [8][64] wave-private
+    uint64_t* wkey;      // [256] key of the row's KSEL-th list entry (0 while the list is not full)
 };
 
 // All 512 threads.  Sort the queue (row, score, index descending), merge every row's best
 // entries into its global list, refresh the admission scores, empty the queue.
 __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* part, long part_row_stride, int q0, int qvalid,
-                                        uint32_t idx_base, int tid) {
+                                        uint32_t idx_base, int tid, uint32_t* tau_g) {
     const int wave = tid >> 6, lane = tid & 63;
     __syncthreads();
     int n = L.ctrl[0];
@@ -87,35 +88,48 @@ __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* part, long p
     uint64_t* ws = L.scratch + wave * 64;
     for (int r = wave; r < qvalid; r += 8) {
         const int s0 = L.start[r];
-        int c = L.end[r] - s0;
-        if (c <= 0) continue;
-        c = c < S256_KSEL ? c : S256_KSEL;
+        const int cnt = L.end[r] - s0;
+        if (cnt <= 0) continue;
         uint64_t* list = part + (long)(q0 + r) * part_row_stride;
-        uint64_t v;
-        if (lane < 32) {
-            v = list[lane];
-        } else {
-            const int jx = 63 - lane;                       // lane 63 takes the row's best queued entry
-            v = jx < c ? s256_entry_to_key(L.queue[s0 + jx], idx_base) : 0ull;
-        }
-        // lanes 0..31 best-first, lanes 32..63 worst-first: bitonic -> sorted best-first
+        uint64_t cur = lane < 32 ? list[lane] : 0ull;          // lanes 0..31: the row's list, best first
+        // The row's queued entries are merged 32 at a time, duplicates removed after every merge: a tile
+        // that is computed again after a queue overflow re-queues entries the list already holds, and
+        // truncating the queue side before de-duplication could push new entries out.
+        for (int off = 0; off < cnt; off += S256_KSEL) {
+            const int c = (cnt - off) < S256_KSEL ? (cnt - off) : S256_KSEL;
+            const uint64_t best = s256_entry_to_key(L.queue[s0 + off], idx_base);
+            const uint64_t worst_kept = __builtin_amdgcn_readlane((uint32_t)cur, S256_KSEL - 1) |
+                                        ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(cur >> 32), S256_KSEL - 1) << 32);
+            if (off > 0 && worst_kept != 0ull && best < worst_kept) break;   // nothing further down can enter
+            uint64_t v;
+            if (lane < 32) {
+                v = cur;
+            } else {
+                const int jx = 63 - lane;                   // lane 63 takes the chunk's best entry
+                v = jx < c ? s256_entry_to_key(L.queue[s0 + off + jx], idx_base) : 0ull;
+            }
+            // lanes 0..31 best-first, lanes 32..63 worst-first: bitonic -> sorted best-first
 #pragma unroll
-        for (int j = 32; j > 0; j >>= 1) {
-            const uint64_t o = s256_shfl_xor(v, j);
-            v = ((lane & j) == 0) ? (v > o ? v : o) : (v < o ? v : o);
+            for (int j = 32; j > 0; j >>= 1) {
+                const uint64_t o = s256_shfl_xor(v, j);
+                v = ((lane & j) == 0) ? (v > o ? v : o) : (v < o ? v : o);
+            }
+            const uint64_t prev = s256_shfl_up1(v);
+            const bool keep = v != 0ull && (lane == 0 || v != prev);
+            const unsigned long long km = __ballot(keep);
+            const int pos = __popcll(km & ((1ull << lane) - 1ull));
+            ws[lane] = 0ull;
+            if (keep) ws[pos] = v;            // LDS operations of one wave complete in order
+            cur = lane < S256_KSEL ? ws[lane] : 0ull;
         }
-        // drop duplicates (a tile is re-scanned after a queue overflow) and compact
-        const uint64_t prev = s256_shfl_up1(v);
-        const bool keep = v != 0ull && (lane == 0 || v != prev);
-        const unsigned long long km = __ballot(keep);
-        const int pos = __popcll(km & ((1ull << lane) - 1ull));
-        ws[lane] = 0ull;
-        if (keep) ws[pos] = v;            // LDS operations of one wave complete in order
-        const uint64_t outv = ws[lane];
-        if (lane < S256_KSEL) list[lane] = outv;
-        const uint64_t last = __builtin_amdgcn_readlane((uint32_t)(outv >> 32), S256_KSEL - 1);
+        if (lane < S256_KSEL) list[lane] = cur;
+        if (lane == S256_KSEL - 1) L.wkey[r] = cur;           // 0 while the list is not full
+        const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(cur >> 32), S256_KSEL - 1);
         if (lane == 0 && last != 0u) {
-            const float t = orderable_f32((uint32_t)last);
+            // this slice's KSEL-th best is a lower bound of the query's final KSEL-th best: publish it
+            // for the other slices of the same query (stale reads only admit a few more candidates)
+            const uint32_t seen = __hip_atomic_fetch_max(tau_g + q0 + r, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float t = orderable_f32(seen > last ? seen : last);
             if (t > L.tau[r]) L.tau[r] = t;
         }
     }
@@ -132,7 +146,7 @@ struct Scan256Args {
     int splits;
     uint64_t* part;               // [Q][lists_per_query][KSEL]; this kernel owns slots [0, splits)
     int lists_per_query;
-    const float* tau0;            // [Q] seed admission scores (-inf when the pre-pass found < KSEL rows)
+    uint32_t* tau_g;              // [Q] shared admission scores (order-preserving u32 of the score), seeded by the pre-pass
 };
 
 __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Args p) {
@@ -144,6 +158,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     L.end = L.start + 256;
     L.ctrl = L.end + 256;
     L.scratch = (uint64_t*)(L.ctrl + 16);
+    L.wkey = L.scratch + 8 * 64;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,7 +177,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     uint64_t* mypart = p.part + (long)sp * S256_KSEL;
     const long part_row_stride = (long)p.lists_per_query * S256_KSEL;
 
-    if (tid < 256) L.tau[tid] = tid < qvalid ? p.tau0[q0 + tid] : INFINITY;
+    if (tid < 256) L.tau[tid] = tid < qvalid ? orderable_f32(p.tau_g[q0 + tid]) : INFINITY;
+    if (tid < 256) L.wkey[tid] = 0ull;
     if (tid == 0) L.ctrl[0] = 0;
     __syncthreads();
     if (t0 >= t1) return;
@@ -172,7 +188,12 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     g256_operand_init(B, p.Gb + row_begin * p.ldg, p.ldg, p.N - row_begin, 0, wave, lane);
     g256_issue_prologue(A, B, smem, p.D, wave);
 
+    // Normal mode: one pass per tile (groups == 1).  If a pass admits more entries than the queue holds
+    // (a badly seeded or adversarially ordered gallery), the tile is recomputed in 2, 4, ... 32 column
+    // groups, one pass and one drain per group; at 32 groups a pass can admit at most 256 x 8 = 2048
+    // entries, so the retry always terminates.  Entries queued twice are removed when lists are merged.
     long t = t0;
+    int groups = 1, grp = 0;
     while (t < t1) {
         const long n0 = p.n_begin + t * 256;
         {
@@ -183,22 +204,19 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
                 for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             gemm256_mainloop(A, B, smem, p.D, wave, lane, acc);
 
-            if (t + 1 < t1) {
+            if (groups == 1 && t + 1 < t1) {
                 // next gallery tile: rebased descriptors (any gallery size), DMA in flight during the selection
                 g256_operand_init(B, p.Gb + (n0 + 256) * p.ldg, p.ldg, p.N - (n0 + 256), 0, wave, lane);
                 g256_issue_prologue(A, B, smem, p.D, wave);
             }
             asm volatile("" : "+v"(lane) :: "memory");
-            // (a runtime branch right behind the main loop: without one hipcc 7.2 allocates the
-            //  loop so that the accumulators spill -- same workaround as in gemm256_kernel)
-            if (p.lists_per_query <= 0) continue;
             const int lr = lane & 15, lq = lane >> 4;
             const int rbase = (wave >> 2) * 128 + lr;            // + m * 16
             const int cbase = (wave & 3) * 64 + lq * 4;          // + n * 16 + j
             const long left = p.N - n0;
             const uint32_t rel0 = (uint32_t)(n0 - row_begin);
-            bool any = false;
             float taum[8];
+            unsigned hitm = 0;             // bit m: some lane of this wave has a candidate in row fragment m
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 taum[m] = L.tau[rbase + m * 16];
@@ -210,25 +228,34 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
                         if (left < 256 && cbase + n * 16 + j >= left) acc[m][n][j] = -INFINITY;
                         mx = fmaxf(mx, acc[m][n][j]);
                     }
-                any |= mx >= taum[m];
+                if (__ballot(mx >= taum[m]) != 0ull) hitm |= 1u << m;
             }
-            if (__ballot(any) != 0ull) {
+            if (hitm) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
+                    if (!(hitm & (1u << m))) continue;          // wave-uniform
+                    // the row's current KSEL-th entry as (score, index); an empty slot admits everything
+                    const uint64_t wk = L.wkey[rbase + m * 16];
+                    const float ws = wk ? key_score(wk) : -INFINITY;
+                    const uint32_t widx = wk ? key_index(wk) : 0xffffffffu;
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float v = acc[m][n][j];
-                            const bool hit = v >= taum[m] && v > -INFINITY;
+                            const int col = cbase + n * 16 + j;
+                            // admission score (shared across slices) first, then the strict test against the
+                            // row's own KSEL-th entry: an equal score enters only with a smaller index, so
+                            // ties cannot keep the queue full forever
+                            const bool hit = v >= taum[m] && v > -INFINITY && (col & (groups - 1)) == grp &&
+                                             (v > ws || (v == ws && idx_base + rel0 + col < widx));
                             const unsigned long long hm = __ballot(hit);
                             if (hm) {
                                 int base = 0;
                                 if (lane == 0) base = atomicAdd(&L.ctrl[0], __popcll(hm));
                                 base = __builtin_amdgcn_readfirstlane(base);
                                 const int pos = base + __popcll(hm & ((1ull << lane) - 1ull));
-                                if (hit && pos < S256_QCAP)
-                                    L.queue[pos] = s256_entry(rbase + m * 16, v, rel0 + cbase + n * 16 + j);
+                                if (hit && pos < S256_QCAP) L.queue[pos] = s256_entry(rbase + m * 16, v, rel0 + col);
                             }
                         }
                 }
@@ -237,23 +264,40 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
         // the accumulators are dead from here on (the drain is a real call)
         __syncthreads();
         const int qc = L.ctrl[0];
-        if (qc > S256_QCAP) {
-            // overflow: entries past the capacity were dropped.  Merge what was queued (the admission
-            // scores rise), then compute this tile again; re-queued duplicates vanish in the list merge.
-            s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile's DMA must not land on top
-            __syncthreads();
-            g256_operand_init(B, p.Gb + n0 * p.ldg, p.ldg, p.N - n0, 0, wave, lane);
-            g256_issue_prologue(A, B, smem, p.D, wave);
+        // pick up what the other slices of these queries have learnt meanwhile (ordered before the next
+        // selection by the barriers of the next main loop)
+        if (tid < qvalid) {
+            const float tg = orderable_f32(__hip_atomic_load(p.tau_g + q0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (tg > L.tau[tid]) L.tau[tid] = tg;
+        }
+        const bool overflow = qc > S256_QCAP;
+        if (groups == 1 && !overflow) {
+            if (qc >= S256_DRAIN || t + 1 >= t1) s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g);
+            ++t;
             continue;
         }
-        if (qc >= S256_DRAIN || t + 1 >= t1) s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid);
-        ++t;
+        // retry mode (or entering it): merge what was queued, then recompute this tile / its next column group
+        s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g);
+        if (overflow) {
+            groups = groups < 32 ? groups * 2 : 32;
+            grp = 0;
+        } else if (++grp == groups) {
+            groups = 1;
+            grp = 0;
+            ++t;                                                  // tile complete
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // a DMA issued for another tile must not land on top
+        __syncthreads();
+        if (t < t1) {
+            const long nn = p.n_begin + t * 256;
+            g256_operand_init(B, p.Gb + nn * p.ldg, p.ldg, p.N - nn, 0, wave, lane);
+            g256_issue_prologue(A, B, smem, p.D, wave);
+        }
     }
 }
 
 int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
-                        int splits, uint64_t* part, int lists_per_query, const float* tau0, hipStream_t st) {
+                        int splits, uint64_t* part, int lists_per_query, uint32_t* tau_g, hipStream_t st) {
     REVO_REQUIRE(D % 64 == 0 && ldq % 8 == 0 && ldg % 8 == 0, "search: D must be a multiple of 64");
     REVO_REQUIRE(N < (1ll << 32), "search: a shard holds at most 2^32 rows");
     REVO_REQUIRE(256l * ldg * 2 < (1l << 31) && 256l * ldq * 2 < (1l << 31), "search: row too long for the DMA window");
@@ -267,30 +311,8 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
                                            S256_LDS));
         done = true;
     }
-    Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, part, lists_per_query, tau0};
+    Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, part, lists_per_query, tau_g};
     hipLaunchKernelGGL(topk_scan256_kernel, dim3((Q + 255) / 256, splits), dim3(G256_THREADS), S256_LDS, st, a);
-    REVO_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-// tau0[q] = score of the KSEL-th entry of the pre-pass list (or -inf), and the list itself is
-// copied into slot `slot` of the query's lists.
-__global__ void topk_seed_kernel(const uint64_t* __restrict__ pre, long pre_stride, uint64_t* __restrict__ part,
-                                 long part_row_stride, int slot, int Q, float* __restrict__ tau0) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= Q) return;
-    if (lane < S256_KSEL) {
-        const uint64_t v = pre[(long)q * pre_stride + lane];
-        part[(long)q * part_row_stride + (long)slot * S256_KSEL + lane] = v;
-        if (lane == S256_KSEL - 1) tau0[q] = v ? key_score(v) : -INFINITY;
-    }
-}
-int launch_topk_seed(const uint64_t* pre, long pre_stride, uint64_t* part, long part_row_stride, int slot, int Q,
-                     float* tau0, hipStream_t st) {
-    if (Q <= 0) return 0;
-    hipLaunchKernelGGL(topk_seed_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, pre, pre_stride, part, part_row_stride,
-                       slot, Q, tau0);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -101,6 +101,40 @@ def test_adversarial_order_forces_queue_overflow(dev):
     G.close()
 
 
+def test_every_late_row_beats_the_seed(dev):
+    """The pre-pass rows are unrelated to the queries and every later row is close to every query:
+    the first fused tile admits all 256 x 256 scores, far more than the selection queue holds, so
+    the tile is recomputed in column groups (the retry ladder of topk256.hip).  Results stay exact."""
+    D, Q, k = 64, 300, 10
+    rng = np.random.default_rng(11)
+    base = rng.standard_normal(D).astype(np.float32)
+    qr = base[None] + 0.3 * rng.standard_normal((Q, D), dtype=np.float32)
+    gal = np.concatenate([rng.standard_normal((8192, D), dtype=np.float32),
+                          base[None] + 0.3 * rng.standard_normal((9000, D), dtype=np.float32)])
+    G = engine.Gallery(D, len(gal), device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    out = G.search(torch.from_numpy(qr).to(dev), k)
+    _check(out, osearch.search(gal, qr, k), atol=1e-5)
+    assert int(out[1].min()) >= 8192
+    G.close()
+
+
+def test_all_rows_identical_ties_terminate(dev):
+    """Every score ties: admission by score alone would refill the queue forever; the strict key
+    test admits an equal score only with a smaller index."""
+    D = 64
+    v = np.random.default_rng(3).standard_normal(D).astype(np.float32)
+    gal = np.repeat(v[None], 30000, axis=0)
+    G = engine.Gallery(D, len(gal), device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    q = torch.from_numpy(np.stack([v, -v, v * 2])).to(dev)
+    s, i, c = G.search(q, 10)
+    assert i[0].cpu().tolist() == list(range(10)) and i[2].cpu().tolist() == list(range(10))
+    assert i[1].cpu().tolist() == list(range(10))            # all -1.0: still index order
+    assert torch.allclose(s.cpu(), torch.tensor([[1.0] * 10, [-1.0] * 10, [1.0] * 10]), atol=1e-6)
+    G.close()
+
+
 @pytest.mark.parametrize("N,Q", [(16384, 1), (16385, 257), (70001, 64), (250000, 513)])
 def test_large_scan_path_vs_oracle(dev, N, Q):
     D, k = 128, 10
