@@ -31,13 +31,20 @@ template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                           bf16_t* __restrict__ out, long ldo, int S, int H, float c,
                                                           int q_lo, int k_lo) {
-    static_assert(HD == 64, "body attention kernel is built for head_dim 64");
+    static_assert(HD == 64 || HD == 96, "body attention kernel is built for head_dim 64 (B16, L14) and 96 (G14)");
     constexpr int NT = NW * 64;
     constexpr int KS = HD / 16;          // k-steps over d for S^T
     constexpr int DB = HD / 32;          // 32-wide d blocks of O^T
-    constexpr int ROWB = HD * 2;         // bytes per K/V tile row (128)
-    constexpr int TILE = 64 * ROWB;      // 8 KB
-    constexpr int NMOVE = (1024 + NT - 1) / NT;   // 16-byte chunks per thread per tile (K: ids 0..511, V: 512..1023)
+    constexpr int CH = HD / 8;           // 16-byte data chunks per K/V row (8 or 12)
+    // LDS rows: 128 B for head_dim 64; 256 B (192 B used) for head_dim 96 so that the XOR swizzles below
+    // stay inside a power-of-two chunk space.  Swizzle of the 16-byte chunk index, chosen per layout so
+    // that the ds_read_b128 K reads and the ds_read_b64_tr_b16 V reads are bank-conflict free:
+    //   128-B rows: K chunk ^= (key>>1)&7,  V chunk ^= ((key>>1)&1)<<2
+    //   256-B rows: K chunk ^= key&15,      V chunk ^= (key&3)<<2
+    constexpr int ROWB = HD == 64 ? 128 : 256;
+    constexpr int TILE = 64 * ROWB;      // 8 or 16 KB
+    constexpr int NCHUNK = 128 * CH;     // chunks per key tile: K ids [0, 64*CH), V ids [64*CH, 128*CH)
+    constexpr int NMOVE = (NCHUNK + NT - 1) / NT;
     constexpr float DEFER = 6.0f;        // skip the O rescale while the running max grows by < 2^6 (T13)
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE];   // K0 K1 V0 V1
 
@@ -62,25 +69,26 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
     }
 
-    // ---- staging: chunk id = tid + NT*i; ids < 512 are K chunks, the rest V chunks
+    // ---- staging: chunk id = tid + NT*i; the first 64*CH ids are K chunks, the rest V chunks
     int st_goff[NMOVE];      // element offset inside a tile-relative row block: key*ld + ch*8 (+ K/V base)
     int st_loff[NMOVE];      // LDS byte offset inside the (K0 K1 V0 V1) image for buffer 0
     int st_key[NMOVE];
 #pragma unroll
     for (int i = 0; i < NMOVE; ++i) {
         const int id = tid + NT * i;
-        const int isv = id >> 9, rem = id & 511;
-        const int key = rem >> 3, ch = rem & 7;
+        const int isv = id >= 64 * CH, rem = id - isv * 64 * CH;
+        const int key = rem / CH, ch = rem - key * CH;
         st_key[i] = key;
         st_goff[i] = ch * 8 + (isv ? 2 * W : W) + h * HD;
-        const int swz = isv ? (((key >> 1) & 1) << 2) : ((key >> 1) & 7);
+        const int swz = HD == 64 ? (isv ? (((key >> 1) & 1) << 2) : ((key >> 1) & 7))
+                                 : (isv ? ((key & 3) << 2) : (key & 15));
         st_loff[i] = isv * 2 * TILE + key * ROWB + ((ch ^ swz) << 4);
     }
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     u32x4 st_reg[NMOVE];
 #define ATT_LOAD_TILE(t)                                                                  \
     _Pragma("unroll") for (int i = 0; i < NMOVE; ++i) {                                   \
-        if (NT * i + NT <= 1024 || tid + NT * i < 1024) {                                 \
+        if (NT * i + NT <= NCHUNK || tid + NT * i < NCHUNK) {                             \
             int key = k_lo + (t) * 64 + st_key[i];                                        \
             key = key < S ? key : S - 1;                                                  \
             st_reg[i] = *(const u32x4*)(qkv + (rowbase + key) * ld + st_goff[i]);         \
@@ -88,22 +96,23 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
     }
 #define ATT_STORE_TILE(buf)                                                               \
     _Pragma("unroll") for (int i = 0; i < NMOVE; ++i) {                                   \
-        if (NT * i + NT <= 1024 || tid + NT * i < 1024)                                   \
+        if (NT * i + NT <= NCHUNK || tid + NT * i < NCHUNK)                               \
             *(u32x4*)(lds + (buf) * TILE + st_loff[i]) = st_reg[i];                       \
     }
 
     // ---- per-lane LDS fragment addresses (buffer 0), swizzles resolved once
     int kaddr[KS], vaddr[DB];
     {
-        const int sw = (r >> 1) & 7;
+        const int sw = HD == 64 ? ((r >> 1) & 7) : (r & 15);      // same for key r and key r + 32
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kaddr[ks] = r * ROWB + (((2 * ks + hh) ^ sw) << 4);
         const int g16 = lane >> 4, li = lane & 15;
         const int tq = li >> 2, tp = li & 3;
-        const int sbit = (tq >> 1) & 1;      // V swizzle bit of keys 4*hh + tq (+ multiples of 8)
+        // V swizzle of keys 4*hh + tq (+ multiples of 8): moves whole 64-byte d-blocks
+        const int sv = HD == 64 ? ((tq >> 1) & 1) : tq;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
-            vaddr[d] = 2 * TILE + (4 * hh + tq) * ROWB + ((((d ^ sbit) * 4 + (g16 & 1) * 2 + (tp >> 1))) << 4) + (tp & 1) * 8;
+            vaddr[d] = 2 * TILE + (4 * hh + tq) * ROWB + ((((d ^ sv) * 4 + (g16 & 1) * 2 + (tp >> 1))) << 4) + (tp & 1) * 8;
     }
 
     f32x16 oacc[DB];
@@ -317,12 +326,12 @@ __global__ __launch_bounds__(256) void attn_row_kernel(const bf16_t* __restrict_
     }
 }
 
-template <int NW>
+template <int HD, int NW>
 static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, float c, int q_lo,
                            int k_lo, hipStream_t st) {
     const int rows = S - q_lo;
     dim3 grid((rows + NW * 32 - 1) / (NW * 32), B * H), block(NW * 64);
-    hipLaunchKernelGGL((attn_fwd_kernel<64, NW>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_lo, k_lo);
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, NW>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_lo, k_lo);
 }
 
 static int g_attn_force_nw = 0;   // timing experiments only
@@ -330,7 +339,7 @@ void attention_force_nw(int nw) { g_attn_force_nw = nw; }
 // has_cls: row 0 of every sequence is the class token (true for every PE-Core variant with use_cls)
 int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, int hd, int has_cls,
                         hipStream_t st) {
-    REVO_REQUIRE(hd == 64, "attention: only head_dim 64 is built (PE-Core B16/L14 body)");
+    REVO_REQUIRE(hd == 64 || hd == 96, "attention: head_dim must be 64 (PE-Core B16 / L14) or 96 (G14)");
     REVO_REQUIRE(ld % 8 == 0 && ldo % 4 == 0, "attention: strides must keep 16-byte alignment");
     REVO_REQUIRE(S <= 1024 || !has_cls, "attention: class-token row kernel holds at most 1024 keys");
     if (B <= 0 || S <= 0) return 0;
@@ -338,7 +347,8 @@ int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B
     const float c = scale * 1.44269504088896340736f;
     // split off the class token when that makes the patch rows/keys tile better
     auto cost = [](int n) { return ((n + 31) / 32) * ((n + 63) / 64); };   // wave-tiles x key tiles
-    const int lo = (has_cls && S > 1 && cost(S - 1) < cost(S)) ? 1 : 0;
+    // (the one-row kernel is built for head_dim 64; the head_dim-96 variant, G14, has no class token)
+    const int lo = (has_cls && hd == 64 && S > 1 && cost(S - 1) < cost(S)) ? 1 : 0;
     const int rows = S - lo;
     // Waves per workgroup.  A workgroup's time per key tile is set by the staging / barrier /
     // softmax latency chain, not by how many of its waves hold query rows (measured, L14: 8 waves
@@ -350,11 +360,17 @@ int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B
         if (blocks < best_blocks) { best_blocks = blocks; best = nw; }
     }
     if (g_attn_force_nw) best = g_attn_force_nw;
-    switch (best) {
-        case 8: launch_attn_nw<8>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;
-        case 7: launch_attn_nw<7>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;
-        case 6: launch_attn_nw<6>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;
-        default: launch_attn_nw<4>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;
+    if (hd == 64) {
+        switch (best) {
+            case 8: launch_attn_nw<64, 8>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;
+            case 7: launch_attn_nw<64, 7>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;
+            case 6: launch_attn_nw<64, 6>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;
+            default: launch_attn_nw<64, 4>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st); break;
+        }
+    } else {
+        // 64 KB of LDS per workgroup: two 8-wave workgroups per CU
+        if (best >= 6) launch_attn_nw<96, 8>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st);
+        else launch_attn_nw<96, 4>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st);
     }
     REVO_HIP_CHECK(hipGetLastError());
     if (lo) {

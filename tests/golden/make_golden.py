@@ -110,6 +110,7 @@ def make_search(path):
 if __name__ == "__main__":
     make_tiny(os.path.join(HERE, "tiny_vit.npz"), "PE-Tiny-T14-56")
     make_tiny(os.path.join(HERE, "tiny_vit_ls.npz"), "PE-Tiny-T14-56-LS")
+    make_tiny(os.path.join(HERE, "tiny_vit_n14.npz"), "PE-Tiny-N14-56")      # head_dim 96, no class token (G14 shape family)
     make_b16_block(os.path.join(HERE, "b16_block.npz"))
     make_search(os.path.join(HERE, "search_4096x1024.npz"))
     for f in sorted(os.listdir(HERE)):

@@ -26,7 +26,8 @@ def _gold(name):
     return np.load(os.path.join(HERE, "golden", name))
 
 
-@pytest.mark.parametrize("fname,cname", [("tiny_vit.npz", "PE-Tiny-T14-56"), ("tiny_vit_ls.npz", "PE-Tiny-T14-56-LS")])
+@pytest.mark.parametrize("fname,cname", [("tiny_vit.npz", "PE-Tiny-T14-56"), ("tiny_vit_ls.npz", "PE-Tiny-T14-56-LS"),
+                                         ("tiny_vit_n14.npz", "PE-Tiny-N14-56")])
 def test_tiny_vit_layer_by_layer(dev, fname, cname):
     gold = _gold(fname)
     cfg, sd, images = make_golden.tiny_case(cname)
@@ -100,6 +101,23 @@ def test_b16_full_depth_vs_oracle(dev):
     # the same images one at a time take the 128 x 128 GEMM and the separate RoPE kernel: same answer
     one = torch.cat([eng.embed(u8[i:i + 1].to(dev)).cpu() for i in range(6)])
     assert ((one * emb).sum(-1) >= 0.99995).all()
+    eng.close()
+
+
+def test_g14_shape_family_single_block(dev):
+    """PE-Core-G14-448 dimensions (width 1536, 16 heads x 96, MLP 8960, no class token, 1024 tokens, out 1280)
+    cut to 2 blocks so the CPU oracle stays cheap: the head_dim-96 attention, K = 1536 / 8960 GEMMs, 192-wide
+    pool heads."""
+    import dataclasses
+    cfg = dataclasses.replace(reverso_amd.get_config("PE-Core-G14-448"), layers=2)
+    sd = weights.synth_weights(cfg, seed=5, randomize_affine=True)
+    g = torch.Generator().manual_seed(6)
+    u8 = torch.randint(0, 256, (2, 3, 448, 448), generator=g, dtype=torch.uint8)
+    ref = pe_vit.embed(sd, cfg, pe_vit.preprocess_u8(u8))
+    eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=2)
+    emb = eng.embed(u8.to(dev)).cpu()
+    assert emb.shape == (2, 1280)
+    assert ((emb * ref).sum(-1) >= 0.999).all(), (emb * ref).sum(-1)
     eng.close()
 
 

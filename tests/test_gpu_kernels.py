@@ -152,10 +152,10 @@ def test_rope(lib, dev):
     assert torch.equal(got[:, 0, :2], ref_in[:, 0, :2])                     # cls token: identity rotation
 
 
+@pytest.mark.parametrize("hd", [64, 96])
 @pytest.mark.parametrize("B,S,H", [(2, 577, 2), (1, 197, 3), (3, 17, 2), (1, 64, 1), (1, 65, 1), (2, 128, 2),
-                                   (1, 129, 1), (1, 1, 1)])
-def test_attention(lib, dev, B, S, H):
-    hd = 64
+                                   (1, 129, 1), (1, 1, 1), (1, 1024, 2), (2, 16, 2)])
+def test_attention(lib, dev, B, S, H, hd):
     W = H * hd
     g = torch.Generator(device="cpu").manual_seed(S * 31 + H)
     qkv = torch.randn(B * S, 3 * W, generator=g).to(dev).bfloat16()

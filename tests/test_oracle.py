@@ -19,7 +19,8 @@ def _load(name):
 
 
 def test_tiny_vit_matches_golden():
-    for fname, cname in (("tiny_vit.npz", "PE-Tiny-T14-56"), ("tiny_vit_ls.npz", "PE-Tiny-T14-56-LS")):
+    for fname, cname in (("tiny_vit.npz", "PE-Tiny-T14-56"), ("tiny_vit_ls.npz", "PE-Tiny-T14-56-LS"),
+                         ("tiny_vit_n14.npz", "PE-Tiny-N14-56")):
         gold = _load(fname)
         cfg, sd, images = make_golden.tiny_case(cname)
         assert np.array_equal(images.numpy(), gold["images"])
