@@ -645,6 +645,7 @@ extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
     revo::gemm_set_debug(flags & 3);
     revo::gemm_force_gy((flags >> 4) & 15);
     revo::attention_force_nw((flags >> 8) & 15);
+    revo::gemm_set_tail_split(((flags >> 12) & 1) ? 0 : 1);
     return 0;
 }
 extern "C" int32_t revo_op_set_gemm_tile(int32_t tile) {

@@ -343,8 +343,44 @@ bool gemm_uses_wide_epilogue(int M, int N, long lda, long ldb, long ldc) {
 }
 
 template <int EPI>
+static int launch_128(const GemmArgs& a, hipStream_t st);
+
+static int g_tail_split = 1;   // timing experiments only: 0 disables the tail split below
+void gemm_set_tail_split(int on) { g_tail_split = on; }
+
+template <int EPI>
 static int launch_t(const GemmArgs& a, hipStream_t st) {
-    if (use_256(a)) return launch_256<EPI>(a, st);
+    if (use_256(a)) {
+        // Tail split.  The 256 x 256 kernel runs one workgroup per CU, so its tiles go in rounds of
+        // 256; a last round that is mostly empty costs a full tile time (PE-L14 at batch 64: out-proj
+        // and fc2 have 580 tiles = 2.27 rounds, fc1 2320 = 9.06).  When the last round would be
+        // less than ~60 % full, the 256 x 256 kernel takes the M rows that make whole rounds and
+        // the remaining rows go to the 128 x 128 kernel (two workgroups per CU, 4x shorter tiles).
+        const long tm = (a.M + 255) / 256, tn = (a.N + 255) / 256;
+        const long tiles = tm * tn, full = tiles / 256 * 256, rem = tiles - full;
+        if (g_tail_split && g_force_tile == 0 && EPI != EPI_PATCH && EPI != EPI_BF16_ROPE && full > 0 && rem > 0 &&
+            rem <= 160) {
+            const long m_tiles_main = full / tn;
+            if (m_tiles_main >= 1 && m_tiles_main < tm) {
+                const int m_main = (int)(m_tiles_main * 256);
+                GemmArgs a1 = a, a2 = a;
+                a1.M = m_main;
+                a2.M = a.M - m_main;
+                a2.A = a.A + (long)m_main * a.lda;
+                const long esz = (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) ? 2 : 4;
+                a2.C = (char*)a.C + (long)m_main * a.ldc * esz;
+                const int rc = launch_256<EPI>(a1, st);
+                if (rc) return rc;
+                return launch_128<EPI>(a2, st);
+            }
+        }
+        return launch_256<EPI>(a, st);
+    }
+    return launch_128<EPI>(a, st);
+}
+
+template <int EPI>
+static int launch_128(const GemmArgs& a, hipStream_t st) {
     constexpr int LDS = 2 * (128 + 128) * 128;
     static bool attr_done = false;
     if (!attr_done) {

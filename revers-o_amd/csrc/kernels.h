@@ -32,6 +32,7 @@ bool gemm_uses_wide_epilogue(int M, int N, long lda, long ldb, long ldc);
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
 void gemm_set_debug(int d);
 void gemm_force_gy(int gy);
+void gemm_set_tail_split(int on);
 void gemm_force_tile(int t);   // 0 = heuristic, 128 or 256 = forced
 
 // --------------------------------------------------------- elementwise -----
