@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=6)
+    ap.add_argument("--dual-stream", type=int, default=0, help="1: embed as two half batches on two HIP streams")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,6 +102,7 @@ def main():
     D = cfg.out_dim
     B = args.batch
     eng = engine.VitEngine.synthetic(cfg, seed=0, device=local_rank, max_batch=B)
+    eng.set_dual_stream(bool(args.dual_stream))
 
     # synthetic gallery shard, generated on the device (seed 42 + rank), rows normalised at insert
     shard_rows = args.gallery // world + (1 if rank < args.gallery % world else 0)

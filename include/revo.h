@@ -65,6 +65,9 @@ int32_t revo_vit_forward(revo_vit* vit, const void* images, int32_t image_dtype,
 int32_t revo_vit_set_debug_layers(revo_vit* vit, int32_t n_layers);
 int32_t revo_vit_read_residual(revo_vit* vit, int32_t batch, float* dst, void* stream);
 int32_t revo_vit_seq_len(const revo_vit* vit);
+/* on != 0: forwards of >= 16 images run as two half batches on two streams (the caller's and an internal one,
+ * fork/join by events on the caller's stream) so that one half's kernels fill the CUs the other half leaves idle */
+int32_t revo_vit_set_dual_stream(revo_vit* vit, int32_t on);
 
 /* ---- gallery: replaces recreate_collection(size=D, COSINE) + upsert (core_system.py:600-622) */
 int32_t revo_gallery_create(int32_t dim, int64_t capacity, int32_t device, int32_t keep_f32, revo_gallery** out);

@@ -37,6 +37,7 @@ SIGNATURES = {
     "revo_vit_set_debug_layers": (_i32, [_p, _i32]),
     "revo_vit_read_residual": (_i32, [_p, _i32, _p, _p]),
     "revo_vit_seq_len": (_i32, [_p]),
+    "revo_vit_set_dual_stream": (_i32, [_p, _i32]),
     "revo_gallery_create": (_i32, [_i32, _i64, _i32, _i32, C.POINTER(_p)]),
     "revo_gallery_destroy": (_i32, [_p]),
     "revo_gallery_append": (_i32, [_p, _p, _i64, _i32, _i32, _p]),

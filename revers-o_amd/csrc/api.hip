@@ -153,6 +153,8 @@ struct revo_vit {
     bf16_t *patches = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr, *pool_att = nullptr,
            *pool_h = nullptr, *pool_m = nullptr, *pool_ob = nullptr;
     float *x = nullptr, *pool_o = nullptr, *feat = nullptr;
+    int dual_stream = 0;               // revo_vit_set_dual_stream
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     template <class T> int dalloc(T** out, size_t count) {
         void* p = nullptr;
@@ -161,7 +163,10 @@ struct revo_vit {
         *out = (T*)p;
         return 0;
     }
-    ~revo_vit() { for (void* p : owned) (void)hipFree(p); }
+    ~revo_vit() {
+        for (void* p : owned) (void)hipFree(p);
+        if (side) { (void)hipStreamDestroy(side); (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); }
+    }
 };
 
 namespace {
@@ -351,6 +356,11 @@ extern "C" int32_t revo_vit_set_debug_layers(revo_vit* vit, int32_t n) {
     vit->debug_layers = n;
     return 0;
 }
+extern "C" int32_t revo_vit_set_dual_stream(revo_vit* vit, int32_t on) {
+    REVO_REQUIRE(vit, "null handle");
+    vit->dual_stream = on != 0;
+    return 0;
+}
 extern "C" int32_t revo_vit_read_residual(revo_vit* vit, int32_t batch, float* dst, void* stream) {
     REVO_REQUIRE(vit && dst && batch >= 1 && batch <= vit->max_batch, "read_residual: bad arguments");
     REVO_HIP_CHECK(hipMemcpyAsync(dst, vit->x, (size_t)batch * vit->S * vit->cfg.width * 4, hipMemcpyDeviceToDevice,
@@ -369,17 +379,43 @@ int gemm(const char* cls, int epi, const bf16_t* A, long lda, const bf16_t* B, l
 }
 }  // namespace
 
-extern "C" int32_t revo_vit_forward(revo_vit* v, const void* images, int32_t image_dtype, int32_t batch, float* out,
-                                    int32_t normalize, void* stream) {
-    API_BEGIN
-    REVO_REQUIRE(v && images && out, "vit_forward: null argument");
-    REVO_REQUIRE(batch >= 1 && batch <= v->max_batch, "vit_forward: batch exceeds max_batch of the handle");
-    REVO_REQUIRE(image_dtype == 0 || image_dtype == 1, "vit_forward: image_dtype must be 0 (f32) or 1 (u8)");
-    hipStream_t st = (hipStream_t)stream;
-    const revo_vit_cfg& c = v->cfg;
-    const int W = c.width, Md = c.mlp_dim, D = c.out_dim, S = v->S, B = batch;
+// Forward of images [b0, b0 + B) of the call's batch on stream st; every workspace buffer is
+// addressed at the rows of those images, so two disjoint ranges can run on two streams at once.
+static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image_dtype, int b0, int B, float* out_all,
+                             int32_t normalize, hipStream_t st) {
+    const revo_vit_cfg& c = vv->cfg;
+    const int W = c.width, Md = c.mlp_dim, D = c.out_dim, S = vv->S;
     const int rows = B * S;
     using namespace revo;
+    // views of the workspace at this range
+    struct View {
+        bf16_t *patches, *h, *qkv, *att, *mlp, *pool_att, *pool_h, *pool_m, *pool_ob;
+        float *x, *pool_o, *feat;
+    } w;
+    const size_t r0 = (size_t)b0 * S;
+    w.patches = vv->patches + (size_t)b0 * vv->G2 * vv->Kp;
+    w.x = vv->x + r0 * W; w.h = vv->h + r0 * W; w.qkv = vv->qkv + r0 * 3 * W; w.att = vv->att + r0 * W;
+    w.mlp = vv->mlp + r0 * Md;
+    w.pool_att = vv->pool_att + (size_t)b0 * W; w.pool_o = vv->pool_o + (size_t)b0 * W;
+    w.pool_h = vv->pool_h + (size_t)b0 * W; w.pool_m = vv->pool_m + (size_t)b0 * Md;
+    w.pool_ob = vv->pool_ob + (size_t)b0 * W; w.feat = vv->feat + (size_t)b0 * D;
+    const size_t img_elems = (size_t)3 * c.image_size * c.image_size;
+    const void* images = (const char*)images_all + (size_t)b0 * img_elems * (image_dtype == 1 ? 1 : 4);
+    float* out = out_all + (size_t)b0 * D;
+    struct FW {
+        // names used by the schedule below: workspace from the view, everything else from the handle
+        bf16_t *patches, *h, *qkv, *att, *mlp, *pool_att, *pool_h, *pool_m, *pool_ob;
+        float *x, *pool_o, *feat;
+        int Kp, G2, hd, phd, debug_layers;
+        bf16_t* w_patch; float *pos, *cls, *lnpre_w, *lnpre_b, *lnpost_w, *lnpost_b;
+        const std::vector<LayerW>& layers;
+        float* q_probe; bf16_t* w_kv; float* b_kv; bf16_t* w_po; float* b_po; float *pln_w, *pln_b;
+        bf16_t* w_pfc1; float* b_pfc1; bf16_t* w_pfc2; float* b_pfc2; bf16_t* w_proj; float2* rope_cs;
+    } fw{w.patches, w.h, w.qkv, w.att, w.mlp, w.pool_att, w.pool_h, w.pool_m, w.pool_ob, w.x, w.pool_o, w.feat,
+         vv->Kp, vv->G2, vv->hd, vv->phd, vv->debug_layers, vv->w_patch, vv->pos, vv->cls, vv->lnpre_w, vv->lnpre_b,
+         vv->lnpost_w, vv->lnpost_b, vv->layers, vv->q_probe, vv->w_kv, vv->b_kv, vv->w_po, vv->b_po, vv->pln_w,
+         vv->pln_b, vv->w_pfc1, vv->b_pfc1, vv->w_pfc2, vv->b_pfc2, vv->w_proj, vv->rope_cs};
+    const FW* v = &fw;
 
     {   // K1 + K2: patch embed GEMM, position add, cls row
         { ProfScope ps("patchify", st);
@@ -439,6 +475,32 @@ extern "C" int32_t revo_vit_forward(revo_vit* v, const void* images, int32_t ima
         ProfScope ps("l2norm", st);
         CHECK_RC(launch_l2norm_rows(v->feat, D, out, D, nullptr, 0, B, D, st));
     }
+    return 0;
+}
+
+extern "C" int32_t revo_vit_forward(revo_vit* v, const void* images, int32_t image_dtype, int32_t batch, float* out,
+                                    int32_t normalize, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(v && images && out, "vit_forward: null argument");
+    REVO_REQUIRE(batch >= 1 && batch <= v->max_batch, "vit_forward: batch exceeds max_batch of the handle");
+    REVO_REQUIRE(image_dtype == 0 || image_dtype == 1, "vit_forward: image_dtype must be 0 (f32) or 1 (u8)");
+    hipStream_t st = (hipStream_t)stream;
+    if (!v->dual_stream || batch < 16 || v->debug_layers >= 0)
+        return vit_forward_range(v, images, image_dtype, 0, batch, out, normalize, st);
+    // Two halves of the batch on two streams: while one half sits in a GEMM's last, partly empty round of
+    // workgroups (or in a latency-bound kernel), the other half's kernels fill the idle CUs.
+    if (!v->side) {
+        REVO_HIP_CHECK(hipStreamCreateWithFlags(&v->side, hipStreamNonBlocking));
+        REVO_HIP_CHECK(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
+        REVO_HIP_CHECK(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
+    }
+    const int b1 = batch / 2;
+    REVO_HIP_CHECK(hipEventRecord(v->ev_fork, st));
+    REVO_HIP_CHECK(hipStreamWaitEvent(v->side, v->ev_fork, 0));
+    CHECK_RC(vit_forward_range(v, images, image_dtype, 0, b1, out, normalize, st));
+    CHECK_RC(vit_forward_range(v, images, image_dtype, b1, batch - b1, out, normalize, v->side));
+    REVO_HIP_CHECK(hipEventRecord(v->ev_join, v->side));
+    REVO_HIP_CHECK(hipStreamWaitEvent(st, v->ev_join, 0));
     return 0;
     API_END
 }

@@ -74,6 +74,10 @@ class VitEngine:
         except Exception:
             pass
 
+    def set_dual_stream(self, on=True):
+        """Run forwards of >= 16 images as two half batches on two HIP streams."""
+        _lib.check(self._lib.revo_vit_set_dual_stream(self._h, int(bool(on))))
+
     # -- the embed entry point ------------------------------------------------
     def embed(self, images, normalize=True, out=None):
         """images: uint8 or float32 ``[B,3,H,W]`` device tensor at the model

@@ -121,6 +121,21 @@ def test_g14_shape_family_single_block(dev):
     eng.close()
 
 
+def test_dual_stream_forward_is_identical(dev):
+    cfg = reverso_amd.get_config("PE-Core-B16-224")
+    eng = engine.VitEngine.synthetic(cfg, seed=2, device=0, max_batch=20)
+    g = torch.Generator().manual_seed(9)
+    u8 = torch.randint(0, 256, (19, 3, 224, 224), generator=g, dtype=torch.uint8).to(dev)
+    a = eng.embed(u8).cpu()
+    eng.set_dual_stream(True)
+    b = eng.embed(u8).cpu()
+    c = eng.embed(u8).cpu()
+    eng.set_dual_stream(False)
+    # rows are independent, but the two half batches take different GEMM tilings than the full batch
+    assert ((a * b).sum(-1) >= 0.99999).all() and torch.equal(b, c)
+    eng.close()
+
+
 def test_embed_rejects_bad_input(dev):
     cfg, sd, _ = make_golden.tiny_case()
     eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=2)
