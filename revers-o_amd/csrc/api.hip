@@ -212,8 +212,8 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
     REVO_REQUIRE(c.width % c.heads == 0 && c.width % c.pool_heads == 0, "vit_create: width must divide into heads");
     REVO_REQUIRE(c.width % 64 == 0 && c.mlp_dim % 64 == 0, "vit_create: width and mlp_dim must be multiples of 64");
     REVO_REQUIRE(c.out_dim % 4 == 0, "vit_create: out_dim must be a multiple of 4");
-    REVO_REQUIRE(c.width / c.heads == 64 || (c.width / c.heads == 96 && !c.use_cls),
-                 "vit_create: body head_dim must be 64 (PE-Core B16 / L14) or 96 without class token (G14)");
+    REVO_REQUIRE(c.width / c.heads == 64 || c.width / c.heads == 96,
+                 "vit_create: body head_dim must be 64 (PE-Core B16 / L14) or 96 (G14)");
     REVO_HIP_CHECK(hipSetDevice(device));
     std::unique_ptr<revo_vit> v(new revo_vit());
     v->cfg = c; v->device = device; v->max_batch = max_batch;

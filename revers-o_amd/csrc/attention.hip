@@ -22,15 +22,16 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* lo, const char* hi) {
     return __builtin_bit_cast(bf16x8, c);
 }
 
-// Body attention.  NW waves per workgroup, 32 query rows per wave.  Query rows
-// [q_lo, S) and key rows [k_lo, S) are tiled; when k_lo == 1 the class-token key
-// (row 0) is folded in as a rank-1 prelude (m = s_cls, l = 1, O = v_cls) so that
-// L14's 576 patch keys are exactly 9 unmasked tiles.  The class-token QUERY row
-// (when q_lo == 1) is served by attn_row_kernel below.
+// Body attention.  NW waves per workgroup, 32 query rows per wave.  Key rows [k_lo, S) are
+// tiled; when k_lo == 1 the class-token key (row 0) is folded in as a rank-1 prelude
+// (m = s_cls, l = 1, O = v_cls) so that L14's 576 patch keys are exactly 9 unmasked tiles.
+// Query rows are then taken in rotated order (1, 2, ..., S-1, 0): the patch rows tile the
+// waves exactly and the class-token query lands in a wave of the last workgroup that would
+// otherwise idle (q_rot).
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                           bf16_t* __restrict__ out, long ldo, int S, int H, float c,
-                                                          int q_lo, int k_lo) {
+                                                          int q_rot, int k_lo) {
     static_assert(HD == 64 || HD == 96, "body attention kernel is built for head_dim 64 (B16, L14) and 96 (G14)");
     constexpr int NT = NW * 64;
     constexpr int KS = HD / 16;          // k-steps over d for S^T
@@ -54,10 +55,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
     const int b = blockIdx.y / H, h = blockIdx.y - b * H;
     const int W = H * HD;
     const long rowbase = (long)b * S;
-    const int q0 = q_lo + blockIdx.x * (NW * 32) + wave * 32;
+    const int q0 = blockIdx.x * (NW * 32) + wave * 32;       // position in the (rotated) row order
     const bool wave_active = q0 < S;
-    const int qrow = q0 + r;
-    const int qrow_c = qrow < S ? qrow : S - 1;
+    const bool row_valid = q0 + r < S;
+    const int qpos = row_valid ? q0 + r : S - 1;
+    const int qrow = q_rot ? (qpos + 1 < S ? qpos + 1 : 0) : qpos;   // sequence row served by this lane
+    const int qrow_c = qrow;
 
     const bf16_t* kg = qkv + W + h * HD;
     const bf16_t* vg = qkv + 2 * W + h * HD;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
 
     if (wave_active) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        if (qrow < S) {
+        if (row_valid) {
             const float inv = 1.0f / l_tot;
             bf16_t* op = out + (rowbase + qrow) * ldo + h * HD;
 #pragma unroll
@@ -250,88 +253,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
 #undef ATT_STORE_TILE
 }
 
-// One query row (the class token) of every (image, head) against all S keys:
-// one wave per (image, head), lanes own keys (lane, lane + 64, ...), the query and the
-// per-lane partial output live in registers; the 64 partial outputs are summed across
-// lanes through LDS.  S <= 64 * RMAX.
-template <int HD, int RMAX>
-__global__ __launch_bounds__(256) void attn_row_kernel(const bf16_t* __restrict__ qkv, long ld,
-                                                       bf16_t* __restrict__ out, long ldo, int S, int H, int BH,
-                                                       int qrow, float scale) {
-    __shared__ float part[4][64][HD + 1];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int bh = blockIdx.x * 4 + wave;
-    if (bh >= BH) return;
-    const int b = bh / H, h = bh - b * H;
-    const int W = H * HD;
-    const bf16_t* base = qkv + (long)b * S * ld + h * HD;
-    float q[HD];
-    {
-        const bf16_t* qp = base + (long)qrow * ld;
-#pragma unroll
-        for (int c8 = 0; c8 < HD / 8; ++c8) {
-            const s16x8 v = *(const s16x8*)(qp + c8 * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) q[c8 * 8 + j] = bf16_to_f32((bf16_t)v[j]) * scale;
-        }
-    }
-    float sc[RMAX];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < RMAX; ++i) {
-        const int s = lane + 64 * i;
-        sc[i] = -INFINITY;
-        if (s < S) {
-            const bf16_t* kr = base + W + (long)s * ld;
-            float acc = 0.f;
-#pragma unroll
-            for (int c8 = 0; c8 < HD / 8; ++c8) {
-                const s16x8 v = *(const s16x8*)(kr + c8 * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc = fmaf(q[c8 * 8 + j], bf16_to_f32((bf16_t)v[j]), acc);
-            }
-            sc[i] = acc;
-            mx = fmaxf(mx, acc);
-        }
-    }
-    mx = wave_max(mx);
-    float o[HD];
-#pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] = 0.f;
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < RMAX; ++i) {
-        const int s = lane + 64 * i;
-        if (s < S) {
-            const float p = __expf(sc[i] - mx);
-            sum += p;
-            const bf16_t* vr = base + 2 * W + (long)s * ld;
-#pragma unroll
-            for (int c8 = 0; c8 < HD / 8; ++c8) {
-                const s16x8 v = *(const s16x8*)(vr + c8 * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[c8 * 8 + j] = fmaf(p, bf16_to_f32((bf16_t)v[j]), o[c8 * 8 + j]);
-            }
-        }
-    }
-    sum = wave_sum(sum);
-#pragma unroll
-    for (int d = 0; d < HD; ++d) part[wave][lane][d] = o[d];
-    // wave-private LDS slab: LDS operations of one wave complete in order, no barrier needed
-    float acc = 0.f;
-    if (lane < HD) {
-#pragma unroll 8
-        for (int l = 0; l < 64; ++l) acc += part[wave][l][lane];
-        out[((long)b * S + qrow) * ldo + h * HD + lane] = f32_to_bf16(acc / sum);
-    }
-}
-
 template <int HD, int NW>
-static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, float c, int q_lo,
+static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, float c, int q_rot,
                            int k_lo, hipStream_t st) {
-    const int rows = S - q_lo;
+    const int rows = S;
     dim3 grid((rows + NW * 32 - 1) / (NW * 32), B * H), block(NW * 64);
-    hipLaunchKernelGGL((attn_fwd_kernel<HD, NW>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_lo, k_lo);
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, NW>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo);
 }
 
 static int g_attn_force_nw = 0;   // timing experiments only
@@ -341,15 +268,13 @@ int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B
                         hipStream_t st) {
     REVO_REQUIRE(hd == 64 || hd == 96, "attention: head_dim must be 64 (PE-Core B16 / L14) or 96 (G14)");
     REVO_REQUIRE(ld % 8 == 0 && ldo % 4 == 0, "attention: strides must keep 16-byte alignment");
-    REVO_REQUIRE(S <= 1024 || !has_cls, "attention: class-token row kernel holds at most 1024 keys");
     if (B <= 0 || S <= 0) return 0;
     const float scale = 1.0f / sqrtf((float)hd);
     const float c = scale * 1.44269504088896340736f;
-    // split off the class token when that makes the patch rows/keys tile better
-    auto cost = [](int n) { return ((n + 31) / 32) * ((n + 63) / 64); };   // wave-tiles x key tiles
-    // (the one-row kernel is built for head_dim 64; the head_dim-96 variant, G14, has no class token)
-    const int lo = (has_cls && hd == 64 && S > 1 && cost(S - 1) < cost(S)) ? 1 : 0;
-    const int rows = S - lo;
+    // split off the class-token key when that saves a key tile (L14: 577 keys = 10 tiles, 576 = 9, no
+    // masked tile); the class-token query then goes last in the rotated row order
+    const int lo = (has_cls && S > 1 && (S - 1 + 63) / 64 < (S + 63) / 64) ? 1 : 0;
+    const int rows = S;
     // Waves per workgroup.  A workgroup's time per key tile is set by the staging / barrier /
     // softmax latency chain, not by how many of its waves hold query rows (measured, L14: 8 waves
     // 0.216 ms, 6 waves 0.244 ms, 4 waves 0.248 ms although 8 waves pad 576 rows to 768), so take
@@ -373,11 +298,6 @@ int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B
         else launch_attn_nw<96, 4>(qkv, ld, out, ldo, B, S, H, c, lo, lo, st);
     }
     REVO_HIP_CHECK(hipGetLastError());
-    if (lo) {
-        hipLaunchKernelGGL((attn_row_kernel<64, 16>), dim3((B * H + 3) / 4), dim3(256), 0, st, qkv, ld, out, ldo, S, H,
-                           B * H, 0, scale);
-        REVO_HIP_CHECK(hipGetLastError());
-    }
     return 0;
 }
 int launch_attention(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, int hd, hipStream_t st) {
