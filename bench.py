@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=6)
     ap.add_argument("--dual-stream", type=int, default=0, help="1: embed as two half batches on two HIP streams")
+    ap.add_argument("--search-queries", type=int, default=10000,
+                    help="extra, untimed-by-the-headline measurement: a batch of this many queries against the local "
+                         "gallery shard (BASELINE.json configs[3]); 0 disables it")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -180,6 +183,36 @@ def main():
                                    "avg_launch_ms": scan_ms}
     classes_ms = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(prof.items())}
 
+    # BASELINE.json configs[3] on this GPU's shard: a large query batch against the gallery, the
+    # MFMA-bound regime of the fused scan (north_star: >= 40 % of bf16 MFMA peak on the query x gallery GEMM).
+    # Measured after the headline region; it does not enter `value`.
+    search_big = None
+    if args.search_queries > 0 and shard_rows > 0:
+        Qn = args.search_queries
+        qg = torch.Generator(device=dev).manual_seed(7 + rank)
+        qbig = torch.randn(Qn, D, generator=qg, device=dev)
+        gal.search(qbig, args.k)
+        torch.cuda.synchronize()
+        engine.prof_reset()
+        engine.prof_enable(True)
+        reps = 3
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            gal.search(qbig, args.k)
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t1) / reps
+        engine.prof_enable(False)
+        p2 = engine.prof_report()
+        sc = p2.get("topk_scan", {})
+        scan_ms_big = sc["ms"] / sc["launches"] if sc.get("launches") else None
+        fl = 2.0 * Qn * shard_rows * D
+        search_big = {"queries": Qn, "gallery_rows": shard_rows, "dim": D, "k": args.k,
+                      "search_ms": dts * 1e3, "queries_per_s": Qn / dts,
+                      "scan_ms": scan_ms_big,
+                      "scan_tflops": fl / (scan_ms_big * 1e-3) / 1e12 if scan_ms_big else None,
+                      "scan_frac_of_mfma_peak": fl / (scan_ms_big * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if scan_ms_big else None,
+                      "end_to_end_tflops": fl / dts / 1e12}
+
     if rank == 0:
         res = {
             "metric": "images/sec embed+top-k (PE-L14-336, 1M x 1024 gallery)", "value": value, "unit": "images/s",
@@ -192,6 +225,7 @@ def main():
             "roofline": roofline,
             "kernel_ms_per_step": classes_ms,
             "embed_tflops": cfg.flops_per_image() * B * args.steps / dt / 1e12,
+            "search_query_batch": search_big,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, args.gallery, D, args.k, args.cpu_images, min(args.gallery, 250_000))

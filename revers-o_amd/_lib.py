@@ -49,6 +49,7 @@ SIGNATURES = {
     "revo_op_gemm": (_i32, [_i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p]),
     "revo_op_set_gemm_tile": (_i32, [_i32]),
     "revo_op_set_gemm_debug": (_i32, [_i32]),
+    "revo_debug_scan_stats": (_i32, [C.POINTER(C.c_int64)]),
     "revo_op_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i64, _i32, _p]),
     "revo_op_rope": (_i32, [_p, _i64, _p, _i32, _i32, _i32, _i32, _p]),
     "revo_op_attention": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),

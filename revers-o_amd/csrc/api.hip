@@ -708,6 +708,13 @@ extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
     revo::gemm_force_gy((flags >> 4) & 15);
     revo::attention_force_nw((flags >> 8) & 15);
     revo::gemm_set_tail_split(((flags >> 12) & 1) ? 0 : 1);
+    revo::topk_scan256_set_debug((flags >> 13) & 3);
+    return 0;
+}
+extern "C" int32_t revo_debug_scan_stats(int64_t* out4) {
+    REVO_HIP_CHECK(hipDeviceSynchronize());
+    REVO_HIP_CHECK(hipMemcpy(out4, revo::topk_scan256_stats(), 32, hipMemcpyDeviceToHost));
+    REVO_HIP_CHECK(hipMemset(revo::topk_scan256_stats(), 0, 64));
     return 0;
 }
 extern "C" int32_t revo_op_set_gemm_tile(int32_t tile) {

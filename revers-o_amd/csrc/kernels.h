@@ -85,6 +85,8 @@ int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const f
                        long long* out_idx, int* out_counts, hipStream_t st);
 // 256 x 256 tile scan with queue + drain selection (topk256.hip); KSEL = 32
 int topk_scan256_splits(int Q, long rows);
+void topk_scan256_set_debug(int d);   // timing experiments only
+unsigned long long* topk_scan256_stats();
 int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
                         int splits, uint64_t* part, int lists_per_query, uint32_t* tau_g, hipStream_t st);
 // pre-pass of the 256 x 256 scan: KSEL best columns of every row of a [Q][n] fp32 score matrix

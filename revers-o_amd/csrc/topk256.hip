@@ -86,12 +86,17 @@ __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* part, long p
     }
     __syncthreads();
     uint64_t* ws = L.scratch + wave * 64;
+    // the lists live in global memory (L2): the next row's list is requested before the current row is
+    // merged, so the round trips of a wave's ~32 rows overlap instead of adding up
+    uint64_t nxt = 0ull;
+    if (wave < qvalid && lane < 32) nxt = part[(long)(q0 + wave) * part_row_stride + lane];
     for (int r = wave; r < qvalid; r += 8) {
+        uint64_t cur = nxt;                                     // lanes 0..31: the row's list, best first
+        if (r + 8 < qvalid && lane < 32) nxt = part[(long)(q0 + r + 8) * part_row_stride + lane];
         const int s0 = L.start[r];
         const int cnt = L.end[r] - s0;
         if (cnt <= 0) continue;
         uint64_t* list = part + (long)(q0 + r) * part_row_stride;
-        uint64_t cur = lane < 32 ? list[lane] : 0ull;          // lanes 0..31: the row's list, best first
         // The row's queued entries are merged 32 at a time, duplicates removed after every merge: a tile
         // that is computed again after a queue overflow re-queues entries the list already holds, and
         // truncating the queue side before de-duplication could push new entries out.
@@ -147,6 +152,8 @@ struct Scan256Args {
     uint64_t* part;               // [Q][lists_per_query][KSEL]; this kernel owns slots [0, splits)
     int lists_per_query;
     uint32_t* tau_g;              // [Q] shared admission scores (order-preserving u32 of the score), seeded by the pre-pass
+    int dbg;                      // timing experiments only: 1 = skip the selection (results are wrong)
+    unsigned long long* stats;    // optional counters: [0] drains, [1] queued entries, [2] retry passes, [3] fragments scanned slowly
 };
 
 __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Args p) {
@@ -194,6 +201,10 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     // entries, so the retry always terminates.  Entries queued twice are removed when lists are merged.
     long t = t0;
     int groups = 1, grp = 0;
+    // (Measured with the debug counters: ~8100 entries are queued per workgroup at Q = 10k, N = 1M, 32
+    //  slices.  That number is set by how tight a bound ONE slice's KSEL-th best can give, about the
+    //  KSEL / slice-rows quantile; draining earlier or more often does not lower it.)
+    const int drain_thr = S256_DRAIN;
     while (t < t1) {
         const long n0 = p.n_begin + t * 256;
         {
@@ -217,6 +228,9 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
             const uint32_t rel0 = (uint32_t)(n0 - row_begin);
             float taum[8];
             unsigned hitm = 0;             // bit m: some lane of this wave has a candidate in row fragment m
+            if (p.dbg & 1) {
+                asm volatile("" :: "v"(acc[0][0]), "v"(acc[7][3]));
+            } else
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 taum[m] = L.tau[rbase + m * 16];
@@ -234,6 +248,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     if (!(hitm & (1u << m))) continue;          // wave-uniform
+                    if (p.stats && lane == 0) atomicAdd(p.stats + 3, 1ull);
                     // the row's current KSEL-th entry as (score, index); an empty slot admits everything
                     const uint64_t wk = L.wkey[rbase + m * 16];
                     const float ws = wk ? key_score(wk) : -INFINITY;
@@ -246,16 +261,12 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
                             const int col = cbase + n * 16 + j;
                             // admission score (shared across slices) first, then the strict test against the
                             // row's own KSEL-th entry: an equal score enters only with a smaller index, so
-                            // ties cannot keep the queue full forever
-                            const bool hit = v >= taum[m] && v > -INFINITY && (col & (groups - 1)) == grp &&
-                                             (v > ws || (v == ws && idx_base + rel0 + col < widx));
-                            const unsigned long long hm = __ballot(hit);
-                            if (hm) {
-                                int base = 0;
-                                if (lane == 0) base = atomicAdd(&L.ctrl[0], __popcll(hm));
-                                base = __builtin_amdgcn_readfirstlane(base);
-                                const int pos = base + __popcll(hm & ((1ull << lane) - 1ull));
-                                if (hit && pos < S256_QCAP) L.queue[pos] = s256_entry(rbase + m * 16, v, rel0 + col);
+                            // ties cannot keep the queue full forever.  Survivors are rare: each lane queues
+                            // its own (one LDS atomic per survivor) under a mostly empty exec mask.
+                            if (v >= taum[m] && v > -INFINITY && (col & (groups - 1)) == grp &&
+                                (v > ws || (v == ws && idx_base + rel0 + col < widx))) {
+                                const int pos = atomicAdd(&L.ctrl[0], 1);
+                                if (pos < S256_QCAP) L.queue[pos] = s256_entry(rbase + m * 16, v, rel0 + col);
                             }
                         }
                 }
@@ -266,13 +277,20 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
         const int qc = L.ctrl[0];
         // pick up what the other slices of these queries have learnt meanwhile (ordered before the next
         // selection by the barriers of the next main loop)
-        if (tid < qvalid) {
+        // (every fourth tile: the load is an L2 round trip that four waves would otherwise sit on after every tile)
+        if ((t & 3) == 0 && tid < qvalid) {
             const float tg = orderable_f32(__hip_atomic_load(p.tau_g + q0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (tg > L.tau[tid]) L.tau[tid] = tg;
         }
         const bool overflow = qc > S256_QCAP;
+        if (p.stats && tid == 0) {
+            if (overflow || groups > 1) atomicAdd(p.stats + 2, 1ull);
+            if (overflow || groups > 1 || qc >= drain_thr || t + 1 >= t1) { atomicAdd(p.stats + 0, 1ull); atomicAdd(p.stats + 1, (unsigned long long)qc); }
+        }
         if (groups == 1 && !overflow) {
-            if (qc >= S256_DRAIN || t + 1 >= t1) s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g);
+            if (qc >= drain_thr || t + 1 >= t1) {
+                s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g);
+            }
             ++t;
             continue;
         }
@@ -296,6 +314,13 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     }
 }
 
+static int g_scan_dbg = 0;
+static unsigned long long* g_scan_stats = nullptr;
+unsigned long long* topk_scan256_stats() {
+    if (!g_scan_stats) { (void)hipMalloc((void**)&g_scan_stats, 64); (void)hipMemset(g_scan_stats, 0, 64); }
+    return g_scan_stats;
+}
+void topk_scan256_set_debug(int d) { g_scan_dbg = d; }
 int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
                         int splits, uint64_t* part, int lists_per_query, uint32_t* tau_g, hipStream_t st) {
     REVO_REQUIRE(D % 64 == 0 && ldq % 8 == 0 && ldg % 8 == 0, "search: D must be a multiple of 64");
@@ -311,7 +336,7 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
                                            S256_LDS));
         done = true;
     }
-    Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, part, lists_per_query, tau_g};
+    Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, part, lists_per_query, tau_g, g_scan_dbg, (g_scan_dbg & 2) ? topk_scan256_stats() : nullptr};
     hipLaunchKernelGGL(topk_scan256_kernel, dim3((Q + 255) / 256, splits), dim3(G256_THREADS), S256_LDS, st, a);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;

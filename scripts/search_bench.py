@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, reverso_amd
 from reverso_amd import engine
 dev = torch.device("cuda", 0)
+from reverso_amd import _lib
+_lib.load().revo_op_set_gemm_debug(int(os.environ.get("SCAN_DBG", "0")) << 13)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 Qs = [int(a) for a in sys.argv[2:]] or [1, 64, 256, 10000]
 D, k = 1024, 10
@@ -28,6 +30,10 @@ for Q in Qs:
     scan = prof["topk_scan"]["ms"] / prof["topk_scan"]["launches"]
     flops = 2.0 * Q * N * D
     byts = N * D * 2 + Q * D * 2 + Q * k * 12
+    if int(os.environ.get("SCAN_DBG", "0")) & 2:
+        import ctypes
+        st4 = (ctypes.c_int64 * 4)(); _lib.load().revo_debug_scan_stats(st4)
+        print("scan stats over", iters + 2, "searches: drains", st4[0], "queued", st4[1], "retry passes", st4[2], "slow fragments", st4[3])
     print(json.dumps({"Q": Q, "N": N, "search_ms": round(ms, 4), "scan_ms": round(scan, 4),
                       "scan_TFLOPs": round(flops / scan / 1e9, 1), "scan_frac_mfma": round(flops / scan / 1e9 / 2500, 4),
                       "scan_GBs": round(byts / scan / 1e6, 1), "scan_frac_hbm": round(byts / scan / 1e6 / 8000, 4),
