@@ -644,7 +644,9 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
         n_pre = n_pre > 8192 ? 8192 : (n_pre < 1024 ? 1024 : n_pre);
         const int splits = topk_scan256_splits(Q, N - n_pre);
         const int lists = splits + 1;
-        const size_t part_bytes = (size_t)Q * lists * ksel * 8;
+        const size_t list_bytes = (size_t)Q * lists * ksel * 8;
+        const size_t gtop_bytes = (size_t)Q * splits * topk_scan256_top_m(splits) * 4;
+        const size_t part_bytes = list_bytes + gtop_bytes;          // zeroed together
         const size_t pre_off = (part_bytes + 255) / 256 * 256;
         CHECK_RC(need_part(pre_off + (size_t)Q * n_pre * 4));
         uint64_t* part = g->part;
@@ -660,7 +662,8 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
                                              g->tau0, st));
         }
         { ProfScope ps("topk_scan", st);
-          CHECK_RC(launch_topk_scan256(g->qb, D, g->gb, D, Q, N, D, n_pre, splits, part, lists, g->tau0, st)); }
+          CHECK_RC(launch_topk_scan256(g->qb, D, g->gb, D, Q, N, D, n_pre, splits, part, lists, g->tau0,
+                                       (uint32_t*)((char*)part + list_bytes), st)); }
         { ProfScope ps("topk_reduce", st); CHECK_RC(launch_topk_reduce(part, Q, lists, ksel, st)); }
         { ProfScope ps("topk_finish", st);
           CHECK_RC(launch_topk_finish(part, (long)lists * ksel, ksel, g->qf, D, g->keep_f32 ? g->gf : nullptr, D, D, Q,
@@ -708,12 +711,12 @@ extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
     revo::gemm_force_gy((flags >> 4) & 15);
     revo::attention_force_nw((flags >> 8) & 15);
     revo::gemm_set_tail_split(((flags >> 12) & 1) ? 0 : 1);
-    revo::topk_scan256_set_debug((flags >> 13) & 3);
+    revo::topk_scan256_set_debug((flags >> 13) & 7);
     return 0;
 }
 extern "C" int32_t revo_debug_scan_stats(int64_t* out4) {
     REVO_HIP_CHECK(hipDeviceSynchronize());
-    REVO_HIP_CHECK(hipMemcpy(out4, revo::topk_scan256_stats(), 32, hipMemcpyDeviceToHost));
+    REVO_HIP_CHECK(hipMemcpy(out4, revo::topk_scan256_stats(), 64, hipMemcpyDeviceToHost));
     REVO_HIP_CHECK(hipMemset(revo::topk_scan256_stats(), 0, 64));
     return 0;
 }

@@ -52,10 +52,72 @@ struct S256Lds {
     uint64_t* wkey;      // [256] key of the row's KSEL-th list entry (0 while the list is not full)
 };
 
+__device__ __forceinline__ uint32_t s256_sort_desc_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const uint32_t o = __shfl_xor(v, j, 64);
+            const bool take_max = (((lane & j) == 0) == ((lane & k2) == 0));
+            v = take_max ? (v > o ? v : o) : (v < o ? v : o);
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t s256_merge_desc_u32(uint32_t v, int lane) {   // v bitonic across the wave
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const uint32_t o = __shfl_xor(v, j, 64);
+        v = ((lane & j) == 0) ? (v > o ? v : o) : (v < o ? v : o);
+    }
+    return v;
+}
+
+// Cross-slice admission bound.  Every slice of a query publishes the scores of its best `top_m` list
+// entries (gtop[q][slice][top_m], order-preserving u32, written at drains).  Those are distinct gallery
+// rows, so the KSEL-th largest of their union is a lower bound of the query's final KSEL-th best score --
+// and a tight one: the global top KSEL is spread over the slices, few slices hold more than top_m of it.
+// One slice's own KSEL-th best only reaches the KSEL / slice-rows quantile (measured: ~6x more queued
+// entries than necessary at 32 slices).  All 512 threads; one wave per row, rows strided by 8.
+__device__ __noinline__ void s256_refresh_bounds(const S256Lds& L, const uint32_t* gtop, int q0, int qvalid, int nvals,
+                                                 int tid, unsigned long long* stats) {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int r = wave; r < qvalid; r += 8) {
+        const uint32_t* row = gtop + (long)(q0 + r) * nvals;
+        uint32_t run = 0u;                                        // lanes 0..31: best KSEL so far, descending
+        for (int base = 0; base < nvals; base += 128) {
+            const int i0 = base + lane * 2;
+            uint32_t v0 = 0u, v1 = 0u;
+            if (i0 < nvals) v0 = __hip_atomic_load(row + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i0 + 1 < nvals) v1 = __hip_atomic_load(row + i0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t a = s256_sort_desc_u32(v0 > v1 ? v0 : v1, lane);
+            const uint32_t b = s256_sort_desc_u32(v0 > v1 ? v1 : v0, lane);
+            // best 32 of the chunk: a[0..31] descending next to b[31..0] ascending is bitonic
+            const uint32_t brev = __shfl(b, 63 - lane, 64);      // all lanes take part: a shuffle reads 0 from inactive lanes
+            uint32_t x = lane < 32 ? a : brev;
+            x = s256_merge_desc_u32(x, lane);
+            const uint32_t xrev = __shfl(x, 63 - lane, 64);
+            uint32_t y = lane < 32 ? run : xrev;
+            y = s256_merge_desc_u32(y, lane);
+            run = lane < 32 ? y : 0u;
+        }
+        const uint32_t bound = (uint32_t)__builtin_amdgcn_readlane((int)run, S256_KSEL - 1);
+        if (lane == 0 && bound != 0u) {
+            const float b = orderable_f32(bound);
+            if (stats) atomicAdd(stats + (b > L.tau[r] ? 4 : 5), 1ull);
+            if (b > L.tau[r]) L.tau[r] = b;
+        } else if (lane == 0 && stats) {
+            atomicAdd(stats + 6, 1ull);
+        }
+    }
+    __syncthreads();
+}
+
 // All 512 threads.  Sort the queue (row, score, index descending), merge every row's best
 // entries into its global list, refresh the admission scores, empty the queue.
 __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* part, long part_row_stride, int q0, int qvalid,
-                                        uint32_t idx_base, int tid, uint32_t* tau_g) {
+                                        uint32_t idx_base, int tid, uint32_t* tau_g, uint32_t* gtop_mine, int gtop_stride,
+                                        int top_m) {
     const int wave = tid >> 6, lane = tid & 63;
     __syncthreads();
     int n = L.ctrl[0];
@@ -129,6 +191,9 @@ __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* part, long p
         }
         if (lane < S256_KSEL) list[lane] = cur;
         if (lane == S256_KSEL - 1) L.wkey[r] = cur;           // 0 while the list is not full
+        if (lane < top_m)                                       // publish this slice's best scores (see s256_refresh_bounds)
+            __hip_atomic_store(gtop_mine + (long)(q0 + r) * gtop_stride + lane, (uint32_t)(cur >> 32), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(cur >> 32), S256_KSEL - 1);
         if (lane == 0 && last != 0u) {
             // this slice's KSEL-th best is a lower bound of the query's final KSEL-th best: publish it
@@ -153,6 +218,8 @@ struct Scan256Args {
     int lists_per_query;
     uint32_t* tau_g;              // [Q] shared admission scores (order-preserving u32 of the score), seeded by the pre-pass
     int dbg;                      // timing experiments only: 1 = skip the selection (results are wrong)
+    uint32_t* gtop;               // [Q][splits][top_m] best list scores of every slice (zeroed before the launch)
+    int top_m;
     unsigned long long* stats;    // optional counters: [0] drains, [1] queued entries, [2] retry passes, [3] fragments scanned slowly
 };
 
@@ -239,12 +306,13 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
                 for (int n = 0; n < 4; ++n)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (left < 256 && cbase + n * 16 + j >= left) acc[m][n][j] = -INFINITY;
+                        // columns past the gallery end become NaN: never admitted, ignored by fmaxf
+                        if (left < 256 && cbase + n * 16 + j >= left) acc[m][n][j] = __builtin_nanf("");
                         mx = fmaxf(mx, acc[m][n][j]);
                     }
                 if (__ballot(mx >= taum[m]) != 0ull) hitm |= 1u << m;
             }
-            if (hitm) {
+            if (hitm && !(p.dbg & 4)) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     if (!(hitm & (1u << m))) continue;          // wave-uniform
@@ -263,7 +331,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
                             // row's own KSEL-th entry: an equal score enters only with a smaller index, so
                             // ties cannot keep the queue full forever.  Survivors are rare: each lane queues
                             // its own (one LDS atomic per survivor) under a mostly empty exec mask.
-                            if (v >= taum[m] && v > -INFINITY && (col & (groups - 1)) == grp &&
+                            if (v >= taum[m] && (col & (groups - 1)) == grp &&
                                 (v > ws || (v == ws && idx_base + rel0 + col < widx))) {
                                 const int pos = atomicAdd(&L.ctrl[0], 1);
                                 if (pos < S256_QCAP) L.queue[pos] = s256_entry(rbase + m * 16, v, rel0 + col);
@@ -283,19 +351,23 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
             if (tg > L.tau[tid]) L.tau[tid] = tg;
         }
         const bool overflow = qc > S256_QCAP;
+        if (groups == 1 && !overflow && (t & 15) == 15)
+            s256_refresh_bounds(L, p.gtop, q0, qvalid, p.splits * p.top_m, tid, p.stats);
         if (p.stats && tid == 0) {
             if (overflow || groups > 1) atomicAdd(p.stats + 2, 1ull);
             if (overflow || groups > 1 || qc >= drain_thr || t + 1 >= t1) { atomicAdd(p.stats + 0, 1ull); atomicAdd(p.stats + 1, (unsigned long long)qc); }
         }
         if (groups == 1 && !overflow) {
             if (qc >= drain_thr || t + 1 >= t1) {
-                s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g);
+                s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g, p.gtop + sp * p.top_m, p.splits * p.top_m,
+                           p.top_m);
             }
             ++t;
             continue;
         }
         // retry mode (or entering it): merge what was queued, then recompute this tile / its next column group
-        s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g);
+        s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g, p.gtop + sp * p.top_m, p.splits * p.top_m,
+                           p.top_m);
         if (overflow) {
             groups = groups < 32 ? groups * 2 : 32;
             grp = 0;
@@ -321,8 +393,11 @@ unsigned long long* topk_scan256_stats() {
     return g_scan_stats;
 }
 void topk_scan256_set_debug(int d) { g_scan_dbg = d; }
+int topk_scan256_top_m(int splits) { return splits >= 128 ? 1 : (splits > 32 ? 2 : 4); }
+
 int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
-                        int splits, uint64_t* part, int lists_per_query, uint32_t* tau_g, hipStream_t st) {
+                        int splits, uint64_t* part, int lists_per_query, uint32_t* tau_g, uint32_t* gtop,
+                        hipStream_t st) {
     REVO_REQUIRE(D % 64 == 0 && ldq % 8 == 0 && ldg % 8 == 0, "search: D must be a multiple of 64");
     REVO_REQUIRE(N < (1ll << 32), "search: a shard holds at most 2^32 rows");
     REVO_REQUIRE(256l * ldg * 2 < (1l << 31) && 256l * ldq * 2 < (1l << 31), "search: row too long for the DMA window");
@@ -336,7 +411,8 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
                                            S256_LDS));
         done = true;
     }
-    Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, part, lists_per_query, tau_g, g_scan_dbg, (g_scan_dbg & 2) ? topk_scan256_stats() : nullptr};
+    Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, part, lists_per_query, tau_g, g_scan_dbg, gtop,
+                  topk_scan256_top_m(splits), (g_scan_dbg & 2) ? topk_scan256_stats() : nullptr};
     hipLaunchKernelGGL(topk_scan256_kernel, dim3((Q + 255) / 256, splits), dim3(G256_THREADS), S256_LDS, st, a);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;

@@ -32,8 +32,8 @@ for Q in Qs:
     byts = N * D * 2 + Q * D * 2 + Q * k * 12
     if int(os.environ.get("SCAN_DBG", "0")) & 2:
         import ctypes
-        st4 = (ctypes.c_int64 * 4)(); _lib.load().revo_debug_scan_stats(st4)
-        print("scan stats over", iters + 2, "searches: drains", st4[0], "queued", st4[1], "retry passes", st4[2], "slow fragments", st4[3])
+        st4 = (ctypes.c_int64 * 8)(); _lib.load().revo_debug_scan_stats(st4)
+        print("scan stats over", iters + 2, "searches: drains", st4[0], "queued", st4[1], "retry passes", st4[2], "slow fragments", st4[3], "bound improved/not/zero", st4[4], st4[5], st4[6])
     print(json.dumps({"Q": Q, "N": N, "search_ms": round(ms, 4), "scan_ms": round(scan, 4),
                       "scan_TFLOPs": round(flops / scan / 1e9, 1), "scan_frac_mfma": round(flops / scan / 1e9 / 2500, 4),
                       "scan_GBs": round(byts / scan / 1e6, 1), "scan_frac_hbm": round(byts / scan / 1e6 / 8000, 4),
