@@ -27,6 +27,7 @@ def run(M, N, K, epi, tile, iters=20):
     ms = e0.elapsed_time(e1) / iters
     return ms, 2.0 * M * N * K / ms / 1e9
 
+TILES = tuple(int(x) for x in os.environ.get("GEMM_TILES", "128,256").split(","))
 shapes = [(4096, 4096, 4096), (8192, 8192, 8192), (36928, 3072, 1024), (36928, 1024, 1024), (36928, 4096, 1024), (36928, 1024, 4096),
           (36864, 4096, 1024), (36864, 1024, 4096)]
 if len(sys.argv) > 1:
@@ -34,7 +35,7 @@ if len(sys.argv) > 1:
 for (M, N, K) in shapes:
     for epi in (0, 1, 2, 3):
         row = []
-        for tile in (128, 256):
+        for tile in TILES:
             ms, tf = run(M, N, K, epi, tile)
             row.append(f"tile{tile}: {ms:7.3f} ms {tf:7.1f} TF")
         print(f"M={M} N={N} K={K} epi={epi}  " + "   ".join(row), flush=True)
