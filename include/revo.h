@@ -122,6 +122,23 @@ int32_t revo_prof_reset(void);
 /* writes a JSON object {"class": {"launches": n, "ms": t}, ...} into buf */
 int32_t revo_prof_report(char* buf, int32_t capacity);
 
+/* ---- preprocessing: crop + squash-resize on the device ----------
+ * Replaces the host-side  self.preprocess(image_pil.convert("RGB"))  resize of
+ * core_system.py:335 / :439 (transform built at :200) for frames that are already decoded to
+ * uint8 RGB in device memory, and implements the per-region crop the reference leaves as a
+ * placeholder (core_system.py:406 "Use global for now"; crop idea at :687-690).
+ * Bit-identical to PIL's  Image.crop(box).resize((S, S), Image.BILINEAR).
+ * `jobs` is a HOST array; src pointers are device memory, interleaved RGB (H x W x 3).
+ * out: device uint8 [n][3][out_size][out_size], ready for revo_vit_forward(image_dtype = 1).
+ * The call returns after the work has completed on `stream`. */
+typedef struct revo_crop_job {
+    const uint8_t* src;      /* device pointer to the top-left pixel of the source image */
+    int32_t height, width;   /* source image size in pixels */
+    int64_t row_stride;      /* bytes between source rows (>= width * 3) */
+    int32_t x0, y0, x1, y1;  /* crop box, half-open [x0, x1) x [y0, y1); the whole image = 0, 0, width, height */
+} revo_crop_job;
+int32_t revo_preprocess_crop_resize(const revo_crop_job* jobs, int32_t n, int32_t out_size, uint8_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

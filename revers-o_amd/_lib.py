@@ -24,6 +24,12 @@ class Tensor(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
 
 
+class CropJob(C.Structure):
+    """revo_crop_job of include/revo.h."""
+    _fields_ = [("src", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32), ("row_stride", C.c_int64),
+                ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32)]
+
+
 _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); mirrors include/revo.h one to one
@@ -57,6 +63,7 @@ SIGNATURES = {
     "revo_prof_enable": (_i32, [_i32]),
     "revo_prof_reset": (_i32, []),
     "revo_prof_report": (_i32, [C.c_char_p, _i32]),
+    "revo_preprocess_crop_resize": (_i32, [C.POINTER(CropJob), _i32, _i32, _p, _p]),
 }
 
 _lib = None

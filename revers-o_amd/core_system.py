@@ -56,8 +56,16 @@ class SimpleReverso:
     """Simplified visual investigation system (MI355X-native hot path)."""
 
     def __init__(self, model_name=DEFAULT_VARIANT, checkpoint=None, device=0, db_root=DB_ROOT, max_batch=64,
-                 detector=None, decode_workers=8, synthetic_seed=0):
+                 detector=None, decode_workers=8, synthetic_seed=0, region_mode="global", device_resize=False):
         print("🚀 Initializing Simple Revers-o...")
+        if region_mode not in ("global", "crop"):
+            raise ValueError("region_mode must be 'global' (the reference's behaviour, core_system.py:406) or 'crop'")
+        # "crop": every region is cropped to its box on the device and embedded on its own -- the
+        # feature the reference leaves as a placeholder (:406 "Use global for now", :687-690)
+        self.region_mode = region_mode
+        # True: decoded frames are uploaded as they are and squash-resized by the HIP kernel
+        # (same pixels as the host PIL resize, bit for bit); False: PIL resize in the decode pool
+        self.device_resize = bool(device_resize)
         self.db_root = db_root
         self.max_batch = int(max_batch)
         self.detector = detector
@@ -216,21 +224,49 @@ class SimpleReverso:
     def _embed_pils(self, pils):
         """list of PIL images -> fp32 CPU tensor [n, D] (L2-normalised)."""
         size = self.pe_model.cfg.image_size
+        if self.device_resize:
+            frames = [torch.from_numpy(np.array(pp.to_pil(im), dtype=np.uint8)).to(self.device, non_blocking=True)
+                      for im in pils]
+            with self._lock:
+                emb = self.pe_model.embed(pp.crop_resize_device(frames, None, size))
+            return emb.cpu()
         u8 = torch.stack(list(self._decode_pool.map(lambda im: pp.resize_u8(im, size), pils)))
         with self._lock:
             emb = self.pe_model.embed(u8.to(self.device, non_blocking=True))
         return emb.cpu()
 
+    def _embed_regions(self, pil, metas):
+        """One vector per region: the frame goes to the device once, every region's bbox is
+        cropped + squash-resized there (bit-identical to PIL crop().resize()), then one
+        batched forward.  Mask-derived boxes are inclusive (core_system.py:411)."""
+        if not metas:
+            return torch.empty((0, self.pe_model.cfg.out_dim))
+        frame = torch.from_numpy(np.array(pil, dtype=np.uint8)).to(self.device)
+        boxes = []
+        for m in metas:
+            x0, y0, x1, y1 = m["bbox"]
+            if m.get("mask_status") == "processed":
+                x1, y1 = x1 + 1, y1 + 1
+            boxes.append((0,) + pp.clamp_box((x0, y0, x1, y1), pil.width, pil.height))
+        with self._lock:
+            u8 = pp.crop_resize_device(frame, boxes, self.pe_model.cfg.image_size)
+            emb = self.pe_model.embed(u8)
+        return emb.cpu()
+
     def extract_embeddings(self, image):
         """core_system.py:320-429: one forward of the full image, every kept region receives
-        the global embedding (:406) with its own mask-derived metadata."""
+        the global embedding (:406) with its own mask-derived metadata.  With
+        ``region_mode="crop"`` every region is embedded from its own crop instead."""
         if not self.detected_regions or len(self.detected_regions) == 0:
             print("❌ No regions detected")
             return [], []
         pil = pp.to_pil(image)
-        g = self._embed_pils([pil])[0]
         kept, metas = self._region_metadata(pil, self.detected_regions)
-        embeddings = [g.clone() for _ in kept]
+        if self.region_mode == "crop":
+            embeddings = list(self._embed_regions(pil, metas))
+        else:
+            g = self._embed_pils([pil])[0]
+            embeddings = [g.clone() for _ in kept]
         self.region_embeddings = embeddings
         print(f"🎯 Extracted {len(embeddings)} region embeddings")
         return embeddings, metas
@@ -345,13 +381,18 @@ class SimpleReverso:
                             failed += 1
                             continue
                         _, metas = self._region_metadata(im, self.detected_regions)
+                        if self.region_mode == "crop":
+                            region_vecs = self._embed_regions(im, metas)
                         log_status(f"✅ Found {n_reg} regions, extracted {len(metas)} embeddings in {filename}")
                     for m in metas:
                         m["image_source"] = path
                         m["filename"] = filename
                         m["original_region_id"] = m.get("region_id", str(uuid.uuid4()))
                         m["region_id"] = str(uuid.uuid4())
-                    self._partial_embeddings.extend(e.clone() for _ in metas)
+                    if self.region_mode == "crop" and not use_direct_pe:
+                        self._partial_embeddings.extend(v.clone() for v in region_vecs)
+                    else:
+                        self._partial_embeddings.extend(e.clone() for _ in metas)
                     self._partial_metadata.extend(metas)
                     processed += 1
                     self._last_processed_file = path

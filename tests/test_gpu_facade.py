@@ -134,3 +134,62 @@ def test_detector_mode_and_resume(system):
     perm = [ref_names.index(nm) for nm in names]
     assert torch.equal(a, b[perm])
     assert r.create_database(str(root), "empty", use_direct_pe=True).endswith(f"❌ No images found in {root}")
+
+
+def test_region_crop_mode_embeds_each_box(tmp_path, dev):
+    """region_mode="crop" (SURVEY §8(f) row 3): every detector box gets the embedding of its own
+    crop -- equal to embedding PIL's crop().resize() of that box -- and the gallery built from
+    a folder stores one distinct vector per region."""
+    from PIL import Image
+    from reverso_amd import preprocess as pp
+    from reverso_amd.core_system import Regions
+    folder = str(tmp_path / "images")
+    paths = _make_jpegs(folder, n=3, seed=4)
+
+    def detector(pil, prompt):
+        w, h = pil.size
+        masks = np.zeros((2, h, w), dtype=bool)
+        masks[0, 10:h // 2, 5:w // 2] = True
+        masks[1, h // 3:h - 7, w // 4:w - 3] = True
+        return Regions([[5, 10, w // 2, h // 2], [w // 4, h // 3, w - 3, h - 7]], mask=masks, confidence=[0.9, 0.8],
+                       class_id=[0, 1], class_names=["person", "car"])
+
+    r = SimpleReverso(model_name="PE-Tiny-T14-56", db_root=str(tmp_path / "db"), max_batch=8, detector=detector,
+                      region_mode="crop")
+    assert r.detect_regions(paths[0], "person . car") == 2
+    embs, metas = r.extract_embeddings(paths[0])
+    assert len(embs) == 2 and metas[0]["detected_class"] == "person" and metas[1]["detected_class"] == "car"
+    pil = Image.open(paths[0]).convert("RGB")
+    for e, m in zip(embs, metas):
+        x0, y0, x1, y1 = m["bbox"]                         # inclusive, mask derived
+        crop = pil.crop((x0, y0, x1 + 1, y1 + 1))
+        want = r.pe_model.embed(pp.resize_u8(crop, 56)[None].to(dev))[0].cpu()
+        assert torch.equal(e, want)
+    assert not torch.equal(embs[0], embs[1])
+    msg = r.create_database(folder, "regions", text_prompt="person . car")
+    assert "✅" in msg and len(r.vector_db.payloads) == 6
+    g = r.vector_db.gallery.read().cpu()
+    assert torch.unique(g, dim=0).shape[0] == 6
+    # the first region of image 0 finds itself
+    r.detect_regions(paths[0], "person . car")
+    r.extract_embeddings(paths[0])
+    _, items = r.search_similar(0.0, 1)
+    assert items[0]["filename"] == os.path.basename(paths[0]) and items[0]["score"] > 0.9999
+    assert items[0]["bbox"] == metas[0]["bbox"]
+
+
+def test_device_resize_ingest_equals_host_resize(system):
+    """device_resize=True builds the same gallery, bit for bit."""
+    r, folder, paths, root = system
+    assert r.load_database("cfg1").startswith("✅")
+    host = r.vector_db.gallery.read().cpu()
+    host_names = [p["filename"] for p in r.vector_db.payloads]
+    r.device_resize = True
+    try:
+        msg = r.create_database(folder, "devresize", use_direct_pe=True)
+    finally:
+        r.device_resize = False
+    assert "✅" in msg
+    names = [p["filename"] for p in r.vector_db.payloads]
+    perm = [host_names.index(nm) for nm in names]
+    assert torch.equal(r.vector_db.gallery.read().cpu(), host[perm])

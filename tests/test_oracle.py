@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 import reverso_amd
@@ -119,3 +120,31 @@ def test_layernorm_and_softmax_known_answers():
     e = torch.randn(5, 16)
     n = pe_vit.l2_normalize(e)
     torch.testing.assert_close(n.norm(dim=-1), torch.ones(5))
+
+
+# ---- resize oracle pinned to Pillow (the library the reference's preprocess calls) ----------
+@pytest.mark.parametrize("h,w,size,box", [(480, 640, 336, None), (100, 50, 56, None), (56, 56, 56, None),
+                                          (37, 41, 224, None), (500, 333, 56, (10, 20, 200, 300)),
+                                          (64, 64, 56, (5, 7, 6, 8)), (720, 1280, 224, (100, 50, 1100, 700)),
+                                          (33, 77, 336, (3, 2, 70, 31)), (57, 3, 56, None)])
+def test_resize_oracle_matches_pillow(h, w, size, box):
+    from PIL import Image
+    from oracle import resize as R
+    rng = np.random.default_rng(h * 1000 + w)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    pil = Image.fromarray(img)
+    if box is not None:
+        pil = pil.crop(box)
+    want = np.asarray(pil.resize((size, size), Image.BILINEAR))
+    got = R.crop_resize_u8(img, size, box)
+    assert np.array_equal(got, want)
+
+
+def test_resize_oracle_matches_product_host_resize():
+    """preprocess.resize_u8 (host PIL path of the facade) == oracle, CHW vs HWC."""
+    from oracle import resize as R
+    from reverso_amd import preprocess
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (123, 211, 3), dtype=np.uint8)
+    chw = preprocess.resize_u8(img, 56).numpy()
+    assert np.array_equal(chw.transpose(1, 2, 0), R.crop_resize_u8(img, 56))
