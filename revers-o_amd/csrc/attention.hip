@@ -46,7 +46,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
     constexpr int TILE = 64 * ROWB;      // 8 or 16 KB
     constexpr int NCHUNK = 128 * CH;     // chunks per key tile: K ids [0, 64*CH), V ids [64*CH, 128*CH)
     constexpr int NMOVE = (NCHUNK + NT - 1) / NT;
-    constexpr float DEFER = 6.0f;        // skip the O rescale while the running max grows by < 2^6 (T13)
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE];   // K0 K1 V0 V1
 
     const int tid = threadIdx.x;
@@ -163,61 +162,81 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
         if (wave_active) {
             const char* base = lds + buf * TILE;
             f32x16 sacc[2];
-#pragma unroll
-            for (int kblk = 0; kblk < 2; ++kblk) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sacc[kblk][i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8 a = *(const bf16x8*)(base + kaddr[ks] + kblk * 32 * ROWB);
-                    sacc[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], sacc[kblk], 0, 0, 0);
-                }
-            }
-            if (t == nt - 1 && (nkeys & 63)) {
+            // S^T = K . Q^T for the 64 keys of the tile, masked past the last key
+#define ATT_SCORES()                                                                                 \
+    do {                                                                                             \
+        _Pragma("unroll") for (int kblk = 0; kblk < 2; ++kblk) {                                     \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) sacc[kblk][i] = 0.f;                      \
+            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                      \
+                const bf16x8 a_ = *(const bf16x8*)(base + kaddr[ks] + kblk * 32 * ROWB);             \
+                sacc[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, qf[ks], sacc[kblk], 0, 0, 0); \
+            }                                                                                        \
+        }                                                                                            \
+        if (t == nt - 1 && (nkeys & 63)) {                                                           \
+            asm volatile("" ::: "memory"); /* a real branch: if-converted, this is 32 selects per key tile */ \
+            _Pragma("unroll") for (int kblk = 0; kblk < 2; ++kblk)                                   \
+                _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                     \
+                    const int key_ = t * 64 + kblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;           \
+                    if (key_ >= nkeys) sacc[kblk][i] = -INFINITY;                                    \
+                }                                                                                    \
+        }                                                                                            \
+    } while (0)
+            ATT_SCORES();
+            // Optimistic softmax.  p = 2^(s c - m) is computed against the running reference m on
+            // register pairs (v_pk_fma_f32 / v_pk_add_f32 / v_cvt_pk_bf16_f32) WITHOUT first taking the
+            // tile maximum: the softmax VALU work, not the MFMAs, bounds this kernel at head_dim 64.
+            // fp32 and bf16 share the exponent range, so a reference that lags the true maximum by up
+            // to 2^80 loses no precision; only when a row sum leaves that range (or m is still -inf)
+            // does the wave take the maximum, move the reference, rescale and redo the exponentials.
+            uint32_t pw[2][8];
+            f32x2 ps2;
+#define ATT_EXPS()                                                                               \
+    do {                                                                                         \
+        const f32x2 c2_ = {c, c}, m2_ = {m_run, m_run};                                          \
+        ps2 = (f32x2){0.f, 0.f};                                                                 \
+        _Pragma("unroll") for (int kblk = 0; kblk < 2; ++kblk)                                   \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                      \
+                const f32x2 sv_ = {sacc[kblk][2 * j], sacc[kblk][2 * j + 1]};                    \
+                const f32x2 e_ = sv_ * c2_ - m2_;                                                \
+                const f32x2 pv_ = {__builtin_amdgcn_exp2f(e_.x), __builtin_amdgcn_exp2f(e_.y)};  \
+                ps2 += pv_;                                                                      \
+                pw[kblk][j] = pack_bf16x2(pv_.x, pv_.y);                                         \
+            }                                                                                    \
+    } while (0)
+            ATT_EXPS();
+            float ps = ps2.x + ps2.y;
+            if (!__all(ps < 0x1p80f)) {
+                asm volatile("" ::: "memory");
+                ATT_SCORES();       // rare path: the scores were consumed in place, compute them again
+                float mx = -INFINITY;
 #pragma unroll
                 for (int kblk = 0; kblk < 2; ++kblk)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = t * 64 + kblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                        if (key >= nkeys) sacc[kblk][i] = -INFINITY;
-                    }
-            }
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kblk = 0; kblk < 2; ++kblk)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kblk][i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
-            if (!__all(mx <= m_run + DEFER)) {
-                // the running max moved by more than the deferral window somewhere in the wave: rescale
+                    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kblk][i]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
                 const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 when m_run was -inf
                 m_run = m_new;
                 l_run *= alpha;
 #pragma unroll
                 for (int d = 0; d < DB; ++d)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+                ATT_EXPS();
+                ps = ps2.x + ps2.y;
             }
-            float ps = 0.f;
-#pragma unroll
-            for (int kblk = 0; kblk < 2; ++kblk)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kblk][i], c, -m_run));
-                    sacc[kblk][i] = p;
-                    ps += p;
-                }
+#undef ATT_EXPS
+#undef ATT_SCORES
             l_run += ps;
 #pragma unroll
             for (int kblk = 0; kblk < 2; ++kblk) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     uint4 pk;
-                    pk.x = pack_bf16x2(sacc[kblk][8 * s2 + 0], sacc[kblk][8 * s2 + 1]);
-                    pk.y = pack_bf16x2(sacc[kblk][8 * s2 + 2], sacc[kblk][8 * s2 + 3]);
-                    pk.z = pack_bf16x2(sacc[kblk][8 * s2 + 4], sacc[kblk][8 * s2 + 5]);
-                    pk.w = pack_bf16x2(sacc[kblk][8 * s2 + 6], sacc[kblk][8 * s2 + 7]);
+                    pk.x = pw[kblk][4 * s2 + 0];
+                    pk.y = pw[kblk][4 * s2 + 1];
+                    pk.z = pw[kblk][4 * s2 + 2];
+                    pk.w = pw[kblk][4 * s2 + 3];
                     const bf16x8 pb = __builtin_bit_cast(bf16x8, pk);
                     // k index (h, j) of this step is key 16*s2 + 8*(j>>2) + 4*h + (j&3) of the block
 #pragma unroll
@@ -252,6 +271,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
 #undef ATT_LOAD_TILE
 #undef ATT_STORE_TILE
 }
+
 
 template <int HD, int NW>
 static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, float c, int q_rot,

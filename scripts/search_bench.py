@@ -9,7 +9,7 @@ from reverso_amd import _lib
 _lib.load().revo_op_set_gemm_debug(int(os.environ.get("SCAN_DBG", "0")) << 13)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 Qs = [int(a) for a in sys.argv[2:]] or [1, 64, 256, 10000]
-D, k = 1024, 10
+D, k = 1024, int(os.environ.get("TOPK", "10"))
 G = engine.Gallery(D, N, device=0)
 g = torch.Generator(device=dev).manual_seed(42)
 for s in range(0, N, 131072):

@@ -185,3 +185,28 @@ def test_attention_peaked_softmax(lib, dev):
     att = torch.softmax(xf[:, 0] @ xf[:, 1].T * hd ** -0.5, dim=-1)
     ref = att @ xf[:, 2]
     assert (out.float() - ref).abs().max().item() <= 0.03
+
+
+@pytest.mark.parametrize("S,hd,scale", [(577, 64, 8.0), (260, 64, 12.0), (257, 96, 8.0), (577, 64, 30.0)])
+def test_attention_huge_logits(lib, dev, S, hd, scale):
+    """Scores spread over hundreds of octaves (|s| up to ~scale^2 * 8): the optimistic softmax's
+    reference must be moved (overflow guard) and rows whose early keys are far below the final
+    maximum must still come out exact.  Compared with an fp64 softmax."""
+    B, H = 2, 2
+    W = H * hd
+    g = torch.Generator(device="cpu").manual_seed(S + hd)
+    qkv = torch.randn(B * S, 3 * W, generator=g)
+    qkv[:, : 2 * W] *= scale
+    # ascending scores along the key axis for the first head: the maximum keeps moving
+    qkv[:, W:W + hd] += torch.linspace(0, scale, B * S)[:, None] * torch.sign(qkv[0, :hd])[None]
+    qkv = qkv.to(dev).bfloat16()
+    out = torch.full((B * S, W), float("nan"), device=dev, dtype=torch.bfloat16)
+    _lib.check(lib.revo_op_attention(_lib.ptr(qkv), 3 * W, _lib.ptr(out), W, B, S, H, hd, _lib.current_stream()))
+    torch.cuda.synchronize()
+    x = qkv.double().reshape(B, S, 3, H, hd)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    att = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1)
+    ref = (att @ v).transpose(1, 2).reshape(B * S, W)
+    assert torch.isfinite(out.float()).all()
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 0.04, err
