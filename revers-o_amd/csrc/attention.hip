@@ -22,6 +22,18 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* lo, const char* hi) {
     return __builtin_bit_cast(bf16x8, c);
 }
 
+// LDS-DMA helpers (plain device functions: called straight from the body of a __global__ template,
+// these target builtins make hipcc 7.2 drop the kernel's host stub).
+struct AttDmaSrc {
+    __amdgpu_buffer_rsrc_t rsrc;
+};
+__device__ __forceinline__ void att_dma_init(AttDmaSrc& src, const void* base, int bytes) {
+    src.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void att_dma_issue(const AttDmaSrc& src, char* dst, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
+}
+
 // Body attention.  NW waves per workgroup, 32 query rows per wave.  Key rows [k_lo, S) are
 // tiled; when k_lo == 1 the class-token key (row 0) is folded in as a rank-1 prelude
 // (m = s_cls, l = 1, O = v_cls) so that L14's 576 patch keys are exactly 9 unmasked tiles.
@@ -33,7 +45,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
                                                           bf16_t* __restrict__ out, long ldo, int S, int H, float c,
                                                           int q_rot, int k_lo) {
     static_assert(HD == 64 || HD == 96, "body attention kernel is built for head_dim 64 (B16, L14) and 96 (G14)");
-    constexpr int NT = NW * 64;
     constexpr int KS = HD / 16;          // k-steps over d for S^T
     constexpr int DB = HD / 32;          // 32-wide d blocks of O^T
     constexpr int CH = HD / 8;           // 16-byte data chunks per K/V row (8 or 12)
@@ -43,13 +54,18 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
     //   128-B rows: K chunk ^= (key>>1)&7,  V chunk ^= ((key>>1)&1)<<2
     //   256-B rows: K chunk ^= key&15,      V chunk ^= (key&3)<<2
     constexpr int ROWB = HD == 64 ? 128 : 256;
-    constexpr int TILE = 64 * ROWB;      // 8 or 16 KB
-    constexpr int NCHUNK = 128 * CH;     // chunks per key tile: K ids [0, 64*CH), V ids [64*CH, 128*CH)
-    constexpr int NMOVE = (NCHUNK + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) char lds[4 * TILE];   // K0 K1 V0 V1
+    constexpr int TILE = 64 * ROWB;      // one operand of one key tile: 8 or 16 KB
+    constexpr int BUF = 2 * TILE;        // K then V
+    constexpr int NBUF = HD == 64 ? 3 : 2;   // ring depth: 48 KiB (hd 64) / 64 KiB (hd 96) per workgroup
+    constexpr int NI = BUF / 1024;       // DMA wave-instructions per tile (1 KiB each)
+    constexpr int NPW = (NI + NW - 1) / NW;   // per wave per tile; when NW does not divide NI the surplus
+    constexpr int NDUMMY = NPW * NW - NI;     // instructions read out of bounds (zeros) into a spare KiB each
+    constexpr int LPR = ROWB / 16;       // 16-byte chunks per LDS row
+    constexpr int RPI = 64 / LPR;        // rows per DMA instruction
+    __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF + NDUMMY * 1024];
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
     const int b = blockIdx.y / H, h = blockIdx.y - b * H;
     const int W = H * HD;
@@ -71,36 +87,44 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
     }
 
-    // ---- staging: chunk id = tid + NT*i; the first 64*CH ids are K chunks, the rest V chunks
-    int st_goff[NMOVE];      // element offset inside a tile-relative row block: key*ld + ch*8 (+ K/V base)
-    int st_loff[NMOVE];      // LDS byte offset inside the (K0 K1 V0 V1) image for buffer 0
-    int st_key[NMOVE];
+    // ---- K/V tiles go global -> LDS by LDS-DMA (buffer_load ... lds): no staging registers, no
+    // address arithmetic and no ds_write in the key loop.  Tile u lives in ring buffer u % NBUF as
+    // [64 K rows | 64 V rows]; a DMA instruction fills 1 KiB (RPI rows), lane = 16-byte chunk, the
+    // swizzle is applied on the source side.  Rows past the last key read as zeros through the
+    // bounds-checked descriptor (one per image and head, starting at key k_lo's K row).
+    const int nkeys = S - k_lo;
+    const int nt = (nkeys + 63) / 64;
+    AttDmaSrc dma_src;
+    att_dma_init(dma_src, kg + (rowbase + k_lo) * ld, (int)(((long)(nkeys - 1) * ld + W + HD) * 2));
+    uint32_t dma_voff[NPW];
 #pragma unroll
-    for (int i = 0; i < NMOVE; ++i) {
-        const int id = tid + NT * i;
-        const int isv = id >= 64 * CH, rem = id - isv * 64 * CH;
-        const int key = rem / CH, ch = rem - key * CH;
-        st_key[i] = key;
-        st_goff[i] = ch * 8 + (isv ? 2 * W : W) + h * HD;
+    for (int i = 0; i < NPW; ++i) {
+        const int j = wave + NW * i;                       // 1-KiB block of the (K | V) image
+        const int row = j * RPI + lane / LPR;              // 0..127
+        const int cp = lane % LPR;
+        const int isv = row >= 64, key = row & 63;
         const int swz = HD == 64 ? (isv ? (((key >> 1) & 1) << 2) : ((key >> 1) & 7))
                                  : (isv ? ((key & 3) << 2) : (key & 15));
-        st_loff[i] = isv * 2 * TILE + key * ROWB + ((ch ^ swz) << 4);
+        const int ch = cp ^ swz;
+        dma_voff[i] = (ch < CH && j < NI) ? (uint32_t)(((long)key * ld + (isv ? W : 0)) * 2 + ch * 16) : 0x80000000u;
     }
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    u32x4 st_reg[NMOVE];
-#define ATT_LOAD_TILE(t)                                                                  \
-    _Pragma("unroll") for (int i = 0; i < NMOVE; ++i) {                                   \
-        if (NT * i + NT <= NCHUNK || tid + NT * i < NCHUNK) {                             \
-            int key = k_lo + (t) * 64 + st_key[i];                                        \
-            key = key < S ? key : S - 1;                                                  \
-            st_reg[i] = *(const u32x4*)(qkv + (rowbase + key) * ld + st_goff[i]);         \
-        }                                                                                 \
-    }
-#define ATT_STORE_TILE(buf)                                                               \
-    _Pragma("unroll") for (int i = 0; i < NMOVE; ++i) {                                   \
-        if (NT * i + NT <= NCHUNK || tid + NT * i < NCHUNK)                               \
-            *(u32x4*)(lds + (buf) * TILE + st_loff[i]) = st_reg[i];                       \
-    }
+    const uint32_t tile_bytes = (uint32_t)(64 * ld * 2);
+#define ATT_ISSUE_TILE(t)                                                                       \
+    do {                                                                                        \
+        char* dst_ = lds + ((t) % NBUF) * BUF + wave * 1024;                                    \
+        _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                       \
+            char* d_ = (NDUMMY == 0 || wave + NW * i < NI) ? dst_ + i * NW * 1024               \
+                                                           : lds + NBUF * BUF + (wave + NW * i - NI) * 1024; \
+            att_dma_issue(dma_src, d_, dma_voff[i], (uint32_t)(t) * tile_bytes);                \
+        }                                                                                       \
+    } while (0)
+    // wait until tile u has landed, given that tiles up to min(u + NBUF - 2, nt - 1) have been requested
+#define ATT_WAIT_TILE(u)                                                                                  \
+    do {                                                                                                  \
+        const int inflight_ = ((u) + NBUF - 2 < nt ? NBUF - 2 : nt - 1 - (u));                             \
+        if (inflight_ >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");                    \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+    } while (0)
 
     // ---- per-lane LDS fragment addresses (buffer 0), swizzles resolved once
     int kaddr[KS], vaddr[DB];
@@ -114,7 +138,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
         const int sv = HD == 64 ? ((tq >> 1) & 1) : tq;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
-            vaddr[d] = 2 * TILE + (4 * hh + tq) * ROWB + ((((d ^ sv) * 4 + (g16 & 1) * 2 + (tp >> 1))) << 4) + (tp & 1) * 8;
+            vaddr[d] = TILE + (4 * hh + tq) * ROWB + ((((d ^ sv) * 4 + (g16 & 1) * 2 + (tp >> 1))) << 4) + (tp & 1) * 8;
     }
 
     f32x16 oacc[DB];
@@ -124,9 +148,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
 
-    const int nkeys = S - k_lo;
-    const int nt = (nkeys + 63) / 64;
-    if (nt > 0) ATT_LOAD_TILE(0);
+    // ring discipline: tiles 0 .. NBUF-2 are requested here; the iteration that starts tile t requests
+    // tile t + NBUF - 1 behind its barrier, i.e. once every wave is done with tile t-1 (same buffer)
+#pragma unroll
+    for (int u = 0; u < NBUF - 1; ++u)
+        if (u < nt) ATT_ISSUE_TILE(u);
 
     if (k_lo == 1 && wave_active) {
         // rank-1 prelude with key row 0: this lane holds q[d] for d = 16*ks + 8*hh + j
@@ -153,14 +179,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
                 for (int j = 0; j < 4; ++j) oacc[d][4 * g + j] = bf16_to_f32((bf16_t)vv[j]);
             }
     }
-    if (nt > 0) ATT_STORE_TILE(0);
-    __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) ATT_LOAD_TILE(t + 1);
+        ATT_WAIT_TILE(t);
+        __builtin_amdgcn_s_barrier();           // tile t is in LDS for every wave; every wave is done with tile t-1
+        if (t + NBUF - 1 < nt) ATT_ISSUE_TILE(t + NBUF - 1);
         if (wave_active) {
-            const char* base = lds + buf * TILE;
+            const char* base = lds + (t % NBUF) * BUF;
             f32x16 sacc[2];
             // S^T = K . Q^T for the 64 keys of the tile, masked past the last key
 #define ATT_SCORES()                                                                                 \
@@ -248,8 +273,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
                 }
             }
         }
-        if (t + 1 < nt) ATT_STORE_TILE(buf ^ 1);
-        __syncthreads();
     }
 
     if (wave_active) {
@@ -268,8 +291,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
                 }
         }
     }
-#undef ATT_LOAD_TILE
-#undef ATT_STORE_TILE
+#undef ATT_ISSUE_TILE
+#undef ATT_WAIT_TILE
 }
 
 
