@@ -9,21 +9,32 @@
 
 namespace revo {
 
-// erf to ~1.5e-7 absolute (Abramowitz-Stegun 7.1.26): the result feeds a bf16
-// store (2^-9 relative), so this is "exact" GELU at the output precision.
-__device__ __forceinline__ float erf_fast(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    p *= t;
-    const float e = __expf(-ax * ax);
-    const float r = fmaf(-p, e, 1.0f);
-    return copysignf(r, x);
+// Exact-erf GELU on register pairs.  erf(z) = 1 - 1/(1 + a1 z + ... + a6 z^6)^16 for z >= 0
+// (Abramowitz-Stegun 7.1.28, |eps| <= 3e-7; ~2e-6 once the 16th power is taken in fp32): one
+// reciprocal and no exponential per element, everything else on the packed fp32 pipe
+// (v_pk_fma_f32 / v_pk_mul_f32), about half the VALU issue slots of the 7.1.26 form.  The result
+// feeds a bf16 store (2^-9 relative), three orders of magnitude coarser than the approximation.
+//   gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) = 0.5 (x + |x| (1 - r)),   r = 1 / poly(|x| / sqrt 2)^16
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
+    const f32x2 z = ax * 0.70710678118654752f;
+    f32x2 p = z * 0.0000430638f + 0.0002765672f;
+    p = p * z + 0.0001520143f;
+    p = p * z + 0.0092705272f;
+    p = p * z + 0.0422820123f;
+    p = p * z + 0.0705230784f;
+    p = p * z + 1.0f;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    const f32x2 r = {__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};   // rcp(inf) = 0 for large |x|
+    return (x + ax * (1.0f - r)) * 0.5f;
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+__device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
+    const f32x2 lo = gelu_erf2((f32x2){v[0], v[1]}), hi = gelu_erf2((f32x2){v[2], v[3]});
+    return (f32x4){lo.x, lo.y, hi.x, hi.y};
+}
 
 template <int EPI, int MF, int NF>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int m_base, int n_base, int lane,
@@ -50,10 +61,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int m_base, int
                 v += b;
             }
             if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
-                if (EPI == EPI_BF16_GELU) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-                }
+                if (EPI == EPI_BF16_GELU) v = gelu_erf4(v);
                 uint2 o;
                 o.x = pack_bf16x2(v[0], v[1]);
                 o.y = pack_bf16x2(v[2], v[3]);
@@ -146,10 +154,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* smem, 
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     f32x4 v = acc[half * 4 + m][n] + bias4[n];
-                    if (EPI == EPI_BF16_GELU) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-                    }
+                    if (EPI == EPI_BF16_GELU) v = gelu_erf4(v);
                     uint2 o;
                     o.x = pack_bf16x2(v[0], v[1]);
                     o.y = pack_bf16x2(v[2], v[3]);
