@@ -44,7 +44,7 @@ extern "C" int32_t revo_sync(void* stream) {
 namespace {
 struct ProfRec { std::string cls; hipEvent_t a, b; };
 struct Profiler {
-    bool on = false;
+    int on = 0;      // 0 off, 1 every kernel class, 2 only the body GEMMs (gemm_qkv / out / fc1 / fc2)
     std::mutex mu;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
@@ -68,7 +68,9 @@ struct Profiler {
 
 struct ProfScope {
     bool active; hipStream_t st; ProfRec rec;
-    ProfScope(const char* cls, hipStream_t s) : active(g_prof.on), st(s) {
+    ProfScope(const char* cls, hipStream_t s) : active(g_prof.on != 0), st(s) {
+        if (active && g_prof.on == 2)
+            active = !strcmp(cls, "gemm_qkv") || !strcmp(cls, "gemm_out") || !strcmp(cls, "gemm_fc1") || !strcmp(cls, "gemm_fc2");
         if (!active) return;
         std::lock_guard<std::mutex> lk(g_prof.mu);
         rec.cls = cls; rec.a = g_prof.get(); rec.b = g_prof.get();
@@ -83,7 +85,7 @@ struct ProfScope {
 };
 }  // namespace
 
-extern "C" int32_t revo_prof_enable(int32_t on) { g_prof.on = on != 0; return 0; }
+extern "C" int32_t revo_prof_enable(int32_t on) { g_prof.on = on < 0 ? 0 : (on > 2 ? 1 : on); return 0; }
 extern "C" int32_t revo_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.drain();
