@@ -283,6 +283,58 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256_kernel(GemmArgs p) {
     }
 }
 
+
+// Skinny GEMM for M <= 64 (the attention-pool head at batch <= 64: four layers whose time is the
+// streaming of 2-8 MB of weights).  The tiled kernels give such a problem N/128 workgroups and a
+// serial K loop; here a workgroup owns 16 output columns, its 4 waves split K, operands go
+// global -> registers in MFMA fragment layout with eight k-steps of loads in flight, and the
+// partial accumulators meet in LDS.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
+    __shared__ f32x4 red[3][4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kw = p.K >> 2;                       // this wave's K range
+    const int nrow = n0 + lr < p.N ? n0 + lr : p.N - 1;
+    const bf16_t* bp = p.B + (long)nrow * p.ldb + wave * kw + lq * 8;
+    const bf16_t* ap[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int row = m * 16 + lr < p.M ? m * 16 + lr : p.M - 1;
+        ap[m] = p.A + (long)row * p.lda + wave * kw + lq * 8;
+    }
+    f32x4 acc[4][1];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < kw; k += 64) {             // kw % 64 == 0 (launcher checks K % 256 == 0)
+        bf16x8 b[2], a[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            b[u] = *(const bf16x8*)(bp + k + u * 32);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[u][m] = *(const bf16x8*)(ap[m] + k + u * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u], a[u][m], acc[m][0], 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) red[wave - 1][m][lane] = acc[m][0];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m][0] += red[w][m][lane];
+        gemm_epilogue<EPI, 4, 1>(p, 0, n0, lane, acc);
+    }
+}
+
 static const char* check_args(const GemmArgs& a) {
     if (a.K <= 0 || a.K % GEMM_BK) return "gemm: K must be a positive multiple of 64";
     if (a.N % 4) return "gemm: N must be a multiple of 4";
@@ -353,8 +405,19 @@ static int launch_128(const GemmArgs& a, hipStream_t st);
 static int g_tail_split = 1;   // timing experiments only: 0 disables the tail split below
 void gemm_set_tail_split(int on) { g_tail_split = on; }
 
+static bool use_skinny(const GemmArgs& a) { return g_force_tile == 0 && a.M <= 64 && a.K % 256 == 0 && a.N >= 256; }
+template <int EPI>
+static int launch_skinny(const GemmArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(gemm_skinny_kernel<EPI>, dim3((a.N + 15) / 16), dim3(256), 0, st, a);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <int EPI>
 static int launch_t(const GemmArgs& a, hipStream_t st) {
+    if constexpr (EPI != EPI_PATCH && EPI != EPI_BF16_ROPE) {
+        if (use_skinny(a)) return launch_skinny<EPI>(a, st);
+    }
     if (use_256(a)) {
         // Tail split.  The 256 x 256 kernel runs one workgroup per CU, so its tiles go in rounds of
         // 256; a last round that is mostly empty costs a full tile time (PE-L14 at batch 64: out-proj

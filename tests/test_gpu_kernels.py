@@ -210,3 +210,33 @@ def test_attention_huge_logits(lib, dev, S, hd, scale):
     assert torch.isfinite(out.float()).all()
     err = (out.double() - ref).abs().max().item()
     assert err <= 0.04, err
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 1024, 1024), (64, 4096, 1024), (64, 1024, 4096), (1, 256, 256), (7, 260, 512),
+                                   (33, 1000, 768), (64, 1024, 1280)])
+def test_gemm_skinny_all_epilogues(lib, dev, gemm_tile, M, N, K):
+    """M <= 64 with the tile heuristic in charge (tile 0) goes to the skinny kernel: all four
+    epilogues against an fp32 reference.  Runs once (not per forced tile)."""
+    if gemm_tile != 128:
+        pytest.skip("heuristic path: one run is enough")
+    _lib.check(lib.revo_op_set_gemm_tile(0))
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    b = (torch.randn(N, K, generator=g) * 0.1).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    gamma = torch.rand(N, generator=g).to(dev) + 0.5
+    ref = a.float() @ b.float().T + bias
+    tol = 3e-3 * math.sqrt(K / 64)
+    c = torch.full((M, N), float("nan"), device=dev)
+    _gemm(lib, EPI_F32, a, b, c, bias)
+    assert (c - ref).abs().max().item() <= tol
+    cb = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
+    _gemm(lib, EPI_BF16, a, b, cb, bias)
+    assert (cb.float() - ref).abs().max().item() <= tol + 0.02 * ref.abs().max().item()
+    _gemm(lib, EPI_BF16_GELU, a, b, cb, bias)
+    gref = torch.nn.functional.gelu(ref)
+    assert (cb.float() - gref).abs().max().item() <= tol + 0.02 * gref.abs().max().item()
+    x0 = torch.randn(M, N, generator=g).to(dev)
+    x = x0.clone()
+    _gemm(lib, EPI_RESID_F32, a, b, x, bias, gamma)
+    assert (x - (x0 + gamma * ref)).abs().max().item() <= 2 * tol
