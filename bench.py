@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=6)
     ap.add_argument("--dual-stream", type=int, default=0, help="1: embed as two half batches on two HIP streams")
+    ap.add_argument("--debug-flags", type=int, default=0, help="A/B experiments: revo_op_set_gemm_debug flags (0 = product path)")
     ap.add_argument("--search-queries", type=int, default=10000,
                     help="extra, untimed-by-the-headline measurement: a batch of this many queries against the local "
                          "gallery shard (BASELINE.json configs[3]); 0 disables it")
@@ -106,6 +107,9 @@ def main():
     B = args.batch
     eng = engine.VitEngine.synthetic(cfg, seed=0, device=local_rank, max_batch=B)
     eng.set_dual_stream(bool(args.dual_stream))
+    if args.debug_flags:
+        from reverso_amd import _lib
+        _lib.check(_lib.load().revo_op_set_gemm_debug(args.debug_flags))
 
     # synthetic gallery shard, generated on the device (seed 42 + rank), rows normalised at insert
     shard_rows = args.gallery // world + (1 if rank < args.gallery % world else 0)

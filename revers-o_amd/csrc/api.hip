@@ -714,6 +714,7 @@ extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
     revo::attention_force_nw((flags >> 8) & 15);
     revo::gemm_set_tail_split(((flags >> 12) & 1) ? 0 : 1);
     revo::topk_scan256_set_debug((flags >> 13) & 7);
+    revo::gemm_set_persistent(((flags >> 16) & 1) ? 0 : 1);
     return 0;
 }
 extern "C" int32_t revo_debug_scan_stats(int64_t* out4) {

@@ -126,15 +126,14 @@ __device__ __forceinline__ void gemm256_epilogue_f32_quarter(const GemmArgs& p, 
 // 16 bytes per lane.  Bias, GELU and LayerScale are applied before the transpose, the
 // residual add after it (on the coalesced rows).
 template <int EPI>
-__device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* smem, int m_base, int n_base, int wave,
-                                                 int lane, f32x4 (&acc)[8][4]) {
+__device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, int m_base, int n_base, int lane,
+                                                 f32x4 (&acc)[8][4]) {
     static_assert(EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_F32 || EPI == EPI_RESID_F32 ||
                   EPI == EPI_BF16_ROPE, "");
     // The main loop runs at the 256-VGPR limit: keep every epilogue value from being
     // computed (or loaded) ahead of it by making the lane id opaque here.
     asm volatile("" : "+v"(lane) :: "memory");
     const int lq = lane >> 4;
-    char* slab = smem + wave * 16384;
     f32x4 bias4[4], gamma4[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -277,12 +276,83 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256_kernel(GemmArgs p) {
         // (a runtime condition for every variant: with the direct epilogue compiled out, hipcc 7.2
         //  allocates the fp32 variants' main loop so badly that the accumulators spill)
         const bool wide = (p.N & 7) == 0 && (p.ldc & 7) == 0;
-        if (wide) gemm256_epilogue<EPI>(p, smem, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, wave, lane, acc);
+        if (wide) gemm256_epilogue<EPI>(p, smem + wave * 16384, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, lane, acc);
         else gemm_epilogue<EPI == EPI_BF16_ROPE ? EPI_BF16 : EPI, 8, 4>(p, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64,
                                                                          lane, acc);
     }
 }
 
+
+// Persistent form of the 256 x 256 kernel: one workgroup per CU walks its share of the XCD's tile
+// region.  The DMA for the next tile's first K-tile is issued BEFORE the epilogue of the current
+// one, so the pipeline fill (and the launch of a fresh workgroup) no longer sits between a tile's
+// last store and the next tile's first MFMA.  LDS while an epilogue runs: A stage 0 and B stage 0
+// are being filled; the wave-private transpose slabs live in A stage 1 (waves 0-2) and in B stage
+// 1 plus the 32 KiB above the main-loop image (waves 3-7).
+constexpr int G256P_LDS = 163840;
+template <int EPI>
+__global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, int nslot) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = (p.N + 255) / 256;
+    const int tiles_m = (p.M + 255) / 256;
+    const int gy = p.gy, gx = 8 / gy;
+    const int xcd = blockIdx.x & 7;
+    const int xi = xcd / gy, xj = xcd - xi * gy;
+    const int pm = (tiles_m + gx - 1) / gx, pn = (tiles_n + gy - 1) / gy;
+    const int m_lo = xi * pm, n_lo = xj * pn;
+    const int m_cnt = (tiles_m - m_lo) < pm ? (tiles_m - m_lo) : pm;
+    const int n_cnt = (tiles_n - n_lo) < pn ? (tiles_n - n_lo) : pn;
+    const int total = (m_cnt > 0 && n_cnt > 0) ? m_cnt * n_cnt : 0;
+    int slot = blockIdx.x >> 3;
+    if (slot >= total) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    char* slab = smem + (wave < 3 ? 32768 + wave * 9216 : 98304 + (wave - 3) * 9216);
+
+    int m0 = (m_lo + slot / n_cnt) * 256, n0 = (n_lo + slot % n_cnt) * 256;
+    G256Operand A, B;
+    g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane);
+    g256_operand_init(B, p.B, p.ldb, p.N, n0, wave, lane);
+    g256_issue_half(A, 0, 0, G256_A(smem, 0), wave);
+    g256_issue_half(A, 1, 0, G256_A(smem, 0), wave);
+    g256_issue_half(B, 0, 0, G256_B(smem, 0), wave);
+    g256_issue_half(B, 1, 0, G256_B(smem, 0), wave);
+    for (;;) {
+        if (p.K > 64) {
+            g256_issue_half(A, 0, 128, G256_A(smem, 1), wave);
+            g256_issue_half(A, 1, 128, G256_A(smem, 1), wave);
+        }
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gemm256_mainloop(A, B, smem, p.K, wave, lane, acc);
+
+        const int mb = m0 + (wave >> 2) * 128, nb = n0 + (wave & 3) * 64;
+        slot += nslot;
+        const bool more = slot < total;
+        if (more) {
+            m0 = (m_lo + slot / n_cnt) * 256;
+            n0 = (n_lo + slot % n_cnt) * 256;
+            g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane);
+            g256_operand_init(B, p.B, p.ldb, p.N, n0, wave, lane);
+            g256_issue_half(A, 0, 0, G256_A(smem, 0), wave);
+            g256_issue_half(A, 1, 0, G256_A(smem, 0), wave);
+            g256_issue_half(B, 0, 0, G256_B(smem, 0), wave);
+            g256_issue_half(B, 1, 0, G256_B(smem, 0), wave);
+        }
+        if constexpr (EPI == EPI_PATCH) {
+            gemm_epilogue<EPI, 8, 4>(p, mb, nb, lane, acc);
+        } else {
+            const bool wide = (p.N & 7) == 0 && (p.ldc & 7) == 0;
+            if (wide) gemm256_epilogue<EPI>(p, slab, mb, nb, lane, acc);
+            else gemm_epilogue<EPI == EPI_BF16_ROPE ? EPI_BF16 : EPI, 8, 4>(p, mb, nb, lane, acc);
+        }
+        if (!more) break;
+        __builtin_amdgcn_s_barrier();      // every wave is out of its slab before A stage 1 is refilled
+    }
+}
 
 // Skinny GEMM for M <= 64 (the attention-pool head at batch <= 64: four layers whose time is the
 // streaming of 2-8 MB of weights).  The tiled kernels give such a problem N/128 workgroups and a
@@ -369,6 +439,29 @@ static int launch_256d(const GemmArgs& a, hipStream_t st) {
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+static int g_persistent = 1;   // timing experiments only: 0 = one workgroup per tile
+void gemm_set_persistent(int on) { g_persistent = on; }
+template <int EPI>
+static int launch_256p(const GemmArgs& a, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           G256P_LDS));
+        attr_done = true;
+    }
+    GemmArgs b = a;
+    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
+    int gy = tiles_n >= 12 ? 4 : (tiles_n >= 8 ? 2 : 1);
+    if (g_force_gy) gy = g_force_gy;
+    b.gy = gy;
+    const int gx = 8 / gy;
+    const int region = ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
+    const int nslot = region < 32 ? region : 32;          // 32 CUs per XCD
+    hipLaunchKernelGGL((gemm256p_kernel<EPI>), dim3(8 * nslot), dim3(G256_THREADS), G256P_LDS, st, b, nslot);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 static int g_dbg = 0;          // timing experiments only (EPI_BF16): 1 = no epilogue stores, 2 = no main loop
 void gemm_set_debug(int d) { g_dbg = d; }
 template <int EPI>
@@ -380,6 +473,7 @@ static int launch_256(const GemmArgs& a, hipStream_t st) {
             default: return launch_256d<EPI_BF16, 3>(a, st);
         }
     }
+    if (g_persistent && a.K >= 128 && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) > 256) return launch_256p<EPI>(a, st);
     return launch_256d<EPI, 0>(a, st);
 }
 

@@ -60,6 +60,7 @@ int launch_attention(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, i
 // has_cls: row 0 is the class token and may be scheduled apart from the patch rows (same result)
 int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, int hd, int has_cls,
                         hipStream_t st);
+void gemm_set_persistent(int on);   // timing experiments only (1 = default)
 void attention_force_nw(int nw);   // timing experiments only (0 = heuristic)
 // single-probe attention pool: q [W] fp32 (already projected and scaled), kv [B*S][ld] bf16 (k | v halves)
 int launch_pool_attention(const float* q, const bf16_t* kv, long ld, bf16_t* out, long ldo, int B, int S, int H,

@@ -240,3 +240,41 @@ def test_gemm_skinny_all_epilogues(lib, dev, gemm_tile, M, N, K):
     x = x0.clone()
     _gemm(lib, EPI_RESID_F32, a, b, x, bias, gamma)
     assert (x - (x0 + gamma * ref)).abs().max().item() <= 2 * tol
+
+
+@pytest.mark.parametrize("M,N,K", [(4352, 4096, 128), (9000, 2304, 256), (4200, 4100, 64)])
+def test_gemm_persistent_tile_loop(lib, dev, gemm_tile, M, N, K):
+    """More than 256 output tiles: the 256x256 kernel runs its persistent form (one workgroup per CU
+    walking several tiles, next tile's DMA issued under the epilogue).  Must equal the
+    one-workgroup-per-tile form bit for bit, for every epilogue, and match an fp32 reference."""
+    if gemm_tile != 256:
+        pytest.skip("only the 256x256 kernel has a persistent form")
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    b = (torch.randn(N, K, generator=g) * 0.1).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    gamma = (torch.rand(N, generator=g) + 0.5).to(dev)
+    x0 = torch.randn(M, N, generator=g).to(dev)
+    ref = a.float() @ b.float().T + bias
+    res = {}
+    try:
+        for flag in (1 << 16, 0):
+            _lib.check(lib.revo_op_set_gemm_debug(flag))
+            c32 = torch.full((M, N), float("nan"), device=dev)
+            _gemm(lib, EPI_F32, a, b, c32, bias)
+            cb = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
+            _gemm(lib, EPI_BF16, a, b, cb, bias)
+            cg = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
+            _gemm(lib, EPI_BF16_GELU, a, b, cg, bias)
+            x = x0.clone()
+            _gemm(lib, EPI_RESID_F32, a, b, x, bias, gamma)
+            res[flag] = (c32, cb, cg, x)
+    finally:
+        _lib.check(lib.revo_op_set_gemm_debug(0))
+    for u, v in zip(res[1 << 16], res[0]):
+        assert torch.equal(u, v)
+    c32, cb, cg, x = res[0]
+    tol = 3e-3 * math.sqrt(max(K, 64) / 64)
+    assert (c32 - ref).abs().max().item() <= tol
+    assert (cg.float() - torch.nn.functional.gelu(ref)).abs().max().item() <= tol + 0.02 * ref.abs().max().item()
+    assert (x - (x0 + gamma * ref)).abs().max().item() <= 2 * tol
