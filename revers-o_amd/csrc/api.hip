@@ -372,10 +372,10 @@ extern "C" int32_t revo_vit_read_residual(revo_vit* vit, int32_t batch, float* d
 
 namespace {
 int gemm(const char* cls, int epi, const bf16_t* A, long lda, const bf16_t* B, long ldb, int M, int N, int K, void* C,
-         long ldc, const float* bias, const float* gamma, hipStream_t st) {
+         long ldc, const float* bias, const float* gamma, hipStream_t st, float* ws = nullptr, long ws_elems = 0) {
     revo::GemmArgs a{};
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
-    a.bias = bias; a.gamma = gamma;
+    a.bias = bias; a.gamma = gamma; a.ws = ws; a.ws_elems = ws_elems;
     ProfScope ps(cls, st);
     return revo::launch_gemm(epi, a, st);
 }
@@ -455,7 +455,9 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
         { ProfScope ps("layernorm", st);
           CHECK_RC(launch_layernorm(v->x, W, L.ln2w, L.ln2b, c.ln_eps, rows, W, v->h, W, 1, st)); }
         CHECK_RC(gemm("gemm_fc1", EPI_BF16_GELU, v->h, W, L.w_fc1, W, rows, Md, W, v->mlp, Md, L.b_fc1, nullptr, st));
-        CHECK_RC(gemm("gemm_fc2", EPI_RESID_F32, v->mlp, Md, L.w_fc2, Md, rows, W, Md, v->x, W, L.b_fc2, L.ls2, st));
+        // the qkv buffer is idle during the MLP: scratch for the split-K tail of fc2
+        CHECK_RC(gemm("gemm_fc2", EPI_RESID_F32, v->mlp, Md, L.w_fc2, Md, rows, W, Md, v->x, W, L.b_fc2, L.ls2, st,
+                      (float*)v->qkv, (long)rows * 3 * W / 2));
     }
     if (v->debug_layers >= 0) return 0;   // parity hook: residual stream only
 
@@ -704,8 +706,13 @@ extern "C" int32_t revo_op_gemm(int32_t epi, const void* a, int64_t lda, const v
                                 void* stream) {
     API_BEGIN
     REVO_REQUIRE(epi >= 0 && epi <= 3, "op_gemm: epilogue must be 0..3");
+    // the residual epilogue may cut the K range of its last, partly filled round of tiles (split-K
+    // tail): give it the scratch the ViT forward would (there: the idle qkv buffer)
+    static float* op_ws = nullptr;
+    constexpr long OP_WS_ELEMS = 16l << 20;
+    if (epi == revo::EPI_RESID_F32 && !op_ws) REVO_HIP_CHECK(hipMalloc((void**)&op_ws, OP_WS_ELEMS * 4));
     return gemm("gemm_op", epi, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, m, n, k, c, ldc, bias, gamma,
-                (hipStream_t)stream);
+                (hipStream_t)stream, epi == revo::EPI_RESID_F32 ? op_ws : nullptr, OP_WS_ELEMS);
     API_END
 }
 extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
@@ -715,6 +722,7 @@ extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
     revo::gemm_set_tail_split(((flags >> 12) & 1) ? 0 : 1);
     revo::topk_scan256_set_debug((flags >> 13) & 7);
     revo::gemm_set_persistent(((flags >> 16) & 1) ? 0 : 1);
+    revo::gemm_set_splitk(((flags >> 17) & 1) ? 0 : 1);
     return 0;
 }
 extern "C" int32_t revo_debug_scan_stats(int64_t* out4) {

@@ -252,6 +252,15 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
+    if (DBG & 4) {
+        // split-K partial: blockIdx.y owns K-tiles [y nt / S, (y+1) nt / S) and writes plain fp32 sums to
+        // its own output plane (the launcher's reduce kernel adds the planes in a fixed order)
+        const int nt = p.K >> 6, t0 = (int)blockIdx.y * nt / p.ksplit, t1 = ((int)blockIdx.y + 1) * nt / p.ksplit;
+        p.A += t0 * 64;
+        p.B += t0 * 64;
+        p.K = (t1 - t0) * 64;
+        p.C = (float*)p.C + (long)blockIdx.y * p.c_split_stride;
+    }
     G256Operand A, B;
     g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane);
     g256_operand_init(B, p.B, p.ldb, p.N, n0, wave, lane);
@@ -499,6 +508,62 @@ static int launch_128(const GemmArgs& a, hipStream_t st);
 static int g_tail_split = 1;   // timing experiments only: 0 disables the tail split below
 void gemm_set_tail_split(int on) { g_tail_split = on; }
 
+// ---- split-K tail of the residual GEMMs -------------------------------------------------------
+// The rows the whole rounds of the 256 x 256 kernel leave over (PE-L14 at batch 64, fc2: 68 tiles)
+// occupy a quarter of the CUs for a full tile time: the K loop is a latency chain (~1.3 us per
+// K-tile), so what helps is fewer K-tiles per CU, not smaller tiles.  Each tile's K range is cut in
+// S parts that run on different CUs and write fp32 partial sums; a second kernel adds them in a
+// fixed order (deterministic, unlike atomics) and applies bias, LayerScale and the residual add.
+__global__ __launch_bounds__(256) void splitk_reduce_resid_kernel(const float* __restrict__ ws, int S, long plane,
+                                                                  int rows, int N, const float* __restrict__ bias,
+                                                                  const float* __restrict__ gamma,
+                                                                  float* __restrict__ x, long ldc) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (long)rows * N) return;
+    const int r = (int)(i / N), c = (int)(i - (long)r * N);
+    f32x4 v = *(const f32x4*)(ws + i);
+    for (int s = 1; s < S; ++s) v += *(const f32x4*)(ws + (long)s * plane + i);
+    if (bias) v += *(const f32x4*)(bias + c);
+    if (gamma) v *= *(const f32x4*)(gamma + c);
+    float* dst = x + (long)r * ldc + c;
+    *(f32x4*)dst = *(const f32x4*)dst + v;
+}
+static int g_splitk = 1;     // timing experiments only: 0 disables the split-K tail
+void gemm_set_splitk(int on) { g_splitk = on; }
+// returns 1 when it took the problem, 0 when the caller should use the ordinary path
+static int try_splitk_tail(const GemmArgs& a, hipStream_t st) {
+    if (!g_splitk || !a.ws || a.N % 4 || a.K < 2048) return 0;
+    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256, nt = a.K / 64;
+    // XCD arrangement that spreads these few tiles most evenly (an XCD has 32 CUs: its tiles x S must fit)
+    int gy = 1, per = 1 << 30;
+    for (int g : {1, 2, 4, 8}) {
+        const int pm = (tiles_m + 8 / g - 1) / (8 / g), pn = (tiles_n + g - 1) / g;
+        if (pm * pn < per) { per = pm * pn; gy = g; }
+    }
+    int S = 32 / per;
+    S = S > 4 ? 4 : S;
+    if (S < 2 || nt / S < 8) return 0;
+    const long plane = (long)a.M * a.N;
+    if (plane * S > a.ws_elems) return 0;
+    static bool attr_done = false;
+    if (!attr_done) {
+        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<EPI_F32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           G256_LDS));
+        attr_done = true;
+    }
+    GemmArgs b = a;
+    b.C = a.ws; b.ldc = a.N; b.bias = nullptr; b.gamma = nullptr;
+    b.ksplit = S; b.c_split_stride = plane;
+    b.gy = gy;
+    hipLaunchKernelGGL((gemm256_kernel<EPI_F32, 4>), dim3(8 * per, S), dim3(G256_THREADS), G256_LDS, st, b);
+    REVO_HIP_CHECK(hipGetLastError());
+    const long quads = plane / 4;
+    hipLaunchKernelGGL(splitk_reduce_resid_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a.ws, S, plane,
+                       a.M, a.N, a.bias, a.gamma, (float*)a.C, a.ldc);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 1;
+}
+
 static bool use_skinny(const GemmArgs& a) { return g_force_tile == 0 && a.M <= 64 && a.K % 256 == 0 && a.N >= 256; }
 template <int EPI>
 static int launch_skinny(const GemmArgs& a, hipStream_t st) {
@@ -533,6 +598,12 @@ static int launch_t(const GemmArgs& a, hipStream_t st) {
                 a2.C = (char*)a.C + (long)m_main * a.ldc * esz;
                 const int rc = launch_256<EPI>(a1, st);
                 if (rc) return rc;
+                if (use_skinny(a2)) return launch_skinny<EPI>(a2, st);      // fc1 at batch 64: 64 rows are left over
+                if constexpr (EPI == EPI_RESID_F32) {
+                    const int rc2 = try_splitk_tail(a2, st);
+                    if (rc2 < 0) return rc2;
+                    if (rc2 == 1) return 0;
+                }
                 return launch_128<EPI>(a2, st);
             }
         }

@@ -26,6 +26,8 @@ struct GemmArgs {
     int gy;                      // XCD arrangement of the 256 x 256 kernel (set by the launcher)
     const float2* rope_cs;       // [rope_S][rope_hd/2] (cos, sin)      (EPI_BF16_ROPE)
     int rope_S, rope_hd, rope_cols;
+    float* ws; long ws_elems;    // optional scratch for the split-K tail of EPI_RESID_F32 (null = never split K)
+    int ksplit; long c_split_stride;   // set by the launcher: K ranges per tile, fp32 elements between partial outputs
 };
 // true when launch_gemm would run the 256 x 256 kernel with the row-coalesced epilogue for these sizes
 bool gemm_uses_wide_epilogue(int M, int N, long lda, long ldb, long ldc);
@@ -60,6 +62,7 @@ int launch_attention(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, i
 // has_cls: row 0 is the class token and may be scheduled apart from the patch rows (same result)
 int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, int hd, int has_cls,
                         hipStream_t st);
+void gemm_set_splitk(int on);       // timing experiments only (1 = default)
 void gemm_set_persistent(int on);   // timing experiments only (1 = default)
 void attention_force_nw(int nw);   // timing experiments only (0 = heuristic)
 // single-probe attention pool: q [W] fp32 (already projected and scaled), kv [B*S][ld] bf16 (k | v halves)

@@ -278,3 +278,33 @@ def test_gemm_persistent_tile_loop(lib, dev, gemm_tile, M, N, K):
     assert (c32 - ref).abs().max().item() <= tol
     assert (cg.float() - torch.nn.functional.gelu(ref)).abs().max().item() <= tol + 0.02 * ref.abs().max().item()
     assert (x - (x0 + gamma * ref)).abs().max().item() <= 2 * tol
+
+
+@pytest.mark.parametrize("M,N,K", [(36928, 1024, 4096), (33000, 1024, 2048), (17000, 2048, 2048)])
+def test_gemm_splitk_tail_residual(lib, dev, gemm_tile, M, N, K):
+    """Residual GEMM whose last round of 256x256 tiles is partly empty: the leftover rows run with their K
+    range cut across CUs (fp32 partial planes + a fixed-order reduce).  Same result as with the split
+    disabled up to fp32 summation order, deterministic run to run, and right against an fp32 reference."""
+    if gemm_tile != 128:
+        pytest.skip("heuristic path: one run is enough")
+    _lib.check(lib.revo_op_set_gemm_tile(0))
+    g = torch.Generator(device=dev).manual_seed(M + K)
+    a = torch.randn(M, K, generator=g, device=dev).bfloat16()
+    b = (torch.randn(N, K, generator=g, device=dev) * 0.05).bfloat16()
+    bias = torch.randn(N, generator=g, device=dev)
+    gamma = torch.rand(N, generator=g, device=dev) + 0.5
+    x0 = torch.randn(M, N, generator=g, device=dev)
+    outs = []
+    try:
+        for flag in (0, 0, 1 << 17):
+            _lib.check(lib.revo_op_set_gemm_debug(flag))
+            x = x0.clone()
+            _gemm(lib, EPI_RESID_F32, a, b, x, bias, gamma)
+            outs.append(x)
+    finally:
+        _lib.check(lib.revo_op_set_gemm_debug(0))
+    assert torch.equal(outs[0], outs[1])                                   # deterministic
+    assert (outs[0] - outs[2]).abs().max().item() <= 1e-3                  # summation order only
+    rows = torch.cat([torch.arange(0, 512, device=dev), torch.arange(M - 4200, M, device=dev)])
+    ref = x0[rows] + gamma * (a[rows].float() @ b.float().T + bias)
+    assert (outs[0][rows] - ref).abs().max().item() <= 3e-3 * math.sqrt(K / 64)
