@@ -87,11 +87,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int m_base, int
 }
 
 // 32 rows (accumulator fragments 2*QT, 2*QT+1) of a wave's fp32 sub-tile: transpose through
-// the wave's LDS slab, then whole 256-byte row segments to/from global memory.
+// the wave's LDS slab, then whole 256-byte row segments to/from global memory.  For the residual
+// epilogue the old values of the quarter arrive in `res` (loaded by gemm256_load_resid one quarter
+// ahead, so that only the first of the four HBM round trips of a tile is exposed).
+template <int QT>
+__device__ __forceinline__ void gemm256_load_resid(const GemmArgs& p, int m_base, int n_base, int lane, f32x4 (&res)[8]) {
+    const int gcol = n_base + (lane & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int grow = m_base + QT * 32 + it * 4 + (lane >> 4);
+        res[it] = (grow < p.M && gcol < p.N) ? *(const f32x4*)((const float*)p.C + (long)grow * p.ldc + gcol)
+                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
 template <int EPI, int QT>
 __device__ __forceinline__ void gemm256_epilogue_f32_quarter(const GemmArgs& p, char* slab, int m_base, int n_base,
                                                              int lane, f32x4 (&acc)[8][4], const f32x4 (&bias4)[4],
-                                                             const f32x4 (&gamma4)[4]) {
+                                                             const f32x4 (&gamma4)[4], const f32x4 (&res)[8]) {
     constexpr int RS = 272;   // 64 fp32 + 16 bytes of padding per slab row
     asm volatile("" : "+v"(lane) :: "memory");   // keep this quarter's address arithmetic inside it
     const int lr = lane & 15, lq = lane >> 4;
@@ -111,7 +123,7 @@ __device__ __forceinline__ void gemm256_epilogue_f32_quarter(const GemmArgs& p, 
         const int grow = m_base + QT * 32 + rl;
         if (grow < p.M && gcol < p.N) {
             float* dst = (float*)p.C + (long)grow * p.ldc + gcol;
-            if (EPI == EPI_RESID_F32) v += *(const f32x4*)dst;
+            if (EPI == EPI_RESID_F32) v += res[it];
             *(f32x4*)dst = v;
         }
     }
@@ -192,10 +204,15 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
             asm volatile("" ::: "memory");
         }
     } else {
-        gemm256_epilogue_f32_quarter<EPI, 0>(p, slab, m_base, n_base, lane, acc, bias4, gamma4);
-        gemm256_epilogue_f32_quarter<EPI, 1>(p, slab, m_base, n_base, lane, acc, bias4, gamma4);
-        gemm256_epilogue_f32_quarter<EPI, 2>(p, slab, m_base, n_base, lane, acc, bias4, gamma4);
-        gemm256_epilogue_f32_quarter<EPI, 3>(p, slab, m_base, n_base, lane, acc, bias4, gamma4);
+        f32x4 ra[8], rb[8];
+        if (EPI == EPI_RESID_F32) gemm256_load_resid<0>(p, m_base, n_base, lane, ra);
+        if (EPI == EPI_RESID_F32) gemm256_load_resid<1>(p, m_base, n_base, lane, rb);
+        gemm256_epilogue_f32_quarter<EPI, 0>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, ra);
+        if (EPI == EPI_RESID_F32) gemm256_load_resid<2>(p, m_base, n_base, lane, ra);
+        gemm256_epilogue_f32_quarter<EPI, 1>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, rb);
+        if (EPI == EPI_RESID_F32) gemm256_load_resid<3>(p, m_base, n_base, lane, rb);
+        gemm256_epilogue_f32_quarter<EPI, 2>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, ra);
+        gemm256_epilogue_f32_quarter<EPI, 3>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, rb);
     }
 }
 
