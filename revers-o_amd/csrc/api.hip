@@ -644,8 +644,17 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
     if (ksel == 32 && N >= 16384) {
         // ---- 256 x 256 scan.  Pre-pass: a plain GEMM of the queries against the first n_pre rows and a
         // per-row selection seed the admission scores; the fused scan covers rows [n_pre, N).
-        long n_pre = ((512l << 20) / (4l * Q)) / 256 * 256;
-        n_pre = n_pre > 8192 ? 8192 : (n_pre < 1024 ? 1024 : n_pre);
+        // Pre-pass size: about one round of 256 x 256 GEMM tiles.  Few queries mean short gallery
+        // slices per CU whose own 32nd-best scores stay loose (a slice of 4 k rows only reaches the 0.8 %
+        // quantile); a 64 k-row pre-pass seeds the 0.05 % quantile instead (Q = 256: 9 300 -> ~500 queued
+        // entries per slice, scan 1.11 -> 0.7 ms).
+        const long qtiles = (Q + 255) / 256;
+        long n_pre = (65536 / qtiles) / 256 * 256;
+        n_pre = n_pre > 65536 ? 65536 : (n_pre < 8192 ? 8192 : n_pre);
+        if (n_pre > N / 4) n_pre = (N / 4) / 256 * 256;
+        const long cap_pre = ((512l << 20) / (4l * Q)) / 256 * 256;
+        if (n_pre > cap_pre) n_pre = cap_pre;
+        if (n_pre < 1024) n_pre = 1024;
         const int splits = topk_scan256_splits(Q, N - n_pre);
         const int lists = splits + 1;
         const size_t list_bytes = (size_t)Q * lists * ksel * 8;
@@ -659,7 +668,7 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
             ProfScope ps("topk_prepass", st);
             GemmArgs ga{};
             ga.A = g->qb; ga.lda = D; ga.B = g->gb; ga.ldb = D; ga.M = Q; ga.N = (int)n_pre; ga.K = D;
-            ga.C = pre_scores; ga.ldc = n_pre;
+            ga.C = pre_scores; ga.ldc = n_pre; ga.prefer256 = 1;
             CHECK_RC(launch_gemm(EPI_F32, ga, st));
             REVO_HIP_CHECK(hipMemsetAsync(part, 0, part_bytes, st));
             CHECK_RC(launch_topk_select_rows(pre_scores, n_pre, (int)n_pre, Q, part, (long)lists * ksel, splits,

@@ -591,6 +591,8 @@ static int launch_skinny(const GemmArgs& a, hipStream_t st) {
 
 template <int EPI>
 static int launch_t(const GemmArgs& a, hipStream_t st) {
+    if (a.prefer256 && g_force_tile == 0 && 256l * a.lda * 2 < (1l << 31) && 256l * a.ldb * 2 < (1l << 31))
+        return launch_256<EPI>(a, st);
     if constexpr (EPI != EPI_PATCH && EPI != EPI_BF16_ROPE) {
         if (use_skinny(a)) return launch_skinny<EPI>(a, st);
     }

@@ -26,6 +26,7 @@ struct GemmArgs {
     int gy;                      // XCD arrangement of the 256 x 256 kernel (set by the launcher)
     const float2* rope_cs;       // [rope_S][rope_hd/2] (cos, sin)      (EPI_BF16_ROPE)
     int rope_S, rope_hd, rope_cols;
+    int prefer256;               // caller's hint: few rows but very many columns (search pre-pass) -> 256 x 256 tiles
     float* ws; long ws_elems;    // optional scratch for the split-K tail of EPI_RESID_F32 (null = never split K)
     int ksplit; long c_split_stride;   // set by the launcher: K ranges per tile, fp32 elements between partial outputs
 };

@@ -278,19 +278,34 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __rest
         const float* qr = Qf + (long)q * ldqf;
         const unsigned long long vmask = __ballot(valid);
         const int nv = __popcll(vmask);   // valid entries are a prefix (lists are best-first)
-        for (int cnd = 0; cnd < nv; ++cnd) {
-            const uint32_t gi = __builtin_amdgcn_readlane(idx, cnd);
-            const float* gr = Gf + (long)gi * ldgf;
-            float acc = 0.f;
-            for (int c = lane * 4; c < D; c += 256) {
-                const f32x4 a = *(const f32x4*)(qr + c), b = *(const f32x4*)(gr + c);
-                acc = fmaf(a[0], b[0], acc);
-                acc = fmaf(a[1], b[1], acc);
-                acc = fmaf(a[2], b[2], acc);
-                acc = fmaf(a[3], b[3], acc);
+        // four candidates at a time: their row reads are independent, so the HBM round trips overlap
+        // (each candidate keeps its own fma chain in the same order: the scores do not change)
+        for (int cnd0 = 0; cnd0 < nv; cnd0 += 4) {
+            const float* gr[4];
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cn = cnd0 + u < nv ? cnd0 + u : nv - 1;
+                gr[u] = Gf + (long)__shfl(idx, cn, 64) * ldgf;
             }
-            acc = wave_sum(acc);
-            if (lane == cnd) score = acc;
+            for (int c = lane * 4; c < D; c += 256) {
+                const f32x4 a = *(const f32x4*)(qr + c);
+                f32x4 b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b[u] = *(const f32x4*)(gr[u] + c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[u] = fmaf(a[0], b[u][0], acc[u]);
+                    acc[u] = fmaf(a[1], b[u][1], acc[u]);
+                    acc[u] = fmaf(a[2], b[u][2], acc[u]);
+                    acc[u] = fmaf(a[3], b[u][3], acc[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float t = wave_sum(acc[u]);
+                if (lane == cnd0 + u && cnd0 + u < nv) score = t;
+            }
         }
     }
     uint64_t k2 = valid ? make_key(score, idx) : 0ull;
@@ -320,23 +335,27 @@ int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const f
 // the KSEL best (score, column) keys of every row, best first, written to
 // part[q][slot][KSEL], and tau0[q] = the KSEL-th score (-inf if fewer than KSEL columns).
 // One wave per query; a 64-column chunk is sorted and merged only if it can change the result.
+constexpr int SW = 16;      // waves per query in the pre-pass selection
+constexpr int SU = 8;       // 64-column chunks of loads in flight per wave
 template <int KSEL>
-__global__ __launch_bounds__(RW * 64) void topk_select_rows_kernel(const float* __restrict__ scores, long lds_, int n,
+__global__ __launch_bounds__(SW * 64) void topk_select_rows_kernel(const float* __restrict__ scores, long lds_, int n,
                                                                   int Q, uint64_t* __restrict__ part,
                                                                   long part_row_stride, int slot,
                                                                   uint32_t* __restrict__ tau0) {
-    // one workgroup of RW waves per query: wave w takes the 64-column chunks w, w + RW, ...
-    __shared__ uint64_t partial[RW][64];
+    // one workgroup of SW waves per query: wave w takes the 64-column chunks w, w + SW, ...; SU chunks of
+    // loads are in flight per wave (the walk is a chain of global-load latencies otherwise)
+    __shared__ uint64_t partial[SW][64];
+    __shared__ uint64_t cand[SW][64];     // per wave: columns that beat the wave's running 32nd-best, compacted
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x;
     const float* row = scores + (long)q * lds_;
     uint64_t run = 0ull;
     float tau = -INFINITY;
-    for (int base = w * 64; base < n; base += RW * 64) {
-        const int c = base + lane;
-        const float s = c < n ? row[c] : -INFINITY;
-        if (__ballot(s >= tau && c < n) == 0ull) continue;
-        uint64_t v = c < n ? make_key(s, (uint32_t)c) : 0ull;
+    int cnt = 0;                           // wave-uniform
+    // Survivors are rare once tau has risen (a 64-column chunk holds ~0.5 of them): instead of sorting
+    // every chunk that has one, they are appended to the wave's buffer and sorted + merged per 64.
+    auto flush = [&]() {
+        uint64_t v = lane < cnt ? cand[w][lane] : 0ull;
         v = wave_sort_desc(v, lane);
         const uint64_t rev = shfl_xor_u64(v, 63);
         const uint64_t mx = run > rev ? run : rev;
@@ -344,12 +363,35 @@ __global__ __launch_bounds__(RW * 64) void topk_select_rows_kernel(const float* 
         if (lane >= KSEL) run = 0ull;
         const uint64_t last = readlane_u64(run, KSEL - 1);
         tau = last ? key_score(last) : -INFINITY;
+        cnt = 0;
+    };
+    for (int base0 = w * 64; base0 < n; base0 += SU * SW * 64) {
+        float sv[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int c = base0 + u * SW * 64 + lane;
+            sv[u] = c < n ? row[c] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int c = base0 + u * SW * 64 + lane;
+            const float s = sv[u];
+            const bool take = s >= tau && c < n;
+            const unsigned long long mask = __ballot(take);
+            if (mask == 0ull) continue;
+            const int add = __popcll(mask);
+            if (cnt + add > 64) flush();                  // (entries kept under the old tau stay valid candidates)
+            if (take) cand[w][cnt + __popcll(mask & ((1ull << lane) - 1ull))] = make_key(s, (uint32_t)c);
+            cnt += add;
+            if (cnt == 64) flush();
+        }
     }
+    if (cnt > 0) flush();
     partial[w][lane] = run;
     __syncthreads();
     if (w == 0) {
 #pragma unroll 1
-        for (int o = 1; o < RW; ++o) {
+        for (int o = 1; o < SW; ++o) {
             const uint64_t rev = partial[o][63 - lane];
             const uint64_t mx = run > rev ? run : rev;
             run = wave_bitonic_merge_desc(mx, lane);
@@ -363,7 +405,7 @@ __global__ __launch_bounds__(RW * 64) void topk_select_rows_kernel(const float* 
 int launch_topk_select_rows(const float* scores, long ld, int n, int Q, uint64_t* part, long part_row_stride, int slot,
                             uint32_t* tau0, hipStream_t st) {
     if (Q <= 0) return 0;
-    hipLaunchKernelGGL((topk_select_rows_kernel<32>), dim3(Q), dim3(RW * 64), 0, st, scores, ld, n, Q, part,
+    hipLaunchKernelGGL((topk_select_rows_kernel<32>), dim3(Q), dim3(SW * 64), 0, st, scores, ld, n, Q, part,
                        part_row_stride, slot, tau0);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
