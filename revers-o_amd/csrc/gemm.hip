@@ -160,6 +160,22 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
         for (int half = 0; half < 2; ++half) {
             asm volatile("" : "+v"(lane) :: "memory");
             const int lr = lane & 15, lq = lane >> 4;
+            // RoPE table entries of this half's 8 store steps, requested before the LDS transpose so that
+            // their latency is not paid once per step (a lane holds 4 interleaved pairs of one token)
+            f32x4 rtab[8][2];
+            if (EPI == EPI_BF16_ROPE) {
+                const int gcol_ = n_base + (lane & 7) * 8;
+                int tok_ = (m_base + half * 64 + (lane >> 3)) % p.rope_S;      // one division per 64 rows; then +8 per step
+                const float2* cs_ = p.rope_cs + ((gcol_ % p.rope_hd) >> 1);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const float2* t = cs_ + (long)tok_ * (p.rope_hd >> 1);
+                    rtab[it][0] = *(const f32x4*)t;
+                    rtab[it][1] = *(const f32x4*)(t + 2);
+                    tok_ += 8;
+                    if (tok_ >= p.rope_S) tok_ -= p.rope_S;
+                }
+            }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -172,32 +188,22 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
                     *(uint2*)(slab + (m * 16 + lr) * RS + (n * 16 + lq * 4) * 2) = o;
                 }
             const int gcol = n_base + (lane & 7) * 8;
-            // RoPE (K5) on the coalesced rows: a lane holds 4 interleaved pairs of one token
-            int tok = 0;
-            const float2* cs = nullptr;
-            if (EPI == EPI_BF16_ROPE) {
-                tok = (m_base + half * 64 + (lane >> 3)) % p.rope_S;      // one division per 64 rows; then +8 per step
-                cs = p.rope_cs + ((gcol % p.rope_hd) >> 1);
-            }
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int rl = it * 8 + (lane >> 3);
                 uint4 v = *(const uint4*)(slab + rl * RS + (lane & 7) * 16);
                 const int grow = m_base + half * 64 + rl;
                 if (EPI == EPI_BF16_ROPE) {
-                    if (gcol < p.rope_cols) {
-                        const float2* t = cs + (long)tok * (p.rope_hd >> 1);
+                    if (gcol < p.rope_cols) {       // K5 on the coalesced rows
                         uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float x0 = bf16_to_f32((bf16_t)(w[j] & 0xffff)), x1 = bf16_to_f32((bf16_t)(w[j] >> 16));
-                            const float2 c = t[j];
-                            w[j] = pack_bf16x2(x0 * c.x - x1 * c.y, x1 * c.x + x0 * c.y);
+                            const float cx = rtab[it][j >> 1][(j & 1) * 2], cy = rtab[it][j >> 1][(j & 1) * 2 + 1];
+                            w[j] = pack_bf16x2(x0 * cx - x1 * cy, x1 * cx + x0 * cy);
                         }
                         v = make_uint4(w[0], w[1], w[2], w[3]);
                     }
-                    tok += 8;
-                    if (tok >= p.rope_S) tok -= p.rope_S;
                 }
                 if (grow < p.M && gcol < p.N) *(uint4*)((bf16_t*)p.C + (long)grow * p.ldc + gcol) = v;
             }
