@@ -148,3 +148,29 @@ def test_embed_rejects_bad_input(dev):
     with pytest.raises(KeyError):
         engine.VitEngine(cfg, bad, device=0)
     eng.close()
+
+
+def test_l14_headline_batch_vs_oracle_and_batch_invariance(dev):
+    """The headline configuration itself (PE-Core-L14-336, 64 images per forward: persistent GEMM, split-K
+    tail, skinny pool GEMMs, 8-wave attention).  Two of the images are checked against the CPU oracle, and
+    every image's embedding must not depend on what else is in the batch (same image alone or in a batch of
+    3: other tile shapes, other kernels, same vector up to bf16 noise)."""
+    cfg = reverso_amd.get_config("PE-Core-L14-336")
+    sd = weights.synth_weights(cfg, seed=0, randomize_affine=True)
+    g = torch.Generator().manual_seed(77)
+    u8 = torch.randint(0, 256, (64, 3, 336, 336), generator=g, dtype=torch.uint8)
+    eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=64)
+    emb = eng.embed(u8.to(dev)).cpu()
+    assert torch.isfinite(emb).all()
+    assert ((emb.norm(dim=-1) - 1).abs() <= 1e-5).all()
+    ref = pe_vit.embed(sd, cfg, pe_vit.preprocess_u8(u8[[0, 63]]))
+    cos = (emb[[0, 63]] * ref).sum(-1)
+    assert (cos >= 0.999).all(), cos
+    gal = torch.nn.functional.normalize(torch.randn(2000, cfg.out_dim, generator=g), dim=-1)
+    assert ((emb[[0, 63]] @ gal.T) - (ref @ gal.T)).abs().max().item() <= 1e-3
+    one = eng.embed(u8[5:6].to(dev)).cpu()
+    three = eng.embed(u8[[4, 5, 6]].to(dev)).cpu()
+    assert (one[0] * emb[5]).sum() >= 0.99995 and (three[1] * emb[5]).sum() >= 0.99995
+    # determinism: the same batch twice gives the same bits (split-K partials are reduced in a fixed order)
+    assert torch.equal(eng.embed(u8.to(dev)).cpu(), emb)
+    eng.close()

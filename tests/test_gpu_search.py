@@ -206,3 +206,45 @@ def test_properties_at_100k(dev):
     assert torch.allclose(s2, s, atol=1e-6)
     G.close()
     G2.close()
+
+
+def test_properties_at_full_gallery_1m(dev):
+    """BASELINE.json's 1 M x 1024 gallery (size-independent properties; the oracle takes minutes here):
+    planted neighbours come first, results are sorted and complete, an 8-way row shard + merge equals the
+    unsharded search bit for bit, scores are the fp32 dot products, and a 10 000-query batch (configs[3])
+    agrees with the 64-query calls on the shared queries."""
+    N, D, k = 1_000_000, 1024, 10
+    g = torch.Generator(device=dev).manual_seed(2024)
+    G = engine.Gallery(D, N, device=0)
+    for s0 in range(0, N, 125_000):
+        G.add(torch.randn(125_000, D, generator=g, device=dev))
+    Q = 64
+    ids = torch.randint(0, N, (Q,), generator=g, device=dev)
+    ids = torch.unique(ids)
+    Q = ids.numel()
+    rows = torch.cat([G.read(int(i), 1) for i in ids])
+    q = rows + 0.02 * torch.randn(Q, D, generator=g, device=dev)
+    s, i, c = G.search(q, k)
+    assert torch.equal(i[:, 0], ids) and (c == k).all()
+    assert (s[:, :-1] >= s[:, 1:]).all()
+    # scores are exact fp32 cosines of the returned rows
+    qn = torch.nn.functional.normalize(q.double(), dim=-1)
+    for j in (0, Q // 2, Q - 1):
+        got = torch.cat([G.read(int(r), 1) for r in i[j]]).double()
+        assert ((got @ qn[j]) - s[j].double()).abs().max().item() <= 2e-6
+    # 8 shards searched apart (global row ids via index_offset) and merged == unsharded
+    parts_s, parts_i = [], []
+    for p in range(8):
+        Gp = engine.Gallery(D, 125_000, device=0)
+        Gp.add(G.read(p * 125_000, 125_000), normalize=False)
+        ps, pi, _ = Gp.search(q, k, index_offset=p * 125_000)
+        parts_s.append(ps); parts_i.append(pi)
+        Gp.close()
+    ms, mi, mc = engine.merge_topk(torch.stack(parts_s), torch.stack(parts_i), k)
+    assert torch.equal(mi, i) and torch.equal(ms, s) and torch.equal(mc, c)
+    # a large query batch takes the MFMA-bound regime of the same scan: same answers on the shared queries
+    big = torch.cat([q, torch.randn(10_000 - Q, D, generator=g, device=dev)])
+    bs, bi, bc = G.search(big, k)
+    assert torch.equal(bi[:Q], i) and torch.equal(bs[:Q], s)
+    assert (bc == k).all() and (bs[:, :-1] >= bs[:, 1:]).all()
+    G.close()
