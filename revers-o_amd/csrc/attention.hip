@@ -275,7 +275,37 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
         }
     }
 
-    if (wave_active) {
+    if constexpr (HD == 64) {
+        // Output through a wave-private LDS slab (the K/V ring is free now) so that global stores are whole
+        // 128-byte rows, 8 rows per instruction; stored straight from the accumulator layout a store
+        // instruction touches 32 rows with 16 bytes each.
+        __builtin_amdgcn_s_barrier();                // every wave is out of the ring
+        if (wave_active) {
+            constexpr int RS = 144;                  // 64 bf16 + 16 bytes of padding per row
+            char* slab = lds + wave * (32 * RS);
+            const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+            const float inv = 1.0f / l_tot;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 o;
+                    o.x = pack_bf16x2(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv);
+                    o.y = pack_bf16x2(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+                    *(uint2*)(slab + r * RS + (d * 32 + 8 * g + 4 * hh) * 2) = o;
+                }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rl = it * 8 + (lane >> 3);
+                const uint4 v = *(const uint4*)(slab + rl * RS + (lane & 7) * 16);
+                const int qp = q0 + rl;
+                if (qp < S) {
+                    const int qr = q_rot ? (qp + 1 < S ? qp + 1 : 0) : qp;
+                    *(uint4*)(out + (rowbase + qr) * ldo + h * HD + (lane & 7) * 8) = v;
+                }
+            }
+        }
+    } else if (wave_active) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         if (row_valid) {
             const float inv = 1.0f / l_tot;
