@@ -717,11 +717,17 @@ extern "C" int32_t revo_op_gemm(int32_t epi, const void* a, int64_t lda, const v
     REVO_REQUIRE(epi >= 0 && epi <= 3, "op_gemm: epilogue must be 0..3");
     // the residual epilogue may cut the K range of its last, partly filled round of tiles (split-K
     // tail): give it the scratch the ViT forward would (there: the idle qkv buffer)
-    static float* op_ws = nullptr;
+    static float* op_ws[16] = {};                     // one per device, allocated on first use, never freed
     constexpr long OP_WS_ELEMS = 16l << 20;
-    if (epi == revo::EPI_RESID_F32 && !op_ws) REVO_HIP_CHECK(hipMalloc((void**)&op_ws, OP_WS_ELEMS * 4));
+    int dev = 0;
+    REVO_HIP_CHECK(hipGetDevice(&dev));
+    float* ws = nullptr;
+    if (epi == revo::EPI_RESID_F32 && dev >= 0 && dev < 16) {
+        if (!op_ws[dev]) REVO_HIP_CHECK(hipMalloc((void**)&op_ws[dev], OP_WS_ELEMS * 4));
+        ws = op_ws[dev];
+    }
     return gemm("gemm_op", epi, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, m, n, k, c, ldc, bias, gamma,
-                (hipStream_t)stream, epi == revo::EPI_RESID_F32 ? op_ws : nullptr, OP_WS_ELEMS);
+                (hipStream_t)stream, ws, OP_WS_ELEMS);
     API_END
 }
 extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {

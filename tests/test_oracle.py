@@ -148,3 +148,55 @@ def test_resize_oracle_matches_product_host_resize():
     img = rng.integers(0, 256, (123, 211, 3), dtype=np.uint8)
     chw = preprocess.resize_u8(img, 56).numpy()
     assert np.array_equal(chw.transpose(1, 2, 0), R.crop_resize_u8(img, 56))
+
+
+# ---- oracle sub-blocks pinned to the torch modules the upstream tower is assembled from --------
+def test_oracle_attention_pool_matches_nn_multiheadattention():
+    """The upstream attention-pool head calls torch.nn.MultiheadAttention (probe as query, tokens as
+    key/value).  That module is installed here: the oracle's hand-assembled attention must equal it."""
+    cfg = reverso_amd.get_config("PE-Tiny-T14-56")
+    sd = reverso_amd.weights.synth_weights(cfg, seed=3, randomize_affine=True)
+    W, H = cfg.width, cfg.pool_heads
+    pre = "visual.attn_pool."
+    mha = torch.nn.MultiheadAttention(W, H, batch_first=True)
+    with torch.no_grad():
+        mha.in_proj_weight.copy_(sd[pre + "attn.in_proj_weight"])
+        mha.in_proj_bias.copy_(sd[pre + "attn.in_proj_bias"])
+        mha.out_proj.weight.copy_(sd[pre + "attn.out_proj.weight"])
+        mha.out_proj.bias.copy_(sd[pre + "attn.out_proj.bias"])
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, cfg.seq, W, generator=g)
+    probe = sd[pre + "probe"].reshape(1, 1, W).expand(3, 1, W)
+    with torch.no_grad():
+        o, _ = mha(probe, x, x, need_weights=False)
+        ln = torch.nn.functional.layer_norm(o, (W,), sd[pre + "layernorm.weight"], sd[pre + "layernorm.bias"], cfg.ln_eps)
+        h = torch.nn.functional.gelu(torch.nn.functional.linear(ln, sd[pre + "mlp.c_fc.weight"], sd[pre + "mlp.c_fc.bias"]))
+        want = (o + torch.nn.functional.linear(h, sd[pre + "mlp.c_proj.weight"], sd[pre + "mlp.c_proj.bias"]))[:, 0]
+    got = pe_vit.attn_pool(x, sd, cfg)
+    assert (got - want).abs().max().item() <= 2e-5
+
+
+def test_oracle_self_attention_matches_sdpa_and_mha_without_rope():
+    """With the rotation switched off (angle 0) the body attention is plain multi-head attention:
+    equal to torch.nn.MultiheadAttention and to F.scaled_dot_product_attention on the same weights."""
+    cfg = reverso_amd.get_config("PE-Tiny-T14-56")
+    sd = reverso_amd.weights.synth_weights(cfg, seed=4, randomize_affine=True)
+    W, H = cfg.width, cfg.heads
+    pre = "visual.transformer.resblocks.0."
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, cfg.seq, W, generator=g)
+    zero = torch.zeros(cfg.seq, W // H)
+    got = pe_vit.self_attention(x, sd, cfg, pre, zero)
+    mha = torch.nn.MultiheadAttention(W, H, batch_first=True)
+    with torch.no_grad():
+        mha.in_proj_weight.copy_(sd[pre + "attn.in_proj_weight"])
+        mha.in_proj_bias.copy_(sd[pre + "attn.in_proj_bias"])
+        mha.out_proj.weight.copy_(sd[pre + "attn.out_proj.weight"])
+        mha.out_proj.bias.copy_(sd[pre + "attn.out_proj.bias"])
+        want, _ = mha(x, x, x, need_weights=False)
+    assert (got - want).abs().max().item() <= 2e-5
+    # and the rotation itself is norm preserving and relative: <rope(q, i), rope(k, j)> depends on i - j only
+    ang = pe_vit.rope_angles(cfg)
+    q = torch.randn(1, 1, cfg.seq, W // H, generator=g)
+    rq = pe_vit.apply_rope(q, ang)
+    assert torch.allclose(rq.norm(dim=-1), q.norm(dim=-1), atol=1e-5)
