@@ -140,8 +140,17 @@ __device__ __forceinline__ void g256_issue_prologue(const G256Operand& A, const 
 // K % 64 == 0, K >= 64.  acc must be zero-initialised (or hold the running sum) by the caller,
 // and g256_issue_prologue(A, B, ...) must have been issued by this wave (any vector-memory
 // operations issued after it only make the first wait below more conservative).
+// ROWS = 64 / 128: only A rows 0..63 / 0..127 of the tile carry data (a search with few queries): the
+// waves of the second wave-row (and, at 64, the A-hi halves of the first) skip their LDS reads and
+// MFMAs (their accumulators stay 0) but keep issuing DMA and meeting the barriers, so the loop runs
+// at the DMA / HBM rate instead of the MFMA rate.
+template <int ROWS = 0>
 __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G256Operand& B, char* smem, int K,
                                                  int wave, int lane, f32x4 (&acc)[8][4]) {
+    static_assert(ROWS == 0 || ROWS == 64 || ROWS == 128, "");
+    const bool wact = wave < 4;
+#define G256_LO(...) do { if (ROWS == 0 || wact) { __VA_ARGS__; } } while (0)
+#define G256_HI(...) do { if (ROWS == 0 || (ROWS == 128 && wact)) { __VA_ARGS__; } } while (0)
     const int nt = K >> 6;
     G256Frags f;
     G256Addr ad;
@@ -153,8 +162,8 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    g256_read_a<0, 0>(f.alo, ad.a);
-    g256_read_b<0, 0>(f.blo, ad.b);
+    G256_LO(g256_read_a<0, 0>(f.alo, ad.a););
+    G256_LO(g256_read_b<0, 0>(f.blo, ad.b););
     G256_FENCE();
 
     // two K-tiles per trip; an odd trailing tile is peeled so the loop has a single exit
@@ -164,23 +173,23 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
         {
             const bool n1 = t + 1 < nt, n2 = t + 2 < nt;
             // P0
-            g256_read_a<64, 0>(f.ahi, ad.a);
+            G256_HI(g256_read_a<64, 0>(f.ahi, ad.a););
             if (n1) g256_issue_half(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
-            g256_cluster<0, 0>(f.alo, f.blo, acc);
+            G256_LO(g256_cluster<0, 0>(f.alo, f.blo, acc););
             G256_FENCE();
             // P1
-            g256_read_b<32, 0>(f.bhi, ad.b);
+            G256_LO(g256_read_b<32, 0>(f.bhi, ad.b););
             if (n1) g256_issue_half(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
-            g256_cluster<4, 0>(f.ahi, f.blo, acc);
+            G256_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
             G256_FENCE();
             // P2: every wave has retired its A reads of this stage -> refill its A halves
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (n2) g256_issue_half(A, 0, (t + 2) * 128, G256_A(smem, 0), wave);
             G256_FENCE();
-            g256_cluster<4, 2>(f.ahi, f.bhi, acc);
+            G256_HI(g256_cluster<4, 2>(f.ahi, f.bhi, acc););
             G256_FENCE();
             // P3: publish tile t+1, start reading it
             if (n2) g256_issue_half(A, 1, (t + 2) * 128, G256_A(smem, 0), wave);
@@ -188,11 +197,11 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
                 if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                g256_read_a<64, 1>(f.ahi, ad.a);          // odd tiles start with A-hi
-                g256_read_b<0, 1>(f.blo, ad.b);
+                G256_HI(g256_read_a<64, 1>(f.ahi, ad.a););          // odd tiles start with A-hi
+                G256_LO(g256_read_b<0, 1>(f.blo, ad.b););
             }
             G256_FENCE();
-            g256_cluster<0, 2>(f.alo, f.bhi, acc);
+            G256_LO(g256_cluster<0, 2>(f.alo, f.bhi, acc););
             G256_FENCE();
         }
         // ------------------------------------------------------------ odd tile t+1, stage 1
@@ -200,23 +209,23 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             const int u = t + 1;
             const bool n1 = u + 1 < nt, n2 = u + 2 < nt;
             // P0'
-            g256_read_a<0, 1>(f.alo, ad.a);
+            G256_LO(g256_read_a<0, 1>(f.alo, ad.a););
             if (n1) g256_issue_half(B, 0, (u + 1) * 128, G256_B(smem, 0), wave);
             G256_FENCE();
-            g256_cluster<4, 0>(f.ahi, f.blo, acc);
+            G256_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
             G256_FENCE();
             // P1'
-            g256_read_b<32, 1>(f.bhi, ad.b);
+            G256_LO(g256_read_b<32, 1>(f.bhi, ad.b););
             if (n1) g256_issue_half(B, 1, (u + 1) * 128, G256_B(smem, 0), wave);
             G256_FENCE();
-            g256_cluster<0, 0>(f.alo, f.blo, acc);
+            G256_LO(g256_cluster<0, 0>(f.alo, f.blo, acc););
             G256_FENCE();
             // P2'
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (n2) g256_issue_half(A, 0, (u + 2) * 128, G256_A(smem, 1), wave);
             G256_FENCE();
-            g256_cluster<0, 2>(f.alo, f.bhi, acc);
+            G256_LO(g256_cluster<0, 2>(f.alo, f.bhi, acc););
             G256_FENCE();
             // P3'
             if (n2) g256_issue_half(A, 1, (u + 2) * 128, G256_A(smem, 1), wave);
@@ -224,11 +233,11 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
                 if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                g256_read_a<0, 0>(f.alo, ad.a);               // even tiles start with A-lo
-                g256_read_b<0, 0>(f.blo, ad.b);
+                G256_LO(g256_read_a<0, 0>(f.alo, ad.a););               // even tiles start with A-lo
+                G256_LO(g256_read_b<0, 0>(f.blo, ad.b););
             }
             G256_FENCE();
-            g256_cluster<4, 2>(f.ahi, f.bhi, acc);
+            G256_HI(g256_cluster<4, 2>(f.ahi, f.bhi, acc););
             G256_FENCE();
         }
     }
@@ -237,23 +246,23 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
         {
             const bool n1 = t + 1 < nt, n2 = t + 2 < nt;
             // P0
-            g256_read_a<64, 0>(f.ahi, ad.a);
+            G256_HI(g256_read_a<64, 0>(f.ahi, ad.a););
             if (n1) g256_issue_half(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
-            g256_cluster<0, 0>(f.alo, f.blo, acc);
+            G256_LO(g256_cluster<0, 0>(f.alo, f.blo, acc););
             G256_FENCE();
             // P1
-            g256_read_b<32, 0>(f.bhi, ad.b);
+            G256_LO(g256_read_b<32, 0>(f.bhi, ad.b););
             if (n1) g256_issue_half(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
-            g256_cluster<4, 0>(f.ahi, f.blo, acc);
+            G256_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
             G256_FENCE();
             // P2: every wave has retired its A reads of this stage -> refill its A halves
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (n2) g256_issue_half(A, 0, (t + 2) * 128, G256_A(smem, 0), wave);
             G256_FENCE();
-            g256_cluster<4, 2>(f.ahi, f.bhi, acc);
+            G256_HI(g256_cluster<4, 2>(f.ahi, f.bhi, acc););
             G256_FENCE();
             // P3: publish tile t+1, start reading it
             if (n2) g256_issue_half(A, 1, (t + 2) * 128, G256_A(smem, 0), wave);
@@ -261,17 +270,19 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
                 if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                g256_read_a<64, 1>(f.ahi, ad.a);          // odd tiles start with A-hi
-                g256_read_b<0, 1>(f.blo, ad.b);
+                G256_HI(g256_read_a<64, 1>(f.ahi, ad.a););          // odd tiles start with A-hi
+                G256_LO(g256_read_b<0, 1>(f.blo, ad.b););
             }
             G256_FENCE();
-            g256_cluster<0, 2>(f.alo, f.bhi, acc);
+            G256_LO(g256_cluster<0, 2>(f.alo, f.bhi, acc););
             G256_FENCE();
         }
     }
     // all waves are past their last LDS read before the caller reuses the LDS image
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#undef G256_LO
+#undef G256_HI
 }
 
 }  // namespace revo

@@ -280,7 +280,10 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
             for (int m = 0; m < 8; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            gemm256_mainloop(A, B, smem, p.D, wave, lane, acc);
+            // at most 64 queries: three quarters of the tile's MFMA work would multiply zero rows
+            // (a 128-row mode as a third instantiation costs the main path 7 %: register allocation)
+            if (qvalid <= 64) gemm256_mainloop<64>(A, B, smem, p.D, wave, lane, acc);
+            else gemm256_mainloop<0>(A, B, smem, p.D, wave, lane, acc);
 
             if (groups == 1 && t + 1 < t1) {
                 // next gallery tile: rebased descriptors (any gallery size), DMA in flight during the selection
