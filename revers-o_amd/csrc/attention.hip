@@ -67,10 +67,27 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.y / H, h = blockIdx.y - b * H;
+    // XCD-aware order.  Blocks L, L+8, L+16, ... share an XCD and start close in time: the query blocks of
+    // one (image, head) are mapped to such a run, so its K/V rows are fetched into one XCD's L2 once instead
+    // of once per query block on different XCDs (L14: 3 query blocks, 505 -> ~230 MB of fabric reads).
+    int bh, qblk;
+    {
+        const int nq = gridDim.x, nbh = gridDim.y, L = blockIdx.y * nq + blockIdx.x;
+        const int full = (nbh / 8) * 8;                 // (image, head) pairs that form whole groups of 8
+        if (L < full * nq) {
+            const int xcd = L & 7, slot = L >> 3;
+            bh = (slot / nq) * 8 + xcd;
+            qblk = slot % nq;
+        } else {
+            const int r = L - full * nq;                // the last < 8 pairs: plain order
+            bh = full + r / nq;
+            qblk = r % nq;
+        }
+    }
+    const int b = bh / H, h = bh - b * H;
     const int W = H * HD;
     const long rowbase = (long)b * S;
-    const int q0 = blockIdx.x * (NW * 32) + wave * 32;       // position in the (rotated) row order
+    const int q0 = qblk * (NW * 32) + wave * 32;             // position in the (rotated) row order
     const bool wave_active = q0 < S;
     const bool row_valid = q0 + r < S;
     const int qpos = row_valid ? q0 + r : S - 1;
