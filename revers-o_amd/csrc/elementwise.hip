@@ -65,12 +65,84 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Same statistics, 8 consecutive elements per lane and step: two adjacent 16-byte loads and ONE 16-byte
+// bf16 store (8-byte stores run at 0.5-0.7x the 16-byte rate).  W % 8 == 0, bf16 output.
+template <int MAXG>
+__global__ __launch_bounds__(256) void layernorm8_kernel(const float* __restrict__ x, long ldx,
+                                                         const float* __restrict__ w, const float* __restrict__ b,
+                                                         float eps, int rows, int W, bf16_t* __restrict__ out, long ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * ldx;
+    const int ngroup = W >> 3;
+    f32x4 v[MAXG][2];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+        const int g = lane + 64 * i;
+        if (g < ngroup) {
+            v[i][0] = *(const f32x4*)(xr + g * 8);
+            v[i][1] = *(const f32x4*)(xr + g * 8 + 4);
+            s += ((v[i][0][0] + v[i][0][1]) + (v[i][0][2] + v[i][0][3])) + ((v[i][1][0] + v[i][1][1]) + (v[i][1][2] + v[i][1][3]));
+        } else {
+            v[i][0] = v[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+        const int g = lane + 64 * i;
+        if (g < ngroup) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[i][h][j] - mean;
+                    q = fmaf(d, d, q);
+                }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+        const int g = lane + 64 * i;
+        if (g < ngroup) {
+            float y[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 gm = *(const f32x4*)(w + g * 8 + h * 4);
+                const f32x4 be = *(const f32x4*)(b + g * 8 + h * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[h * 4 + j] = fmaf((v[i][h][j] - mean) * rstd, gm[j], be[j]);
+            }
+            uint4 o;
+            o.x = pack_bf16x2(y[0], y[1]);
+            o.y = pack_bf16x2(y[2], y[3]);
+            o.z = pack_bf16x2(y[4], y[5]);
+            o.w = pack_bf16x2(y[6], y[7]);
+            *(uint4*)(out + (long)row * ldo + g * 8) = o;
+        }
+    }
+}
+
 int launch_layernorm(const float* x, long ldx, const float* w, const float* b, float eps, int rows, int W, void* out,
                      long ldo, int out_is_bf16, hipStream_t st) {
     REVO_REQUIRE(W % 4 == 0 && W <= 2048, "layernorm: W must be a multiple of 4 and <= 2048");
     REVO_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "layernorm: row strides must be multiples of 4");
     if (rows <= 0) return 0;
     dim3 grid((rows + 3) / 4), block(256);
+    if (out_is_bf16 && W % 8 == 0 && ldx % 4 == 0 && ldo % 8 == 0 && (((uintptr_t)out) & 15) == 0) {
+        const int groups = (W / 8 + 63) / 64;
+        bf16_t* o = (bf16_t*)out;
+        if (groups <= 1) hipLaunchKernelGGL((layernorm8_kernel<1>), grid, block, 0, st, x, ldx, w, b, eps, rows, W, o, ldo);
+        else if (groups <= 2) hipLaunchKernelGGL((layernorm8_kernel<2>), grid, block, 0, st, x, ldx, w, b, eps, rows, W, o, ldo);
+        else if (groups <= 3) hipLaunchKernelGGL((layernorm8_kernel<3>), grid, block, 0, st, x, ldx, w, b, eps, rows, W, o, ldo);
+        else hipLaunchKernelGGL((layernorm8_kernel<4>), grid, block, 0, st, x, ldx, w, b, eps, rows, W, o, ldo);
+        REVO_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const int chunks = (W / 4 + 63) / 64;
 #define LN_LAUNCH(MC)                                                                                              \
     if (out_is_bf16)                                                                                               \
