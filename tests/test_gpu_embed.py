@@ -174,3 +174,33 @@ def test_l14_headline_batch_vs_oracle_and_batch_invariance(dev):
     # determinism: the same batch twice gives the same bits (split-K partials are reduced in a fixed order)
     assert torch.equal(eng.embed(u8.to(dev)).cpu(), emb)
     eng.close()
+
+
+def test_handles_release_device_memory(dev):
+    """Create / destroy cycles of the two handle types give their HBM back (no growth over 10 cycles)."""
+    from reverso_amd import preprocess
+    torch.cuda.synchronize()
+
+    def used():
+        free, total = torch.cuda.mem_get_info()
+        return total - free
+
+    def cycle():
+        eng = engine.VitEngine.synthetic("PE-Tiny-T14-56", seed=0, device=0, max_batch=8)
+        img = torch.randint(0, 256, (8, 3, 56, 56), device=dev, dtype=torch.uint8)
+        e = eng.embed(img)
+        gal = engine.Gallery(eng.cfg.out_dim, 20000, device=0)
+        gal.add(torch.randn(20000, eng.cfg.out_dim, device=dev))
+        gal.search(e, 5)
+        preprocess.crop_resize_device(torch.zeros((100, 120, 3), dtype=torch.uint8, device=dev), None, 56)
+        torch.cuda.synchronize()
+        gal.close()
+        eng.close()
+
+    cycle()                      # first use allocates library-lifetime scratch (preprocess tables, hip modules)
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    base = used()
+    for _ in range(10):
+        cycle()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    assert used() - base <= 8 << 20, (used() - base)
