@@ -641,7 +641,7 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
     { ProfScope ps("search_prep", st);
       CHECK_RC(launch_l2norm_rows(queries, D, g->qf, D, g->qb, D, Q, D, st)); }
 
-    if (ksel == 32 && N >= 16384) {
+    if (N >= 16384) {
         // ---- 256 x 256 scan.  Pre-pass: a plain GEMM of the queries against the first n_pre rows and a
         // per-row selection seed the admission scores; the fused scan covers rows [n_pre, N).
         // Pre-pass size: about one round of 256 x 256 GEMM tiles.  Few queries mean short gallery
@@ -658,7 +658,7 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
         const int splits = topk_scan256_splits(Q, N - n_pre);
         const int lists = splits + 1;
         const size_t list_bytes = (size_t)Q * lists * ksel * 8;
-        const size_t gtop_bytes = (size_t)Q * splits * topk_scan256_top_m(splits) * 4;
+        const size_t gtop_bytes = (size_t)Q * splits * topk_scan256_top_m(splits, ksel) * 4;
         const size_t part_bytes = list_bytes + gtop_bytes;          // zeroed together
         const size_t pre_off = (part_bytes + 255) / 256 * 256;
         CHECK_RC(need_part(pre_off + (size_t)Q * n_pre * 4));
@@ -672,18 +672,18 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
             CHECK_RC(launch_gemm(EPI_F32, ga, st));
             REVO_HIP_CHECK(hipMemsetAsync(part, 0, part_bytes, st));
             CHECK_RC(launch_topk_select_rows(pre_scores, n_pre, (int)n_pre, Q, part, (long)lists * ksel, splits,
-                                             g->tau0, st));
+                                             g->tau0, ksel, st));
         }
         { ProfScope ps("topk_scan", st);
           CHECK_RC(launch_topk_scan256(g->qb, D, g->gb, D, Q, N, D, n_pre, splits, part, lists, g->tau0,
-                                       (uint32_t*)((char*)part + list_bytes), st)); }
+                                       (uint32_t*)((char*)part + list_bytes), ksel, st)); }
         { ProfScope ps("topk_reduce", st); CHECK_RC(launch_topk_reduce(part, Q, lists, ksel, st)); }
         { ProfScope ps("topk_finish", st);
           CHECK_RC(launch_topk_finish(part, (long)lists * ksel, ksel, g->qf, D, g->keep_f32 ? g->gf : nullptr, D, D, Q,
                                       k, has_thr, thr, index_offset, scores, (long long*)indices, counts, st)); }
         return 0;
     }
-    // ---- small galleries (and k > 16): 128 x 128 scan with per-wave LDS lists
+    // ---- small galleries: 128 x 128 scan with per-wave LDS lists
     const int splits = topk_scan_workspace_splits(Q, N);
     CHECK_RC(need_part((size_t)Q * splits * ksel * 8));
     ScanArgs a{};

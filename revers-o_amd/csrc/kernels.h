@@ -93,12 +93,12 @@ int topk_scan256_splits(int Q, long rows);
 void topk_scan256_set_debug(int d);   // timing experiments only
 unsigned long long* topk_scan256_stats();
 int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
-                        int splits, uint64_t* part, int lists_per_query, uint32_t* tau_g, uint32_t* gtop,
+                        int splits, uint64_t* part, int lists_per_query, uint32_t* tau_g, uint32_t* gtop, int ksel,
                         hipStream_t st);
-int topk_scan256_top_m(int splits);   // best scores each slice publishes for the cross-slice bound
+int topk_scan256_top_m(int splits, int ksel);   // best scores each slice publishes for the cross-slice bound
 // pre-pass of the 256 x 256 scan: KSEL best columns of every row of a [Q][n] fp32 score matrix
 int launch_topk_select_rows(const float* scores, long ld, int n, int Q, uint64_t* part, long part_row_stride, int slot,
-                            uint32_t* tau0, hipStream_t st);
+                            uint32_t* tau0, int ksel, hipStream_t st);
 // all-padding result for an empty gallery
 int launch_topk_fill_empty(float* s, long long* i, int* c, int Q, int k, hipStream_t st);
 // merge P per-shard result lists [P][Q][k] -> [Q][k]

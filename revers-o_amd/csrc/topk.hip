@@ -403,10 +403,14 @@ __global__ __launch_bounds__(SW * 64) void topk_select_rows_kernel(const float* 
     }
 }
 int launch_topk_select_rows(const float* scores, long ld, int n, int Q, uint64_t* part, long part_row_stride, int slot,
-                            uint32_t* tau0, hipStream_t st) {
+                            uint32_t* tau0, int ksel, hipStream_t st) {
     if (Q <= 0) return 0;
-    hipLaunchKernelGGL((topk_select_rows_kernel<32>), dim3(Q), dim3(SW * 64), 0, st, scores, ld, n, Q, part,
-                       part_row_stride, slot, tau0);
+    if (ksel == 32)
+        hipLaunchKernelGGL((topk_select_rows_kernel<32>), dim3(Q), dim3(SW * 64), 0, st, scores, ld, n, Q, part,
+                           part_row_stride, slot, tau0);
+    else
+        hipLaunchKernelGGL((topk_select_rows_kernel<64>), dim3(Q), dim3(SW * 64), 0, st, scores, ld, n, Q, part,
+                           part_row_stride, slot, tau0);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

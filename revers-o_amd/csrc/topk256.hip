@@ -21,8 +21,7 @@ namespace revo {
 
 constexpr int S256_QCAP = 2048;          // queue entries
 constexpr int S256_DRAIN = 1792;         // drain once this many are queued (256 slots of slack for the next tile)
-constexpr int S256_KSEL = 32;
-constexpr int S256_LDS = G256_LDS + S256_QCAP * 8 + 256 * 4 * 3 + 64 + 8 * 64 * 8 + 256 * 8;
+constexpr int S256_LDS = G256_LDS + S256_QCAP * 8 + 256 * 4 * 3 + 64 + 8 * 128 * 8 + 256 * 8;   // + queue, tau/start/end, ctrl, merge scratch, wkey
 
 __device__ __forceinline__ uint64_t s256_entry(int row, float score, uint32_t relidx) {
     return ((uint64_t)row << 56) | ((uint64_t)f32_orderable(score) << 24) | (uint64_t)((~relidx) & 0xffffffu);
@@ -79,6 +78,7 @@ __device__ __forceinline__ uint32_t s256_merge_desc_u32(uint32_t v, int lane) { 
 // and a tight one: the global top KSEL is spread over the slices, few slices hold more than top_m of it.
 // One slice's own KSEL-th best only reaches the KSEL / slice-rows quantile (measured: ~6x more queued
 // entries than necessary at 32 slices).  All 512 threads; one wave per row, rows strided by 8.
+template <int KSEL>
 __device__ __noinline__ void s256_refresh_bounds(const S256Lds& L, const uint32_t* gtop, int q0, int qvalid, int nvals,
                                                  int tid, unsigned long long* stats) {
     const int wave = tid >> 6, lane = tid & 63;
@@ -94,14 +94,23 @@ __device__ __noinline__ void s256_refresh_bounds(const S256Lds& L, const uint32_
             const uint32_t b = s256_sort_desc_u32(v0 > v1 ? v1 : v0, lane);
             // best 32 of the chunk: a[0..31] descending next to b[31..0] ascending is bitonic
             const uint32_t brev = __shfl(b, 63 - lane, 64);      // all lanes take part: a shuffle reads 0 from inactive lanes
-            uint32_t x = lane < 32 ? a : brev;
-            x = s256_merge_desc_u32(x, lane);
-            const uint32_t xrev = __shfl(x, 63 - lane, 64);
-            uint32_t y = lane < 32 ? run : xrev;
-            y = s256_merge_desc_u32(y, lane);
-            run = lane < 32 ? y : 0u;
+            if (KSEL == 32) {
+                uint32_t x = lane < 32 ? a : brev;
+                x = s256_merge_desc_u32(x, lane);
+                const uint32_t xrev = __shfl(x, 63 - lane, 64);
+                uint32_t y = lane < 32 ? run : xrev;
+                y = s256_merge_desc_u32(y, lane);
+                run = lane < 32 ? y : 0u;
+            } else {
+                // best 64 of the 128: the element-wise maximum of a descending and an ascending run is bitonic
+                uint32_t x = a > brev ? a : brev;
+                x = s256_merge_desc_u32(x, lane);
+                const uint32_t xrev = __shfl(x, 63 - lane, 64);
+                uint32_t y = run > xrev ? run : xrev;
+                run = s256_merge_desc_u32(y, lane);
+            }
         }
-        const uint32_t bound = (uint32_t)__builtin_amdgcn_readlane((int)run, S256_KSEL - 1);
+        const uint32_t bound = (uint32_t)__builtin_amdgcn_readlane((int)run, KSEL - 1);
         if (lane == 0 && bound != 0u) {
             const float b = orderable_f32(bound);
             if (stats) atomicAdd(stats + (b > L.tau[r] ? 4 : 5), 1ull);
@@ -115,6 +124,7 @@ __device__ __noinline__ void s256_refresh_bounds(const S256Lds& L, const uint32_
 
 // All 512 threads.  Sort the queue (row, score, index descending), merge every row's best
 // entries into its global list, refresh the admission scores, empty the queue.
+template <int KSEL>
 __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* part, long part_row_stride, int q0, int qvalid,
                                         uint32_t idx_base, int tid, uint32_t* tau_g, uint32_t* gtop_mine, int gtop_stride,
                                         int top_m) {
@@ -147,54 +157,82 @@ __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* part, long p
         if (i == n - 1 || (int)(L.queue[i + 1] >> 56) != r) L.end[r] = i + 1;
     }
     __syncthreads();
-    uint64_t* ws = L.scratch + wave * 64;
+    uint64_t* ws = L.scratch + wave * 128;
     // the lists live in global memory (L2): the next row's list is requested before the current row is
     // merged, so the round trips of a wave's ~32 rows overlap instead of adding up
     uint64_t nxt = 0ull;
-    if (wave < qvalid && lane < 32) nxt = part[(long)(q0 + wave) * part_row_stride + lane];
+    if (wave < qvalid && lane < KSEL) nxt = part[(long)(q0 + wave) * part_row_stride + lane];
     for (int r = wave; r < qvalid; r += 8) {
-        uint64_t cur = nxt;                                     // lanes 0..31: the row's list, best first
-        if (r + 8 < qvalid && lane < 32) nxt = part[(long)(q0 + r + 8) * part_row_stride + lane];
+        uint64_t cur = nxt;                                     // lanes 0..KSEL-1: the row's list, best first
+        if (r + 8 < qvalid && lane < KSEL) nxt = part[(long)(q0 + r + 8) * part_row_stride + lane];
         const int s0 = L.start[r];
         const int cnt = L.end[r] - s0;
         if (cnt <= 0) continue;
         uint64_t* list = part + (long)(q0 + r) * part_row_stride;
-        // The row's queued entries are merged 32 at a time, duplicates removed after every merge: a tile
+        // The row's queued entries are merged KSEL at a time, duplicates removed after every merge: a tile
         // that is computed again after a queue overflow re-queues entries the list already holds, and
         // truncating the queue side before de-duplication could push new entries out.
-        for (int off = 0; off < cnt; off += S256_KSEL) {
-            const int c = (cnt - off) < S256_KSEL ? (cnt - off) : S256_KSEL;
+        for (int off = 0; off < cnt; off += KSEL) {
+            const int c = (cnt - off) < KSEL ? (cnt - off) : KSEL;
             const uint64_t best = s256_entry_to_key(L.queue[s0 + off], idx_base);
-            const uint64_t worst_kept = __builtin_amdgcn_readlane((uint32_t)cur, S256_KSEL - 1) |
-                                        ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(cur >> 32), S256_KSEL - 1) << 32);
+            const uint64_t worst_kept = __builtin_amdgcn_readlane((uint32_t)cur, KSEL - 1) |
+                                        ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(cur >> 32), KSEL - 1) << 32);
             if (off > 0 && worst_kept != 0ull && best < worst_kept) break;   // nothing further down can enter
-            uint64_t v;
-            if (lane < 32) {
-                v = cur;
-            } else {
-                const int jx = 63 - lane;                   // lane 63 takes the chunk's best entry
-                v = jx < c ? s256_entry_to_key(L.queue[s0 + off + jx], idx_base) : 0ull;
-            }
-            // lanes 0..31 best-first, lanes 32..63 worst-first: bitonic -> sorted best-first
+            if (KSEL == 32) {
+                uint64_t v;
+                if (lane < 32) {
+                    v = cur;
+                } else {
+                    const int jx = 63 - lane;                   // lane 63 takes the chunk's best entry
+                    v = jx < c ? s256_entry_to_key(L.queue[s0 + off + jx], idx_base) : 0ull;
+                }
+                // lanes 0..31 best-first, lanes 32..63 worst-first: bitonic -> sorted best-first
 #pragma unroll
-            for (int j = 32; j > 0; j >>= 1) {
-                const uint64_t o = s256_shfl_xor(v, j);
-                v = ((lane & j) == 0) ? (v > o ? v : o) : (v < o ? v : o);
+                for (int j = 32; j > 0; j >>= 1) {
+                    const uint64_t o = s256_shfl_xor(v, j);
+                    v = ((lane & j) == 0) ? (v > o ? v : o) : (v < o ? v : o);
+                }
+                const uint64_t prev = s256_shfl_up1(v);
+                const bool keep = v != 0ull && (lane == 0 || v != prev);
+                const unsigned long long km = __ballot(keep);
+                const int pos = __popcll(km & ((1ull << lane) - 1ull));
+                ws[lane] = 0ull;
+                if (keep) ws[pos] = v;            // LDS operations of one wave complete in order
+                cur = lane < KSEL ? ws[lane] : 0ull;
+            } else {
+                // 64-entry list + up to 64 queued entries: a 128-element bitonic merge held in two registers.
+                // hi = element-wise maximum (the best 64, bitonic), lo = minimum (the rest, bitonic); both are
+                // sorted, duplicates dropped across the whole 128, and the first 64 survivors are the new list.
+                const int jx = 63 - lane;
+                const uint64_t q1 = jx < c ? s256_entry_to_key(L.queue[s0 + off + jx], idx_base) : 0ull;   // worst-first
+                uint64_t hi = cur > q1 ? cur : q1, lo = cur > q1 ? q1 : cur;
+#pragma unroll
+                for (int j = 32; j > 0; j >>= 1) {
+                    const uint64_t oh = s256_shfl_xor(hi, j), ol = s256_shfl_xor(lo, j);
+                    hi = ((lane & j) == 0) ? (hi > oh ? hi : oh) : (hi < oh ? hi : oh);
+                    lo = ((lane & j) == 0) ? (lo > ol ? lo : ol) : (lo < ol ? lo : ol);
+                }
+                const uint64_t hprev = s256_shfl_up1(hi), lprev = s256_shfl_up1(lo);
+                const uint64_t hlast = __builtin_amdgcn_readlane((uint32_t)hi, 63) |
+                                       ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(hi >> 32), 63) << 32);
+                const bool keep_h = hi != 0ull && (lane == 0 || hi != hprev);
+                const bool keep_l = lo != 0ull && lo != (lane == 0 ? hlast : lprev);
+                const unsigned long long mh = __ballot(keep_h), ml = __ballot(keep_l);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const int nh = __popcll(mh);
+                ws[lane] = 0ull;
+                ws[64 + lane] = 0ull;
+                if (keep_h) ws[__popcll(mh & below)] = hi;
+                if (keep_l) ws[nh + __popcll(ml & below)] = lo;
+                cur = ws[lane];
             }
-            const uint64_t prev = s256_shfl_up1(v);
-            const bool keep = v != 0ull && (lane == 0 || v != prev);
-            const unsigned long long km = __ballot(keep);
-            const int pos = __popcll(km & ((1ull << lane) - 1ull));
-            ws[lane] = 0ull;
-            if (keep) ws[pos] = v;            // LDS operations of one wave complete in order
-            cur = lane < S256_KSEL ? ws[lane] : 0ull;
         }
-        if (lane < S256_KSEL) list[lane] = cur;
-        if (lane == S256_KSEL - 1) L.wkey[r] = cur;           // 0 while the list is not full
+        if (lane < KSEL) list[lane] = cur;
+        if (lane == KSEL - 1) L.wkey[r] = cur;                // 0 while the list is not full
         if (lane < top_m)                                       // publish this slice's best scores (see s256_refresh_bounds)
             __hip_atomic_store(gtop_mine + (long)(q0 + r) * gtop_stride + lane, (uint32_t)(cur >> 32), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(cur >> 32), S256_KSEL - 1);
+        const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(cur >> 32), KSEL - 1);
         if (lane == 0 && last != 0u) {
             // this slice's KSEL-th best is a lower bound of the query's final KSEL-th best: publish it
             // for the other slices of the same query (stale reads only admit a few more candidates)
@@ -223,6 +261,7 @@ struct Scan256Args {
     unsigned long long* stats;    // optional counters: [0] drains, [1] queued entries, [2] retry passes, [3] fragments scanned slowly
 };
 
+template <int KSEL>
 __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     S256Lds L;
@@ -232,7 +271,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     L.end = L.start + 256;
     L.ctrl = L.end + 256;
     L.scratch = (uint64_t*)(L.ctrl + 16);
-    L.wkey = L.scratch + 8 * 64;
+    L.wkey = L.scratch + 8 * 128;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -248,8 +287,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     const long t1 = (t0 + per) < tiles ? (t0 + per) : tiles;
     const long row_begin = p.n_begin + t0 * 256;            // first gallery row of this slice
     const uint32_t idx_base = (uint32_t)row_begin;
-    uint64_t* mypart = p.part + (long)sp * S256_KSEL;
-    const long part_row_stride = (long)p.lists_per_query * S256_KSEL;
+    uint64_t* mypart = p.part + (long)sp * KSEL;
+    const long part_row_stride = (long)p.lists_per_query * KSEL;
 
     if (tid < 256) L.tau[tid] = tid < qvalid ? orderable_f32(p.tau_g[q0 + tid]) : INFINITY;
     if (tid < 256) L.wkey[tid] = 0ull;
@@ -355,21 +394,21 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
         }
         const bool overflow = qc > S256_QCAP;
         if (groups == 1 && !overflow && (t & 15) == 15)
-            s256_refresh_bounds(L, p.gtop, q0, qvalid, p.splits * p.top_m, tid, p.stats);
+            s256_refresh_bounds<KSEL>(L, p.gtop, q0, qvalid, p.splits * p.top_m, tid, p.stats);
         if (p.stats && tid == 0) {
             if (overflow || groups > 1) atomicAdd(p.stats + 2, 1ull);
             if (overflow || groups > 1 || qc >= drain_thr || t + 1 >= t1) { atomicAdd(p.stats + 0, 1ull); atomicAdd(p.stats + 1, (unsigned long long)qc); }
         }
         if (groups == 1 && !overflow) {
             if (qc >= drain_thr || t + 1 >= t1) {
-                s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g, p.gtop + sp * p.top_m, p.splits * p.top_m,
+                s256_drain<KSEL>(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g, p.gtop + sp * p.top_m, p.splits * p.top_m,
                            p.top_m);
             }
             ++t;
             continue;
         }
         // retry mode (or entering it): merge what was queued, then recompute this tile / its next column group
-        s256_drain(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g, p.gtop + sp * p.top_m, p.splits * p.top_m,
+        s256_drain<KSEL>(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g, p.gtop + sp * p.top_m, p.splits * p.top_m,
                            p.top_m);
         if (overflow) {
             groups = groups < 32 ? groups * 2 : 32;
@@ -396,11 +435,13 @@ unsigned long long* topk_scan256_stats() {
     return g_scan_stats;
 }
 void topk_scan256_set_debug(int d) { g_scan_dbg = d; }
-int topk_scan256_top_m(int splits) { return splits >= 128 ? 1 : (splits > 32 ? 2 : 4); }
+// per-slice scores published for the cross-slice bound: enough that splits x top_m comfortably exceeds KSEL
+int topk_scan256_top_m(int splits, int ksel) { return (splits >= 128 ? 1 : (splits > 32 ? 2 : 4)) * (ksel / 32); }
 
 int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
-                        int splits, uint64_t* part, int lists_per_query, uint32_t* tau_g, uint32_t* gtop,
+                        int splits, uint64_t* part, int lists_per_query, uint32_t* tau_g, uint32_t* gtop, int ksel,
                         hipStream_t st) {
+    REVO_REQUIRE(ksel == 32 || ksel == 64, "search: the 256 x 256 scan keeps 32 or 64 candidates per query");
     REVO_REQUIRE(D % 64 == 0 && ldq % 8 == 0 && ldg % 8 == 0, "search: D must be a multiple of 64");
     REVO_REQUIRE(N < (1ll << 32), "search: a shard holds at most 2^32 rows");
     REVO_REQUIRE(256l * ldg * 2 < (1l << 31) && 256l * ldq * 2 < (1l << 31), "search: row too long for the DMA window");
@@ -410,13 +451,16 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
     if (Q <= 0 || N <= n_begin) return 0;
     static bool done = false;
     if (!done) {
-        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)topk_scan256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)topk_scan256_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           S256_LDS));
+        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)topk_scan256_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            S256_LDS));
         done = true;
     }
     Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, part, lists_per_query, tau_g, g_scan_dbg, gtop,
-                  topk_scan256_top_m(splits), (g_scan_dbg & 2) ? topk_scan256_stats() : nullptr};
-    hipLaunchKernelGGL(topk_scan256_kernel, dim3((Q + 255) / 256, splits), dim3(G256_THREADS), S256_LDS, st, a);
+                  topk_scan256_top_m(splits, ksel), (g_scan_dbg & 2) ? topk_scan256_stats() : nullptr};
+    if (ksel == 32) hipLaunchKernelGGL(topk_scan256_kernel<32>, dim3((Q + 255) / 256, splits), dim3(G256_THREADS), S256_LDS, st, a);
+    else hipLaunchKernelGGL(topk_scan256_kernel<64>, dim3((Q + 255) / 256, splits), dim3(G256_THREADS), S256_LDS, st, a);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

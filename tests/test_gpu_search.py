@@ -22,11 +22,20 @@ def _gold():
     return np.load(os.path.join(HERE, "golden", "search_4096x1024.npz"))
 
 
-def _check(out, ref, atol=1e-3):
+def _check(out, ref, atol=1e-3, near_tie=0.0):
+    """near_tie > 0: two neighbours whose oracle scores differ by less than that may come out swapped
+    (the GPU re-scores with an fp32 fma chain, the oracle rounds an fp64 sum once: ~1e-7 apart)."""
     s, i, c = (t.cpu().numpy() for t in out)
     rs, ri, rc = ref
     assert np.array_equal(c, rc)
-    assert np.array_equal(i, ri)
+    if near_tie > 0.0 and not np.array_equal(i, ri):
+        for q in np.where((i != ri).any(1))[0]:
+            assert sorted(i[q].tolist()) == sorted(ri[q].tolist()), q
+            for j in np.where(i[q] != ri[q])[0]:
+                jj = int(np.where(ri[q] == i[q][j])[0][0])
+                assert abs(jj - j) == 1 and abs(rs[q][jj] - rs[q][j]) <= near_tie, (q, j)
+    else:
+        assert np.array_equal(i, ri)
     fin = np.isfinite(rs)
     assert np.array_equal(np.isfinite(s), fin)
     assert np.abs(s[fin] - rs[fin]).max(initial=0.0) <= atol
@@ -247,4 +256,59 @@ def test_properties_at_full_gallery_1m(dev):
     bs, bi, bc = G.search(big, k)
     assert torch.equal(bi[:Q], i) and torch.equal(bs[:Q], s)
     assert (bc == k).all() and (bs[:, :-1] >= bs[:, 1:]).all()
+    G.close()
+
+
+@pytest.mark.parametrize("k", [17, 20, 50])
+def test_large_scan_path_wide_k(dev, k):
+    """limit 20 and 50 (the reference UI's other choices, ui.py:342) keep 64 candidates per query: the
+    256 x 256 scan's 64-entry lists (128-element merges with de-duplication in the drains)."""
+    for (N, Q, D) in [(70001, 64, 128), (120000, 300, 64)]:
+        rng = np.random.default_rng(N + Q + k)
+        gal = rng.standard_normal((N, D), dtype=np.float32)
+        gal[N // 3: N // 3 + 90] = gal[N // 3]             # a tie group longer than the 64-entry list
+        qr = rng.standard_normal((Q, D), dtype=np.float32)
+        qr[0] = gal[N // 3]
+        G = engine.Gallery(D, N, device=0)
+        G.add(torch.from_numpy(gal).to(dev))
+        out = G.search(torch.from_numpy(qr).to(dev), k, None)
+        _check(out, osearch.search(gal, qr, k), atol=1e-5, near_tie=3e-7)
+        assert out[1][0].cpu().tolist() == list(range(N // 3, N // 3 + k))
+        _check(G.search(torch.from_numpy(qr).to(dev), k, 0.25), osearch.search(gal, qr, k, 0.25), atol=1e-5, near_tie=3e-7)
+        G.close()
+
+
+def test_wide_k_adversarial_overflow_and_ties(dev):
+    """The queue-overflow ladder, the re-queued duplicates and the all-ties gallery with 64-entry lists."""
+    k = 50
+    N, D, Q = 40000, 64, 300
+    rng = np.random.default_rng(5)
+    qr = rng.standard_normal((Q, D), dtype=np.float32)
+    ramp = np.linspace(0.0, 4.0, N, dtype=np.float32)[:, None]
+    gal = qr.mean(0)[None] * ramp + rng.standard_normal((N, D), dtype=np.float32)
+    G = engine.Gallery(D, N, device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    _check(G.search(torch.from_numpy(qr).to(dev), k), osearch.search(gal, qr, k), atol=1e-5, near_tie=3e-7)
+    G.close()
+    base = rng.standard_normal(D).astype(np.float32)
+    qr = base[None] + 0.3 * rng.standard_normal((Q, D), dtype=np.float32)
+    gal = np.concatenate([rng.standard_normal((8192, D), dtype=np.float32),
+                          base[None] + 0.3 * rng.standard_normal((9000, D), dtype=np.float32)])
+    G = engine.Gallery(D, len(gal), device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    # 9000 rows within a few 1e-5 of each other per rank: with 50 of 64 candidates used, a handful of
+    # queries fall outside the bf16 selection margin (DESIGN.md, "Why bit-exact indices with a bf16 scan":
+    # 3 of 300 here) and neighbours tie to 1e-8.  What must hold: the ladder terminates, every returned
+    # score is an exact cosine, and the score lists agree with the oracle's to 5e-4 (north star: 1e-3).
+    s, i, c = (t.cpu().numpy() for t in G.search(torch.from_numpy(qr).to(dev), k))
+    rs, ri, rc = osearch.search(gal, qr, k)
+    assert np.array_equal(c, rc) and int(i.min()) >= 8192
+    assert np.abs(s - rs).max() <= 5e-4
+    assert np.mean([len(set(a) & set(b)) for a, b in zip(i.tolist(), ri.tolist())]) >= k - 0.5
+    G.close()
+    v = rng.standard_normal(D).astype(np.float32)
+    G = engine.Gallery(D, 30000, device=0)
+    G.add(torch.from_numpy(np.repeat(v[None], 30000, axis=0)).to(dev))
+    s, i, c = G.search(torch.from_numpy(np.stack([v, -v])).to(dev), k)
+    assert i[0].cpu().tolist() == list(range(k)) and i[1].cpu().tolist() == list(range(k))
     G.close()
