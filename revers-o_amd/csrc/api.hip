@@ -140,6 +140,7 @@ struct LayerW {
     float *b_qkv, *b_o, *b_fc1, *b_fc2, *ln1w, *ln1b, *ln2w, *ln2b, *ls1, *ls2;
 };
 
+constexpr size_t SPLITK_WS_ELEMS = 16u << 20;     // 64 MiB of fp32 per stream
 struct revo_vit {
     revo_vit_cfg cfg;
     int device = 0, max_batch = 0, S = 0, G2 = 0, Kp = 0, hd = 0, phd = 0, debug_layers = -1;
@@ -155,6 +156,7 @@ struct revo_vit {
     bf16_t *patches = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr, *pool_att = nullptr,
            *pool_h = nullptr, *pool_m = nullptr, *pool_ob = nullptr;
     float *x = nullptr, *pool_o = nullptr, *feat = nullptr;
+    float* splitk_ws = nullptr;        // fp32 partial planes of the split-K residual GEMMs, one region per stream
     int dual_stream = 0;               // revo_vit_set_dual_stream
     hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
@@ -340,6 +342,7 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
     CHECK_RC(v->dalloc(&v->pool_m, B * M));
     CHECK_RC(v->dalloc(&v->pool_ob, B * W));
     CHECK_RC(v->dalloc(&v->feat, B * D));
+    CHECK_RC(v->dalloc(&v->splitk_ws, 2 * SPLITK_WS_ELEMS));
     REVO_HIP_CHECK(hipDeviceSynchronize());
     *out = v.release();
     return 0;
@@ -455,9 +458,9 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
         { ProfScope ps("layernorm", st);
           CHECK_RC(launch_layernorm(v->x, W, L.ln2w, L.ln2b, c.ln_eps, rows, W, v->h, W, 1, st)); }
         CHECK_RC(gemm("gemm_fc1", EPI_BF16_GELU, v->h, W, L.w_fc1, W, rows, Md, W, v->mlp, Md, L.b_fc1, nullptr, st));
-        // the qkv buffer is idle during the MLP: scratch for the split-K tail of fc2
+        // scratch for the split-K forms of fc2 (leftover rows at large batch, the whole GEMM at small batch)
         CHECK_RC(gemm("gemm_fc2", EPI_RESID_F32, v->mlp, Md, L.w_fc2, Md, rows, W, Md, v->x, W, L.b_fc2, L.ls2, st,
-                      (float*)v->qkv, (long)rows * 3 * W / 2));
+                      vv->splitk_ws + (b0 ? SPLITK_WS_ELEMS : 0), (long)SPLITK_WS_ELEMS));
     }
     if (v->debug_layers >= 0) return 0;   // parity hook: residual stream only
 

@@ -564,8 +564,9 @@ static int try_splitk_tail(const GemmArgs& a, hipStream_t st) {
         if (pm * pn < per) { per = pm * pn; gy = g; }
     }
     int S = 32 / per;
-    S = S > 4 ? 4 : S;
-    if (S < 2 || nt / S < 8) return 0;
+    S = S > 8 ? 8 : S;
+    while (S > 1 && nt / S < 8) --S;
+    if (S < 2) return 0;
     const long plane = (long)a.M * a.N;
     if (plane * S > a.ws_elems) return 0;
     static bool attr_done = false;
@@ -599,6 +600,15 @@ template <int EPI>
 static int launch_t(const GemmArgs& a, hipStream_t st) {
     if (a.prefer256 && g_force_tile == 0 && 256l * a.lda * 2 < (1l << 31) && 256l * a.ldb * 2 < (1l << 31))
         return launch_256<EPI>(a, st);
+    if constexpr (EPI == EPI_RESID_F32) {
+        // a few tiles with a long K (fc2 of one to a few images): the K loop is a latency chain, cut it across CUs
+        if (g_force_tile == 0 && a.M > 64 && a.K >= 2048 && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) <= 96 &&
+            256l * a.lda * 2 < (1l << 31) && 256l * a.ldb * 2 < (1l << 31)) {
+            const int rc2 = try_splitk_tail(a, st);
+            if (rc2 < 0) return rc2;
+            if (rc2 == 1) return 0;
+        }
+    }
     if constexpr (EPI != EPI_PATCH && EPI != EPI_BF16_ROPE) {
         if (use_skinny(a)) return launch_skinny<EPI>(a, st);
     }
