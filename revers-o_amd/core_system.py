@@ -20,6 +20,7 @@ There is no CPU fallback: constructing the class without a GPU raises.
 import os
 import shutil
 import threading
+import time
 import uuid
 from concurrent.futures import ThreadPoolExecutor
 
@@ -66,6 +67,7 @@ class SimpleReverso:
         # True: decoded frames are uploaded as they are and squash-resized by the HIP kernel
         # (same pixels as the host PIL resize, bit for bit); False: PIL resize in the decode pool
         self.device_resize = bool(device_resize)
+        self.checkpoint_interval_s = 30.0     # a checkpoint rewrites all vectors collected so far
         self.db_root = db_root
         self.max_batch = int(max_batch)
         self.detector = detector
@@ -235,23 +237,32 @@ class SimpleReverso:
             emb = self.pe_model.embed(u8.to(self.device, non_blocking=True))
         return emb.cpu()
 
-    def _embed_regions(self, pil, metas):
-        """One vector per region: the frame goes to the device once, every region's bbox is
-        cropped + squash-resized there (bit-identical to PIL crop().resize()), then one
-        batched forward.  Mask-derived boxes are inclusive (core_system.py:411)."""
-        if not metas:
+    def _embed_regions_batch(self, items):
+        """items: [(pil, metas)].  One vector per region of every image: the frames go to the device once,
+        every region's bbox is cropped + squash-resized there in one launch (bit-identical to PIL
+        crop().resize()), then forwards of max_batch crops.  Mask-derived boxes are inclusive
+        (core_system.py:411).  Returns fp32 CPU tensor [n_regions, D] in item order."""
+        frames, boxes = [], []
+        for pil, metas in items:
+            if not metas:
+                continue
+            fi = len(frames)
+            frames.append(torch.from_numpy(np.array(pil, dtype=np.uint8)).to(self.device, non_blocking=True))
+            for m in metas:
+                x0, y0, x1, y1 = m["bbox"]
+                if m.get("mask_status") == "processed":
+                    x1, y1 = x1 + 1, y1 + 1
+                boxes.append((fi,) + pp.clamp_box((x0, y0, x1, y1), pil.width, pil.height))
+        if not boxes:
             return torch.empty((0, self.pe_model.cfg.out_dim))
-        frame = torch.from_numpy(np.array(pil, dtype=np.uint8)).to(self.device)
-        boxes = []
-        for m in metas:
-            x0, y0, x1, y1 = m["bbox"]
-            if m.get("mask_status") == "processed":
-                x1, y1 = x1 + 1, y1 + 1
-            boxes.append((0,) + pp.clamp_box((x0, y0, x1, y1), pil.width, pil.height))
         with self._lock:
-            u8 = pp.crop_resize_device(frame, boxes, self.pe_model.cfg.image_size)
+            u8 = pp.crop_resize_device(frames, boxes, self.pe_model.cfg.image_size)
             emb = self.pe_model.embed(u8)
         return emb.cpu()
+
+    def _embed_regions(self, pil, metas):
+        """One vector per region of one image (see _embed_regions_batch)."""
+        return self._embed_regions_batch([(pil, metas)])
 
     def extract_embeddings(self, image):
         """core_system.py:320-429: one forward of the full image, every kept region receives
@@ -292,11 +303,22 @@ class SimpleReverso:
         """core_system.py:461-648, with batched embedding and a working checkpoint."""
         status_messages = []
 
+        class _Log(str):
+            """What log_status returns: the whole log so far, joined only if somebody looks at it
+            (the reference joins on every call, which is quadratic in the number of images)."""
+            def __new__(cls, parts):
+                o = super().__new__(cls, "")
+                o._parts = parts
+                return o
+
+            def __str__(self):
+                return "\n".join(self._parts)
+
         def log_status(message, progress_value=None):
             status_messages.append(message)
             if progress_callback:
                 progress_callback(message, progress_value)
-            return "\n".join(status_messages)
+            return _Log(status_messages)
 
         os.makedirs(self.db_root, exist_ok=True)
         db_path = os.path.join(self.db_root, database_name)
@@ -321,11 +343,11 @@ class SimpleReverso:
                            if any(f.lower().endswith(e) for e in IMAGE_EXTENSIONS)]
         image_files.sort()
         if not image_files:
-            return log_status(f"❌ No images found in {folder_path}")
+            return str(log_status(f"❌ No images found in {folder_path}"))
         if resume_from_checkpoint:
             image_files = [f for f in image_files if f not in processed_files]
             if not image_files:
-                return log_status("✅ All files already processed. Database is complete.")
+                return str(log_status("✅ All files already processed. Database is complete."))
         log_status(f"📊 Found {len(image_files)} images to process", 0.1)
         if include_subfolders:
             log_status("📂 Including images from subfolders")
@@ -341,24 +363,47 @@ class SimpleReverso:
             except Exception as e:
                 log_status(f"⚠️ Error saving checkpoint: {str(e)}")
 
+        host_resize = not self.device_resize and not (self.region_mode == "crop" and not use_direct_pe)
+        model_size = self.pe_model.cfg.image_size
+
         def open_rgb(path):
+            """pool task: decode (and, on the host-resize path, squash-resize) one file"""
             try:
-                return Image.open(path).convert("RGB")
+                im = Image.open(path).convert("RGB")
+                return im, (pp.resize_u8(im, model_size) if host_resize else None)
             except Exception as e:           # per-image failure: logged and skipped (core_system.py:585-591)
-                return e
+                return e, None
 
         try:
             B = self.max_batch
+
+            def submit(s0):
+                return [self._decode_pool.submit(open_rgb, p) for p in image_files[s0:s0 + B]]
+
+            # the next batch is decoded by the pool while the device embeds the current one
+            pending = submit(0)
+            last_ckpt = time.monotonic()
             for s in range(0, len(image_files), B):
                 if self._stop_requested:
                     log_status("🛑 Stop requested. Saving progress...")
                     checkpoint()
                     return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
                 paths = image_files[s:s + B]
-                pils = list(self._decode_pool.map(open_rgb, paths))
-                good = [(p, im) for p, im in zip(paths, pils) if not isinstance(im, Exception)]
-                embs = self._embed_pils([im for _, im in good]) if good else None
+                futures, pending = pending, (submit(s + B) if s + B < len(image_files) else [])
+                results = [f.result() for f in futures]
+                pils = [r[0] for r in results]
+                crop_mode = self.region_mode == "crop" and not use_direct_pe
+                good = [r for r in results if not isinstance(r[0], Exception)]
+                # global vectors of the whole batch in one forward (not needed when every region is cropped)
+                embs = None
+                if good and not crop_mode:
+                    if host_resize:
+                        with self._lock:
+                            embs = self.pe_model.embed(torch.stack([u8 for _, u8 in good]).to(self.device, non_blocking=True)).cpu()
+                    else:
+                        embs = self._embed_pils([im for im, _ in good])
                 gi = 0
+                batch_items = []                       # (path, filename, pil, metas, global vector or None)
                 for j, (path, im) in enumerate(zip(paths, pils)):
                     i = s + j
                     filename = os.path.basename(path)
@@ -368,8 +413,10 @@ class SimpleReverso:
                         log_status(f"❌ Error processing {filename}: {str(im)}")
                         failed += 1
                         continue
-                    e = embs[gi]
-                    gi += 1
+                    e = None
+                    if embs is not None:
+                        e = embs[gi]
+                        gi += 1
                     if use_direct_pe:
                         metas = [{"region_id": str(uuid.uuid4()), "bbox": [0, 0, im.width, im.height], "area_ratio": 1.0,
                                   "detection_index": 0, "confidence": 1.0, "detected_class": "full_image"}]
@@ -381,26 +428,33 @@ class SimpleReverso:
                             failed += 1
                             continue
                         _, metas = self._region_metadata(im, self.detected_regions)
-                        if self.region_mode == "crop":
-                            region_vecs = self._embed_regions(im, metas)
                         log_status(f"✅ Found {n_reg} regions, extracted {len(metas)} embeddings in {filename}")
                     for m in metas:
                         m["image_source"] = path
                         m["filename"] = filename
                         m["original_region_id"] = m.get("region_id", str(uuid.uuid4()))
                         m["region_id"] = str(uuid.uuid4())
-                    if self.region_mode == "crop" and not use_direct_pe:
-                        self._partial_embeddings.extend(v.clone() for v in region_vecs)
+                    batch_items.append((path, im, metas, e))
+                # region crops of the whole batch: frames go to the device once, one crop + resize launch,
+                # forwards of max_batch crops
+                region_vecs = self._embed_regions_batch([(im, metas) for _, im, metas, _ in batch_items]) if crop_mode else None
+                ri = 0
+                for path, im, metas, e in batch_items:
+                    if crop_mode:
+                        self._partial_embeddings.extend(region_vecs[ri + t].clone() for t in range(len(metas)))
+                        ri += len(metas)
                     else:
                         self._partial_embeddings.extend(e.clone() for _ in metas)
                     self._partial_metadata.extend(metas)
                     processed += 1
                     self._last_processed_file = path
-                    if processed % 10 == 0 or i == len(image_files) - 1:
-                        checkpoint()
+                # checkpoints rewrite everything collected so far: at most one per interval, and one at the end
+                if time.monotonic() - last_ckpt >= self.checkpoint_interval_s or s + B >= len(image_files):
+                    checkpoint()
+                    last_ckpt = time.monotonic()
 
             if not self._partial_embeddings:
-                return log_status("❌ No embeddings extracted from any images")
+                return str(log_status("❌ No embeddings extracted from any images"))
 
             vector_dim = self._partial_embeddings[0].shape[0]
             collection_name = f"simple_reverso_{database_name}"
