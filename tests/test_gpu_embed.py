@@ -204,3 +204,18 @@ def test_handles_release_device_memory(dev):
         cycle()
     torch.cuda.synchronize(); torch.cuda.empty_cache()
     assert used() - base <= 8 << 20, (used() - base)
+
+
+def test_g14_full_depth_sanity(dev):
+    """BASELINE.json configs[4]'s tower (PE-Core-G14-448: 50 blocks, width 1536, head_dim 96, no class
+    token, S = 1024) end to end: finite unit vectors, and an image's vector does not depend on its batch."""
+    cfg = reverso_amd.get_config("PE-Core-G14-448")
+    eng = engine.VitEngine.synthetic(cfg, seed=0, device=0, max_batch=8)
+    g = torch.Generator(device=dev).manual_seed(1)
+    img = torch.randint(0, 256, (8, 3, cfg.image_size, cfg.image_size), device=dev, dtype=torch.uint8, generator=g)
+    e = eng.embed(img)
+    assert torch.isfinite(e).all() and ((e.norm(dim=-1) - 1).abs() <= 1e-5).all()
+    one = eng.embed(img[3:4])
+    assert float((one[0] * e[3]).sum()) >= 0.99995
+    assert torch.equal(eng.embed(img), e)
+    eng.close()
