@@ -222,11 +222,13 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
     }
 }
 
-// 128 x 128 x 64 tile, 4 waves as 2 (M) x 2 (N), each 64 x 64.
-template <int EPI>
+// 128 x BN x 64 tile (BN = 128 or 64), 4 waves as 2 (M) x 2 (N), each 64 x BN/2.  BN = 64 halves the work
+// per workgroup so that two or three are resident per CU and hide each other's latency chains when the
+// problem has about as many 128 x 128 tiles as there are CUs (the out-proj leftover rows).
+template <int EPI, int BN = 128>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm128_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 128, BN = 128, MF = 4, NF = 4;
+    constexpr int BM = 128, MF = 4, NF = BN / 32;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int s = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -247,8 +249,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm128_kernel(GemmArgs p) {
 #pragma unroll
         for (int n = 0; n < NF; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    gemm_mainloop<BM, BN, MF, NF>(la, lb, smem, p.K, wave, lane, wr * 64, wc * 64, acc);
-    gemm_epilogue<EPI, MF, NF>(p, m0 + wr * 64, n0 + wc * 64, lane, acc);
+    gemm_mainloop<BM, BN, MF, NF>(la, lb, smem, p.K, wave, lane, wr * 64, wc * (BN / 2), acc);
+    gemm_epilogue<EPI, MF, NF>(p, m0 + wr * 64, n0 + wc * (BN / 2), lane, acc);
 }
 
 // 256 x 256 x 64 tile, 8 waves as 2 (M) x 4 (N), each 128 x 64; see gemm256_core.h.
@@ -649,15 +651,20 @@ static int launch_t(const GemmArgs& a, hipStream_t st) {
 
 template <int EPI>
 static int launch_128(const GemmArgs& a, hipStream_t st) {
-    constexpr int LDS = 2 * (128 + 128) * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)gemm128_kernel<EPI>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)gemm128_kernel<EPI, 128>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * 128));
         attr_done = true;
     }
     const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    hipLaunchKernelGGL(gemm128_kernel<EPI>, dim3(tiles), dim3(GEMM_THREADS), LDS, st, a);
+    // about one 128 x 128 tile per CU: one latency-bound workgroup each; 128 x 64 tiles put two or three on a CU
+    if (g_force_tile == 0 && tiles > 128 && tiles <= 384 && a.K >= 512 && a.N % 64 == 0) {
+        const int tiles64 = ((a.M + 127) / 128) * ((a.N + 63) / 64);
+        hipLaunchKernelGGL((gemm128_kernel<EPI, 64>), dim3(tiles64), dim3(GEMM_THREADS), 2 * (128 + 64) * 128, st, a);
+    } else {
+        hipLaunchKernelGGL((gemm128_kernel<EPI, 128>), dim3(tiles), dim3(GEMM_THREADS), 2 * (128 + 128) * 128, st, a);
+    }
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

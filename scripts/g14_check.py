@@ -23,3 +23,7 @@ for B in (1, 8, 32):
     for _ in range(5): eng.embed(x)
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
     print(f"B={B}: {ms:.2f} ms/forward, {B / ms * 1e3:.1f} img/s, {cfg.flops_per_image() * B / ms / 1e9:.0f} TFLOP/s", flush=True)
+engine.prof_reset(); engine.prof_enable(1)
+for _ in range(3): eng.embed(img)
+torch.cuda.synchronize(); engine.prof_enable(0)
+print({k: round(v["ms"] / 3, 3) for k, v in sorted(engine.prof_report().items())})

@@ -308,3 +308,30 @@ def test_gemm_splitk_tail_residual(lib, dev, gemm_tile, M, N, K):
     rows = torch.cat([torch.arange(0, 512, device=dev), torch.arange(M - 4200, M, device=dev)])
     ref = x0[rows] + gamma * (a[rows].float() @ b.float().T + bias)
     assert (outs[0][rows] - ref).abs().max().item() <= 3e-3 * math.sqrt(K / 64)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 4096, 512), (900, 2368, 1024), (640, 3008, 576)])
+def test_gemm_128x64_variant_all_epilogues(lib, dev, gemm_tile, M, N, K):
+    """Between 128 and 384 tiles of 128 x 128 (about one per CU) the heuristic takes 128 x 64 tiles so that
+    several workgroups share a CU.  All four epilogues against an fp32 reference."""
+    if gemm_tile != 128:
+        pytest.skip("heuristic path: one run is enough")
+    _lib.check(lib.revo_op_set_gemm_tile(0))
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g, device=dev).bfloat16()
+    b = (torch.randn(N, K, generator=g, device=dev) * 0.1).bfloat16()
+    bias = torch.randn(N, generator=g, device=dev)
+    gamma = torch.rand(N, generator=g, device=dev) + 0.5
+    ref = a.float() @ b.float().T + bias
+    tol = 3e-3 * math.sqrt(K / 64)
+    c = torch.full((M, N), float("nan"), device=dev)
+    _gemm(lib, EPI_F32, a, b, c, bias)
+    assert (c - ref).abs().max().item() <= tol
+    cb = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
+    _gemm(lib, EPI_BF16_GELU, a, b, cb, bias)
+    gref = torch.nn.functional.gelu(ref)
+    assert (cb.float() - gref).abs().max().item() <= tol + 0.02 * gref.abs().max().item()
+    x0 = torch.randn(M, N, generator=g, device=dev)
+    x = x0.clone()
+    _gemm(lib, EPI_RESID_F32, a, b, x, bias, gamma)
+    assert (x - (x0 + gamma * ref)).abs().max().item() <= 2 * tol
