@@ -658,8 +658,9 @@ static int launch_128(const GemmArgs& a, hipStream_t st) {
         attr_done = true;
     }
     const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    // about one 128 x 128 tile per CU: one latency-bound workgroup each; 128 x 64 tiles put two or three on a CU
-    if (g_force_tile == 0 && tiles > 128 && tiles <= 384 && a.K >= 512 && a.N % 64 == 0) {
+    // at most about one 128 x 128 tile per CU: one latency-bound workgroup each; 128 x 64 tiles halve the work per
+    // K step of a workgroup and put two or three of them on a CU
+    if (g_force_tile == 0 && tiles <= 384 && a.K >= 512 && a.N % 64 == 0) {
         const int tiles64 = ((a.M + 127) / 128) * ((a.N + 63) / 64);
         hipLaunchKernelGGL((gemm128_kernel<EPI, 64>), dim3(tiles64), dim3(GEMM_THREADS), 2 * (128 + 64) * 128, st, a);
     } else {
