@@ -104,7 +104,8 @@ int32_t revo_op_set_gemm_tile(int32_t tile);
  * bits 4-7 = force the XCD arrangement (N-stripes 1, 2, 4 or 8; 0 = heuristic), bits 8-11 = force the
  * attention waves per workgroup, bit 12 = disable the GEMM tail split, bit 13 = skip the scan's selection
  * (wrong results), bit 14 = count scan events for revo_debug_scan_stats, bit 16 = one workgroup per tile instead of the
- * persistent 256 x 256 GEMM, bit 17 = no split-K for the leftover rows of a residual GEMM; 0 = normal */
+ * persistent 256 x 256 GEMM, bit 17 = no split-K for the leftover rows of a residual GEMM, bit 18 = 256 x 256 tiles also for
+ * problems with fewer than 100 of them; 0 = normal */
 int32_t revo_op_set_gemm_debug(int32_t flags);
 /* counters of the fused scan when debug bit 14 is set: drains, queued entries, retry passes, slow fragments */
 int32_t revo_debug_scan_stats(int64_t* out4);

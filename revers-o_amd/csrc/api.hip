@@ -741,6 +741,7 @@ extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
     revo::topk_scan256_set_debug((flags >> 13) & 7);
     revo::gemm_set_persistent(((flags >> 16) & 1) ? 0 : 1);
     revo::gemm_set_splitk(((flags >> 17) & 1) ? 0 : 1);
+    revo::gemm_set_min_tiles256(((flags >> 18) & 1) ? 0 : 100);
     return 0;
 }
 extern "C" int32_t revo_debug_scan_stats(int64_t* out4) {

@@ -514,11 +514,15 @@ static int launch_256(const GemmArgs& a, hipStream_t st) {
 static int g_force_tile = 0;   // 0 = heuristic, 128 / 256 = forced (tests, A/B timing)
 void gemm_force_tile(int t) { g_force_tile = t; }
 
+static int g_min_tiles256 = 100;
+void gemm_set_min_tiles256(int n) { g_min_tiles256 = n; }
 static bool use_256(const GemmArgs& a) {
     if (256l * a.lda * 2 >= (1l << 31) || 256l * a.ldb * 2 >= (1l << 31)) return false;   // 32-bit DMA offsets per tile window
     if (g_force_tile == 256) return true;
     if (g_force_tile == 128) return false;
-    return a.M >= 1024 && a.N >= 256;
+    // the big tile needs enough tiles to occupy the chip: below ~100 of them (a couple of images) the
+    // 128-row kernels spread the same work over more CUs
+    return a.M >= 1024 && a.N >= 256 && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= g_min_tiles256;
 }
 
 bool gemm_uses_wide_epilogue(int M, int N, long lda, long ldb, long ldc) {

@@ -63,6 +63,7 @@ int launch_attention(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, i
 // has_cls: row 0 is the class token and may be scheduled apart from the patch rows (same result)
 int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, int hd, int has_cls,
                         hipStream_t st);
+void gemm_set_min_tiles256(int n);  // timing experiments only (default 100)
 void gemm_set_splitk(int on);       // timing experiments only (1 = default)
 void gemm_set_persistent(int on);   // timing experiments only (1 = default)
 void attention_force_nw(int nw);   // timing experiments only (0 = heuristic)
