@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=6)
     ap.add_argument("--dual-stream", type=int, default=0, help="1: embed as two half batches on two HIP streams")
+    ap.add_argument("--timed-events", type=int, default=3,
+                    help="profiler mode inside the timed region: 3 = HIP events around every fourth launch of each body-GEMM "
+                         "class (default; the events of mode 2, every launch, cost 0.4 ms of a 28.6 ms step), 0 = none")
     ap.add_argument("--debug-flags", type=int, default=0, help="A/B experiments: revo_op_set_gemm_debug flags (0 = product path)")
     ap.add_argument("--search-queries", type=int, default=10000,
                     help="extra, untimed-by-the-headline measurement: a batch of this many queries against the local "
@@ -137,10 +140,11 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # Timed region: HIP events (on the launch stream) only around the roofline kernel class, the four
-    # body GEMMs: an event pair costs a few microseconds of stream time, and there are ~250 kernels a step.
+    # Timed region: HIP events (on the launch stream) only around the roofline kernel class, the four body
+    # GEMMs, and only around every fourth launch of each (24 identical layers): an event pair costs a few
+    # microseconds of stream time (all ~250 kernels of a step: 1 ms; the 96 GEMMs: 0.4 ms; sampled: 0.1 ms).
     engine.prof_reset()
-    engine.prof_enable(2)
+    engine.prof_enable(args.timed_events)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()

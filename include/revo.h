@@ -119,8 +119,9 @@ int32_t revo_op_f32_to_bf16(const float* src, int64_t ld_src, void* dst_bf16, in
                             int32_t cols, void* stream);
 
 /* ---- per-kernel-class device timing (HIP events on the launch stream) for bench.py.
- * on: 0 = off, 1 = every kernel class, 2 = only the four body GEMM classes (the roofline kernel);
- * an event pair costs a few microseconds of stream time per kernel, so the timed region uses 2. */
+ * on: 0 = off, 1 = every kernel class, 2 = only the four body GEMM classes (the roofline kernel),
+ * 3 = every fourth launch of each of those classes (all layers have the same shapes);
+ * an event pair costs a few microseconds of stream time per kernel, so the timed region uses 3. */
 int32_t revo_prof_enable(int32_t on);
 int32_t revo_prof_reset(void);
 /* writes a JSON object {"class": {"launches": n, "ms": t}, ...} into buf */

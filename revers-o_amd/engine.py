@@ -252,7 +252,8 @@ def search(queries, k=5, score_threshold=None, gallery=None):
 
 # ---- profiler ---------------------------------------------------------------
 def prof_enable(on=True):
-    """on: False/0 off, True/1 every kernel class, 2 only the body GEMMs (cheap enough for a timed region)."""
+    """on: False/0 off, True/1 every kernel class, 2 only the body GEMMs, 3 every fourth launch of each
+    body-GEMM class (cheap enough for a timed region)."""
     _lib.load().revo_prof_enable(int(on))
 
 
