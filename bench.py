@@ -189,7 +189,7 @@ def main():
     except Exception:
         traffic = None
     roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "kernel": "gemm256_kernel",
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "kernel": "gemm256p_kernel (+ the leftover-row kernels of the same linear layer; one layer call = one launch)",
                 "avg_launch_ms": avg_ms, "launches": gemm_launches,
                 "algorithmic_flops_per_launch": flops_per_launch}
     # the search scan is HBM bound at this query count: report it next to the GEMM
