@@ -261,7 +261,9 @@ struct Scan256Args {
     unsigned long long* stats;    // optional counters: [0] drains, [1] queued entries, [2] retry passes, [3] fragments scanned slowly
 };
 
-template <int KSEL>
+// ROWS: 0 = all 256 query rows of a tile may be valid; 64 / 128 = the whole search has at most that many
+// queries (one query tile), and the main loop skips the MFMA work of the rows that cannot be valid.
+template <int KSEL, int ROWS>
 __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     S256Lds L;
@@ -319,10 +321,9 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
             for (int m = 0; m < 8; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // at most 64 queries: three quarters of the tile's MFMA work would multiply zero rows
-            // (a 128-row mode as a third instantiation costs the main path 7 %: register allocation)
-            if (qvalid <= 64) gemm256_mainloop<64>(A, B, smem, p.D, wave, lane, acc);
-            else gemm256_mainloop<0>(A, B, smem, p.D, wave, lane, acc);
+            // few queries: most of the tile's MFMA work would multiply zero rows (separate kernel
+            // instantiations: inside one kernel a second main loop costs the main path its register allocation)
+            gemm256_mainloop<ROWS>(A, B, smem, p.D, wave, lane, acc);
 
             if (groups == 1 && t + 1 < t1) {
                 // next gallery tile: rebased descriptors (any gallery size), DMA in flight during the selection
@@ -449,18 +450,30 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
     const long per = (tiles + splits - 1) / splits;
     REVO_REQUIRE(per * 256 <= (1l << 24), "search: a gallery slice holds at most 2^24 rows; use more splits");
     if (Q <= 0 || N <= n_begin) return 0;
-    static bool done = false;
-    if (!done) {
-        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)topk_scan256_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           S256_LDS));
-        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)topk_scan256_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           S256_LDS));
-        done = true;
-    }
     Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, part, lists_per_query, tau_g, g_scan_dbg, gtop,
                   topk_scan256_top_m(splits, ksel), (g_scan_dbg & 2) ? topk_scan256_stats() : nullptr};
-    if (ksel == 32) hipLaunchKernelGGL(topk_scan256_kernel<32>, dim3((Q + 255) / 256, splits), dim3(G256_THREADS), S256_LDS, st, a);
-    else hipLaunchKernelGGL(topk_scan256_kernel<64>, dim3((Q + 255) / 256, splits), dim3(G256_THREADS), S256_LDS, st, a);
+    const dim3 grid((Q + 255) / 256, splits), block(G256_THREADS);
+#define S256_LAUNCH(KS, RW)                                                                                    \
+    do {                                                                                                       \
+        static bool attr_ = false;                                                                             \
+        if (!attr_) {                                                                                          \
+            REVO_HIP_CHECK(hipFuncSetAttribute((const void*)topk_scan256_kernel<KS, RW>,                        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, S256_LDS));         \
+            attr_ = true;                                                                                      \
+        }                                                                                                      \
+        hipLaunchKernelGGL((topk_scan256_kernel<KS, RW>), grid, block, S256_LDS, st, a);                       \
+    } while (0)
+    const int rows_mode = Q <= 64 ? 64 : (Q <= 128 ? 128 : 0);
+    if (ksel == 32) {
+        if (rows_mode == 64) S256_LAUNCH(32, 64);
+        else if (rows_mode == 128) S256_LAUNCH(32, 128);
+        else S256_LAUNCH(32, 0);
+    } else {
+        if (rows_mode == 64) S256_LAUNCH(64, 64);
+        else if (rows_mode == 128) S256_LAUNCH(64, 128);
+        else S256_LAUNCH(64, 0);
+    }
+#undef S256_LAUNCH
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
