@@ -2,6 +2,8 @@
 against a plain PyTorch fp32 reference of the same op on the same inputs."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -335,3 +337,40 @@ def test_gemm_128x64_variant_all_epilogues(lib, dev, gemm_tile, M, N, K):
     x = x0.clone()
     _gemm(lib, EPI_RESID_F32, a, b, x, bias, gamma)
     assert (x - (x0 + gamma * ref)).abs().max().item() <= 2 * tol
+
+
+def test_gemm_random_shapes_through_the_heuristic(lib, dev, gemm_tile):
+    """Seeded random problem sizes with the tile heuristic in charge: whatever kernel family a size lands in
+    (skinny, 128 x 64, 128 x 128, 256 x 256 per tile or persistent, split-K) must agree with an fp32 reference."""
+    if gemm_tile != 128:
+        pytest.skip("heuristic path: one run is enough")
+    _lib.check(lib.revo_op_set_gemm_tile(0))
+    rng = np.random.default_rng(2025)
+    for case in range(40):
+        M = int(rng.choice([1, 3, 17, 64, 65, 127, 128, 300, 577, 1024, 1154, 2308, 4160, 9232]))
+        M = max(1, M + int(rng.integers(-2, 3)))
+        N = int(rng.choice([4, 64, 132, 256, 768, 1024, 1280, 3072])) + 4 * int(rng.integers(0, 3))
+        K = 64 * int(rng.choice([1, 2, 4, 9, 16, 24, 48, 64]))
+        epi = int(rng.integers(0, 4))
+        g = torch.Generator(device=dev).manual_seed(case)
+        a = torch.randn(M, K, generator=g, device=dev).bfloat16()
+        b = (torch.randn(N, K, generator=g, device=dev) * 0.1).bfloat16()
+        bias = torch.randn(N, generator=g, device=dev)
+        gamma = torch.rand(N, generator=g, device=dev) + 0.5
+        ref = a.float() @ b.float().T + bias
+        tol = 3e-3 * math.sqrt(K / 64)
+        if epi == EPI_F32:
+            c = torch.full((M, N), float("nan"), device=dev)
+            _gemm(lib, epi, a, b, c, bias)
+            err = (c - ref).abs().max().item()
+        elif epi == EPI_RESID_F32:
+            x0 = torch.randn(M, N, generator=g, device=dev)
+            c = x0.clone()
+            _gemm(lib, epi, a, b, c, bias, gamma)
+            err = (c - (x0 + gamma * ref)).abs().max().item() / 2
+        else:
+            want = torch.nn.functional.gelu(ref) if epi == EPI_BF16_GELU else ref
+            c = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
+            _gemm(lib, epi, a, b, c, bias)
+            err = (c.float() - want).abs().max().item() - 0.02 * want.abs().max().item()
+        assert err <= tol, (case, M, N, K, epi, err)
