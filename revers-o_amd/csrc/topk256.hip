@@ -488,7 +488,7 @@ int topk_scan256_splits(int Q, long rows) {
     for (int s = 1; s <= 512; ++s) {
         if (s > tiles) break;
         const long per = (tiles + s - 1) / s;
-        if (s > 1 && per < 8) break;
+        if (s > 1 && per < 3) break;         // (short slices are fine: the pre-pass and the cross-slice bound seed the admission scores)
         const long wgs = (long)qtiles * s;
         const long rounds = (wgs + 255) / 256;
         const double eff = (double)wgs / (double)(rounds * 256);
