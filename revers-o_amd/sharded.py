@@ -55,13 +55,23 @@ class ShardedSearch:
         self.local_rows = int(local_rows)
         self.offset, self.total_rows = self._exchange_offsets()
 
+    def _all_gather(self, out, inp):
+        """all_gather_into_tensor; device tensors on a gloo group (a rehearsal of the N > 1 path on one GPU,
+        or a CPU-only interconnect) are staged through host memory, RCCL takes them as they are."""
+        if inp.is_cuda and dist.get_backend(self.group) != "nccl":
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, inp.contiguous().cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, inp.contiguous(), group=self.group)
+
     def gather_queries(self, local_queries):
         """Data-parallel embed leaves [B, D] on every rank; all ranks need all queries."""
         if self.world == 1:
             return local_queries
         out = torch.empty((self.world * local_queries.shape[0], local_queries.shape[1]),
                           dtype=local_queries.dtype, device=local_queries.device)
-        dist.all_gather_into_tensor(out, local_queries.contiguous(), group=self.group)
+        self._all_gather(out, local_queries)
         return out
 
     def search(self, queries, k, threshold=None):
@@ -73,6 +83,6 @@ class ShardedSearch:
         # concatenated along dim 0 (the layout both RCCL and gloo accept), viewed as [world, Q, k]
         ps = torch.empty((self.world * Q, k), dtype=s.dtype, device=s.device)
         pi = torch.empty((self.world * Q, k), dtype=i.dtype, device=i.device)
-        dist.all_gather_into_tensor(ps, s.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(pi, i.contiguous(), group=self.group)
+        self._all_gather(ps, s)
+        self._all_gather(pi, i)
         return self.merge(ps.view(self.world, Q, k), pi.view(self.world, Q, k), k, threshold)

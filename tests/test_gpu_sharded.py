@@ -1,0 +1,70 @@
+"""GPU: the N > 1 product wiring (DP embed -> gather queries -> every rank scans its gallery shard with
+the HIP kernels -> gather per-shard top-k -> HIP merge) rehearsed with TWO processes on one GPU.
+The interconnect is gloo with host staging here (RCCL wants one device per rank; the driver's multi-GPU
+run uses it); everything else is the code path of bench.py --gpus N."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import reverso_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmp, N, B, k):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import reverso_amd  # noqa: F401
+    from reverso_amd import engine, sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    eng = engine.VitEngine.synthetic("PE-Tiny-T14-56", seed=0, device=0, max_batch=B, randomize_affine=True)
+    D = eng.cfg.out_dim
+    g = torch.Generator().manual_seed(99)
+    gal = torch.randn(N, D, generator=g)
+    imgs = torch.randint(0, 256, (world * B, 3, 56, 56), generator=g, dtype=torch.uint8)
+    sizes = [N // world + (1 if r < N % world else 0) for r in range(world)]
+    lo = sum(sizes[:rank])
+    G = engine.Gallery(D, sizes[rank], device=0)
+    G.add(gal[lo:lo + sizes[rank]].to(dev))
+    ss = sharded.ShardedSearch.from_gallery(G)
+    assert ss.offset == lo and ss.total_rows == N
+    emb = eng.embed(imgs[rank * B:(rank + 1) * B].to(dev))          # this rank's images
+    q = ss.gather_queries(emb)                                        # everybody's embeddings, rank order
+    out = {}
+    for thr in (None, 0.02):
+        s, i, c = ss.search(q, k, thr)
+        out[str(thr)] = (s.cpu().numpy(), i.cpu().numpy(), c.cpu().numpy())
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), q=q.cpu().numpy(),
+             **{f"{t}_{n}": v for t, (a, b, c) in out.items() for n, v in (("s", a), ("i", b), ("c", c))})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_the_single_process_search(tmp_path, dev):
+    import torch.multiprocessing as mp
+    from reverso_amd import engine
+    N, B, k, world = 40001, 4, 10, 2
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), N, B, k), nprocs=world, join=True)
+    eng = engine.VitEngine.synthetic("PE-Tiny-T14-56", seed=0, device=0, max_batch=world * B, randomize_affine=True)
+    D = eng.cfg.out_dim
+    g = torch.Generator().manual_seed(99)
+    gal = torch.randn(N, D, generator=g)
+    imgs = torch.randint(0, 256, (world * B, 3, 56, 56), generator=g, dtype=torch.uint8)
+    q = torch.cat([eng.embed(imgs[r * B:(r + 1) * B].to(dev)) for r in range(world)])
+    G = engine.Gallery(D, N, device=0)
+    G.add(gal.to(dev))
+    for thr in (None, 0.02):
+        s, i, c = (t.cpu().numpy() for t in G.search(q, k, thr))
+        for rank in range(world):
+            got = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+            assert np.array_equal(got["q"], q.cpu().numpy())
+            assert np.array_equal(got[f"{thr}_i"], i) and np.array_equal(got[f"{thr}_c"], c)
+            assert np.array_equal(got[f"{thr}_s"], s)
