@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--timed-events", type=int, default=3,
                     help="profiler mode inside the timed region: 3 = HIP events around every fourth launch of each body-GEMM "
                          "class (default; the events of mode 2, every launch, cost 0.4 ms of a 28.6 ms step), 0 = none")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the "
+                                                      "multi-rank code path on fewer GPUs, together with --one-gpu)")
+    ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--debug-flags", type=int, default=0, help="A/B experiments: revo_op_set_gemm_debug flags (0 = product path)")
     ap.add_argument("--search-queries", type=int, default=10000,
                     help="extra, untimed-by-the-headline measurement: a batch of this many queries against the local "
@@ -125,10 +128,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     cfg = reverso_amd.get_config(args.variant)
     D = cfg.out_dim
