@@ -220,3 +220,18 @@ def test_g14_full_depth_sanity(dev):
     assert float((one[0] * e[3]).sum()) >= 0.99995
     assert torch.equal(eng.embed(img), e)
     eng.close()
+
+
+@pytest.mark.parametrize("B", [10, 12])
+def test_mid_size_batches_are_deterministic(dev, B):
+    """Batches whose GEMMs have more 128-row tiles than fit on the chip at once (B16-224, 10-12 images:
+    576-684 workgroups): repeated forwards must give the same bits, block by block and at the end."""
+    cfg = reverso_amd.get_config("PE-Core-B16-224")
+    eng = engine.VitEngine.synthetic(cfg, seed=2, device=0, max_batch=16)
+    g = torch.Generator().manual_seed(9)
+    u8 = torch.randint(0, 256, (B, 3, 224, 224), generator=g, dtype=torch.uint8).to(dev)
+    r = [eng.residual_after(u8, 1).cpu() for _ in range(3)]
+    assert torch.equal(r[0], r[1]) and torch.equal(r[0], r[2])
+    e = [eng.embed(u8).cpu() for _ in range(3)]
+    assert torch.equal(e[0], e[1]) and torch.equal(e[0], e[2])
+    eng.close()
