@@ -374,3 +374,25 @@ def test_gemm_random_shapes_through_the_heuristic(lib, dev, gemm_tile):
             _gemm(lib, epi, a, b, c, bias)
             err = (c.float() - want).abs().max().item() - 0.02 * want.abs().max().item()
         assert err <= tol, (case, M, N, K, epi, err)
+
+
+def test_gemm_repeat_determinism_large_grids(lib, dev, gemm_tile):
+    """Every kernel family, grids larger than one resident set of workgroups: the same call five times
+    must give the same bits (no timing-dependent reads)."""
+    if gemm_tile != 128:
+        pytest.skip("heuristic path: one run is enough")
+    _lib.check(lib.revo_op_set_gemm_tile(0))
+    g = torch.Generator(device=dev).manual_seed(77)
+    for (M, N, K) in [(1970, 2304, 768), (2364, 3072, 768), (2167, 768, 3072), (4160, 1024, 1024), (9000, 1024, 4096),
+                      (36928, 1024, 1024), (64, 4096, 1024), (1000, 4096, 512)]:
+        a = torch.randn(M, K, generator=g, device=dev).bfloat16()
+        b = (torch.randn(N, K, generator=g, device=dev) * 0.05).bfloat16()
+        bias = torch.randn(N, generator=g, device=dev)
+        x0 = torch.randn(M, N, generator=g, device=dev)
+        for epi in (EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32):
+            outs = []
+            for _ in range(5):
+                c = x0.clone() if epi in (EPI_RESID_F32, EPI_F32) else torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
+                _gemm(lib, epi, a, b, c, bias)
+                outs.append(c)
+            assert all(torch.equal(o, outs[0]) for o in outs[1:]), (M, N, K, epi)
