@@ -98,6 +98,11 @@ int32_t revo_topk_merge(const float* scores, const int64_t* indices, int32_t par
 /* ---- single kernels, exposed for parity tests and micro-benchmarks (device pointers) */
 int32_t revo_op_gemm(int32_t epilogue, const void* a_bf16, int64_t lda, const void* b_bf16, int64_t ldb, int32_t m,
                      int32_t n, int32_t k, void* c, int64_t ldc, const float* bias, const float* gamma, void* stream);
+/* C bf16 = rope(A . B^T + bias): the QKV projection with the axial rotary embedding of the first
+ * rope_cols columns fused into the epilogue (cos_sin: [seq][head_dim/2] (cos, sin) pairs; row r is token r % seq) */
+int32_t revo_op_gemm_rope(const void* a_bf16, int64_t lda, const void* b_bf16, int64_t ldb, int32_t m, int32_t n, int32_t k,
+                          void* c_bf16, int64_t ldc, const float* bias, const float* cos_sin, int32_t seq,
+                          int32_t head_dim, int32_t rope_cols, void* stream);
 /* 0 = size heuristic (default), 128 or 256 = force that GEMM tile (tests, A/B timing) */
 int32_t revo_op_set_gemm_tile(int32_t tile);
 /* timing experiments only (scripts/): bit 0 = skip the epilogue stores, bit 1 = skip the main loop,

@@ -53,6 +53,7 @@ SIGNATURES = {
     "revo_search_topk": (_i32, [_p, _p, _i32, _i32, _i32, _f32, _i64, _p, _p, _p, _p]),
     "revo_topk_merge": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p]),
     "revo_op_gemm": (_i32, [_i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p]),
+    "revo_op_gemm_rope": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
     "revo_op_set_gemm_tile": (_i32, [_i32]),
     "revo_op_set_gemm_debug": (_i32, [_i32]),
     "revo_debug_scan_stats": (_i32, [C.POINTER(C.c_int64)]),

@@ -449,18 +449,14 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
         const LayerW& L = v->layers[i];
         { ProfScope ps("layernorm", st);
           CHECK_RC(launch_layernorm(v->x, W, L.ln1w, L.ln1b, c.ln_eps, rows, W, v->h, W, 1, st)); }
-        if (gemm_uses_wide_epilogue(rows, 3 * W, W, W, 3 * W)) {
-            // K4 + K5: bias and the 2-D rotary embedding of q and k in the GEMM epilogue
+        {
+            // K4 + K5: bias and the 2-D rotary embedding of q and k in the GEMM epilogue (every tile shape)
             GemmArgs a{};
             a.A = v->h; a.lda = W; a.B = L.w_qkv; a.ldb = W; a.M = rows; a.N = 3 * W; a.K = W; a.C = v->qkv;
             a.ldc = 3 * W; a.bias = L.b_qkv; a.rope_cs = v->rope_cs; a.rope_S = S; a.rope_hd = v->hd;
             a.rope_cols = 2 * W;
             ProfScope ps("gemm_qkv", st);
             CHECK_RC(launch_gemm(EPI_BF16_ROPE, a, st));
-        } else {
-            CHECK_RC(gemm("gemm_qkv", EPI_BF16, v->h, W, L.w_qkv, W, rows, 3 * W, W, v->qkv, 3 * W, L.b_qkv, nullptr, st));
-            ProfScope ps("rope", st);
-            CHECK_RC(launch_rope(v->qkv, 3 * W, v->rope_cs, rows, S, W, c.heads, st));
         }
         { ProfScope ps("attention", st);
           CHECK_RC(launch_attention_ex(v->qkv, 3 * W, v->att, W, B, S, c.heads, v->hd, c.use_cls, st)); }
@@ -741,6 +737,16 @@ extern "C" int32_t revo_op_gemm(int32_t epi, const void* a, int64_t lda, const v
     }
     return gemm("gemm_op", epi, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, m, n, k, c, ldc, bias, gamma,
                 (hipStream_t)stream, ws, OP_WS_ELEMS);
+    API_END
+}
+extern "C" int32_t revo_op_gemm_rope(const void* a, int64_t lda, const void* b, int64_t ldb, int32_t m, int32_t n,
+                                     int32_t k, void* c, int64_t ldc, const float* bias, const float* cos_sin,
+                                     int32_t seq, int32_t head_dim, int32_t rope_cols, void* stream) {
+    API_BEGIN
+    revo::GemmArgs g{};
+    g.A = (const bf16_t*)a; g.lda = lda; g.B = (const bf16_t*)b; g.ldb = ldb; g.M = m; g.N = n; g.K = k; g.C = c; g.ldc = ldc;
+    g.bias = bias; g.rope_cs = (const float2*)cos_sin; g.rope_S = seq; g.rope_hd = head_dim; g.rope_cols = rope_cols;
+    return revo::launch_gemm(revo::EPI_BF16_ROPE, g, (hipStream_t)stream);
     API_END
 }
 extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {

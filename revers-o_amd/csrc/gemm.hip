@@ -60,7 +60,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int m_base, int
                 const f32x4 b = *(const f32x4*)(p.bias + col);
                 v += b;
             }
-            if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+            if (EPI == EPI_BF16_ROPE) {
+                {
+                    // K5 on the accumulator layout: a lane holds two interleaved pairs of one token.  The values are
+                    // rounded to bf16 first, as the row-coalesced epilogue of the 256 x 256 kernel does (it rotates what
+                    // it reads back from its bf16 slab) and as the stand-alone RoPE kernel sees them: same bits on
+                    // every path.  Branch-free on purpose (columns past rope_cols rotate by the identity): with the
+                    // rotation inside a divergent `if`, hipcc 7.2's code for this epilogue gave run-to-run different
+                    // results in one element per fragment once the grid exceeded one resident set of workgroups.
+                    const bool rot = col < p.rope_cols;
+                    const float2* t = p.rope_cs + (long)(row % p.rope_S) * (p.rope_hd >> 1) + ((col % p.rope_hd) >> 1);
+                    const f32x4 tc = *(const f32x4*)t;
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const float x0 = bf16_to_f32(f32_to_bf16(v[2 * h2])), x1 = bf16_to_f32(f32_to_bf16(v[2 * h2 + 1]));
+                        const float cx = rot ? tc[2 * h2] : 1.0f, cy = rot ? tc[2 * h2 + 1] : 0.0f;
+                        v[2 * h2] = x0 * cx - x1 * cy;
+                        v[2 * h2 + 1] = x1 * cx + x0 * cy;
+                    }
+                }
+            }
+            if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE) {
                 if (EPI == EPI_BF16_GELU) v = gelu_erf4(v);
                 uint2 o;
                 o.x = pack_bf16x2(v[0], v[1]);
@@ -311,8 +331,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256_kernel(GemmArgs p) {
         //  allocates the fp32 variants' main loop so badly that the accumulators spill)
         const bool wide = (p.N & 7) == 0 && (p.ldc & 7) == 0;
         if (wide) gemm256_epilogue<EPI>(p, smem + wave * 16384, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, lane, acc);
-        else gemm_epilogue<EPI == EPI_BF16_ROPE ? EPI_BF16 : EPI, 8, 4>(p, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64,
-                                                                         lane, acc);
+        else gemm_epilogue<EPI, 8, 4>(p, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, lane, acc);
     }
 }
 
@@ -381,7 +400,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
         } else {
             const bool wide = (p.N & 7) == 0 && (p.ldc & 7) == 0;
             if (wide) gemm256_epilogue<EPI>(p, slab, mb, nb, lane, acc);
-            else gemm_epilogue<EPI == EPI_BF16_ROPE ? EPI_BF16 : EPI, 8, 4>(p, mb, nb, lane, acc);
+            else gemm_epilogue<EPI, 8, 4>(p, mb, nb, lane, acc);
         }
         if (!more) break;
         __builtin_amdgcn_s_barrier();      // every wave is out of its slab before A stage 1 is refilled
@@ -686,11 +705,11 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
         case EPI_F32: return launch_t<EPI_F32>(a, st);
         case EPI_PATCH: return launch_t<EPI_PATCH>(a, st);
         case EPI_BF16_ROPE:
-            if (!gemm_uses_wide_epilogue(a.M, a.N, a.lda, a.ldb, a.ldc)) {
-                revo_set_error("gemm: the fused RoPE epilogue needs the 256 x 256 kernel (caller must check)");
+            if (!a.rope_cs || a.rope_S <= 0 || a.rope_hd <= 0 || a.rope_hd % 8 || a.rope_cols % a.rope_hd || a.rope_cols > a.N) {
+                revo_set_error("gemm: the RoPE epilogue needs a table, rope_hd % 8 == 0 and rope_cols a multiple of rope_hd");
                 return -2;
             }
-            return launch_256<EPI_BF16_ROPE>(a, st);
+            return launch_t<EPI_BF16_ROPE>(a, st);
     }
     revo_set_error("gemm: unknown epilogue");
     return -2;

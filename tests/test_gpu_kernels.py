@@ -396,3 +396,31 @@ def test_gemm_repeat_determinism_large_grids(lib, dev, gemm_tile):
                 _gemm(lib, epi, a, b, c, bias)
                 outs.append(c)
             assert all(torch.equal(o, outs[0]) for o in outs[1:]), (M, N, K, epi)
+
+
+@pytest.mark.parametrize("M,S,H,hd", [(577, 577, 4, 64), (1970, 197, 12, 64), (2364, 197, 12, 64), (4616, 577, 4, 64),
+                                      (1024, 1024, 2, 96), (36928, 577, 2, 64), (130, 65, 2, 64)])
+def test_gemm_with_fused_rope_equals_gemm_then_rope(lib, dev, gemm_tile, M, S, H, hd):
+    """The QKV projection with RoPE in the epilogue (any tile family) == the plain projection followed by the
+    stand-alone RoPE kernel, bit for bit, and is the same on every repeat."""
+    W = H * hd
+    N, K = 3 * W, 256
+    g = torch.Generator(device=dev).manual_seed(M + hd)
+    a = torch.randn(M, K, generator=g, device=dev).bfloat16()
+    b = (torch.randn(N, K, generator=g, device=dev) * 0.1).bfloat16()
+    bias = torch.randn(N, generator=g, device=dev)
+    cs = torch.randn(S, hd // 2, 2, generator=g, device=dev)
+    st = _lib.current_stream()
+    outs = []
+    for _ in range(4):
+        c = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        _lib.check(lib.revo_op_gemm_rope(_lib.ptr(a), K, _lib.ptr(b), K, M, N, K, _lib.ptr(c), N, _lib.ptr(bias), _lib.ptr(cs), S, hd,
+                                         2 * W, st), "gemm_rope")
+        torch.cuda.synchronize()
+        outs.append(c)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    c0 = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
+    _gemm(lib, EPI_BF16, a, b, c0, bias)
+    _lib.check(lib.revo_op_rope(_lib.ptr(c0), N, _lib.ptr(cs), M, S, W, H, st))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], c0)
