@@ -235,3 +235,21 @@ def test_mid_size_batches_are_deterministic(dev, B):
     e = [eng.embed(u8).cpu() for _ in range(3)]
     assert torch.equal(e[0], e[1]) and torch.equal(e[0], e[2])
     eng.close()
+
+
+def test_l14_every_batch_size_family_agrees(dev):
+    """PE-Core-L14-336 at batch sizes that land in different GEMM tile families and leftover handlings
+    (1, 2, 3, 5, 9, 17, 33 images): every forward is repeatable bit for bit, and an image's vector is the
+    same (up to bf16 noise) whatever batch it is embedded in."""
+    cfg = reverso_amd.get_config("PE-Core-L14-336")
+    eng = engine.VitEngine.synthetic(cfg, seed=0, device=0, max_batch=64, randomize_affine=True)
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (33, 3, 336, 336), generator=g, dtype=torch.uint8).to(dev)
+    full = eng.embed(u8)
+    for B in (1, 2, 3, 5, 9, 17, 33):
+        a = eng.embed(u8[:B])
+        b = eng.embed(u8[:B])
+        assert torch.equal(a, b), B
+        cos = (a * full[:B]).sum(-1)
+        assert float(cos.min()) >= 0.99995, (B, float(cos.min()))
+    eng.close()
