@@ -3,9 +3,9 @@
 // (K9).  Replaces the SDPA / nn.MultiheadAttention calls inside upstream
 // encode_image (reference call site core_system.py:442).
 //
-// Body kernel: one workgroup = 4 waves = 128 query rows of one (image, head);
-// each wave owns 32 query rows.  K/V tiles of 64 keys are register-staged into
-// a double-buffered LDS image.  Scores are computed transposed (S^T = K . Q^T,
+// Body kernel: one workgroup = up to 8 waves of one (image, head); each wave owns
+// 32 query rows.  K/V tiles of 64 keys arrive by LDS-DMA into a ring of swizzled
+// LDS images.  Scores are computed transposed (S^T = K . Q^T,
 // v_mfma_f32_32x32x16_bf16) so a lane owns ONE query column: the online-softmax
 // row statistics are lane-local (one cross-half exchange), and the exponentiated
 // accumulator is fed straight back as the B operand of O^T = V^T . P^T with no
@@ -366,8 +366,8 @@ int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B
     const int lo = (has_cls && S > 1 && (S - 1 + 63) / 64 < (S + 63) / 64) ? 1 : 0;
     const int rows = S;
     // Waves per workgroup.  A workgroup's time per key tile is set by the staging / barrier /
-    // softmax latency chain, not by how many of its waves hold query rows (measured, L14: 8 waves
-    // 0.216 ms, 6 waves 0.244 ms, 4 waves 0.248 ms although 8 waves pad 576 rows to 768), so take
+    // softmax latency chain, not by how many of its waves hold query rows (measured, L14, current kernel:
+    // 8 waves 0.171 ms, 7 waves 0.187 ms, 6 waves 0.235 ms, 4 waves 0.184 ms although 8 waves pad 577 rows to 768), so take
     // the fewest workgroups per (image, head) and, among equals, the most waves (16 waves per CU).
     int best = 4, best_blocks = 1 << 30;
     for (int nw : {8, 7, 6, 4}) {
