@@ -6,7 +6,7 @@
 // 8 query rows (running KSEL-th best: a lower bound of the final one, so nothing that can
 // end up in the top KSEL is ever dropped).  Survivors are rare after the first tiles; they
 // are appended to a 2048-entry LDS queue as 64-bit entries  row | score | ~index.  When the
-// queue passes half full the workgroup drains it: a bitonic sort of the queue groups the
+// queue holds 1792 entries (or the slice ends) the workgroup drains it: a bitonic sort of the queue groups the
 // entries by query row (best first), and each row's best <= KSEL entries are merged into
 // that row's candidate list, which lives in global memory (L2 resident, touched only at
 // drains) because the 128 KiB main-loop image leaves no room for 256 lists in LDS.  The
