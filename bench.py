@@ -3,8 +3,9 @@
 
 One step = one batch of synthetic 336x336 images per GPU through the HIP embed
 path, then cosine top-10 of every embedding against the row-sharded 1M x 1024
-gallery (all-gather of queries, per-shard scan, all-gather of per-shard top-k,
-merge).  Inputs are resident in HBM when the timed region starts.
+gallery (all-gather of queries, per-shard scan, all-gather of the shards' admission
+scores, bounded fp32 re-score, all-gather of the packed per-shard top-k, merge).
+Inputs are resident in HBM when the timed region starts.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -110,14 +111,14 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=6)
-    ap.add_argument("--dual-stream", type=int, default=0, help="1: embed as two half batches on two HIP streams")
     ap.add_argument("--timed-events", type=int, default=3,
                     help="profiler mode inside the timed region: 3 = HIP events around every fourth launch of each body-GEMM "
                          "class (default; the events of mode 2, every launch, cost 0.4 ms of a 28.6 ms step), 0 = none")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank code path on fewer GPUs, together with --one-gpu)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--debug-flags", type=int, default=0, help="A/B experiments: revo_op_set_gemm_debug flags (0 = product path)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="A/B experiments: revo_op_set_gemm_debug flags (0 = product path); "
+                                                               "needs REVO_EXPERIMENTS=1 (librevo_exp.so, `make -C revers-o_amd/csrc exp`)")
     ap.add_argument("--search-queries", type=int, default=10000,
                     help="extra, untimed-by-the-headline measurement: a batch of this many queries against the local "
                          "gallery shard (BASELINE.json configs[3]); 0 disables it")
@@ -142,7 +143,6 @@ def main():
     D = cfg.out_dim
     B = args.batch
     eng = engine.VitEngine.synthetic(cfg, seed=0, device=local_rank, max_batch=B)
-    eng.set_dual_stream(bool(args.dual_stream))
     if args.debug_flags:
         from reverso_amd import _lib
         _lib.check(_lib.load().revo_op_set_gemm_debug(args.debug_flags))
@@ -225,45 +225,97 @@ def main():
                 "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "kernel": "gemm256p_kernel (+ the leftover-row kernels of the same linear layer; one layer call = one launch)",
                 "avg_launch_ms": avg_ms, "launches": gemm_launches,
                 "algorithmic_flops_per_launch": flops_per_launch}
-    # the search scan is HBM bound at this query count: report it next to the GEMM
+    # per layer type: the four linear layers of a block have different shapes and epilogues
+    W_, M_, rows_ = cfg.width, cfg.mlp_dim, B * cfg.seq
+    layer_flops = {"gemm_qkv": 2.0 * rows_ * W_ * 3 * W_, "gemm_out": 2.0 * rows_ * W_ * W_,
+                   "gemm_fc1": 2.0 * rows_ * W_ * M_, "gemm_fc2": 2.0 * rows_ * M_ * W_}
+    roofline["per_layer_tflops"] = {
+        c: round(layer_flops[c] / (prof_all[c]["ms"] / prof_all[c]["launches"] * 1e-3) / 1e12, 1)
+        for c in gemm_classes if prof_all.get(c, {}).get("launches")}
+    # The search at this query count is HBM bound.  `search_scan`: the fused scan kernel alone against the bytes IT
+    # reads (the gallery rows behind the pre-pass, the queries, the result); `search_total`: every kernel of the
+    # search (query normalise, pre-pass GEMM + selection, scan, final selection, fp32 re-score, merge) against
+    # the algorithmic bytes of the whole search, SURVEY.md 8(d): N*D*2 + Q*D*2 + Q*k*12.
+    Qs = B * world
+    plan = gal.search_plan(Qs, args.k) if shard_rows > 0 else None
     scan = prof_all.get("topk_scan", {})
-    if scan.get("launches"):
+    if scan.get("launches") and plan:
         scan_ms = scan["ms"] / scan["launches"]
-        scan_bytes = shard_rows * D * 2 + B * world * D * 2 + B * world * args.k * 12
+        scan_rows = shard_rows - plan["prepass_rows"]
+        scan_bytes = scan_rows * D * 2 + Qs * D * 2 + Qs * plan["ksel"] * 8
         roofline["search_scan"] = {"bound": "hbm", "achieved": scan_bytes / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": scan_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   "avg_launch_ms": scan_ms}
+                                   "avg_launch_ms": scan_ms, "rows_scanned": scan_rows,
+                                   "rows_in_prepass": plan["prepass_rows"], "slices": plan["slices"]}
+        search_classes = [c for c in prof_all if c.startswith("topk_") or c == "search_prep"]
+        tot_ms = sum(prof_all[c]["ms"] for c in search_classes) / bsteps
+        tot_bytes = shard_rows * D * 2 + Qs * D * 2 + Qs * args.k * 12
+        roofline["search_total"] = {"bound": "hbm", "achieved": tot_bytes / (tot_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": tot_bytes / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "ms_per_step": tot_ms, "kernels": sorted(search_classes)}
     classes_ms = {k: round(v["ms"] / bsteps, 4) for k, v in sorted(prof_all.items())}
 
-    # BASELINE.json configs[3] on this GPU's shard: a large query batch against the gallery, the
-    # MFMA-bound regime of the fused scan (north_star: >= 40 % of bf16 MFMA peak on the query x gallery GEMM).
-    # Measured after the headline region; it does not enter `value`.
+    # BASELINE.json configs[3]: a large batch of replicated queries against the whole gallery THROUGH the sharded
+    # search (per-shard scan, both all-gathers, merge) -- the MFMA-bound regime of the fused scan (north_star:
+    # >= 40 % of bf16 MFMA peak on the query x gallery GEMM, >= 6x at 8 GPUs).  Measured after the headline
+    # region; it does not enter `value`.
     search_big = None
     if args.search_queries > 0 and shard_rows > 0:
         Qn = args.search_queries
-        qg = torch.Generator(device=dev).manual_seed(7 + rank)
+        qg = torch.Generator(device=dev).manual_seed(7)               # the same queries on every rank
         qbig = torch.randn(Qn, D, generator=qg, device=dev)
-        gal.search(qbig, args.k)
-        torch.cuda.synchronize()
-        engine.prof_reset()
-        engine.prof_enable(True)
         reps = 3
+        ss.search(qbig, args.k)
+        fence()
         t1 = time.perf_counter()
         for _ in range(reps):
-            gal.search(qbig, args.k)
-        torch.cuda.synchronize()
+            ss.search(qbig, args.k)
+        fence()
         dts = (time.perf_counter() - t1) / reps
+        if world > 1:
+            tt = torch.tensor([dts], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = float(tt.item())
+        # the same searches with events around every kernel class: this rank's per-stage times
+        engine.prof_reset()
+        engine.prof_enable(True)
+        for _ in range(reps):
+            ss.search(qbig, args.k)
+        fence()
         engine.prof_enable(False)
         p2 = engine.prof_report()
         sc = p2.get("topk_scan", {})
         scan_ms_big = sc["ms"] / sc["launches"] if sc.get("launches") else None
-        fl = 2.0 * Qn * shard_rows * D
-        search_big = {"queries": Qn, "gallery_rows": shard_rows, "dim": D, "k": args.k,
-                      "search_ms": dts * 1e3, "queries_per_s": Qn / dts,
-                      "scan_ms": scan_ms_big,
+        planb = gal.search_plan(Qn, args.k)
+        fl = 2.0 * Qn * (shard_rows - planb["prepass_rows"]) * D       # the scan kernel's own rows
+        fl_all = 2.0 * Qn * args.gallery * D
+        search_big = {"queries": Qn, "gallery_rows": args.gallery, "shard_rows": shard_rows, "dim": D, "k": args.k,
+                      "sharded_ms": dts * 1e3, "queries_per_s": Qn / dts,
+                      "stage_ms_rank0": {c: round(v["ms"] / v["launches"], 4) for c, v in sorted(p2.items())},
+                      "scan_ms": scan_ms_big, "scan_rows": shard_rows - planb["prepass_rows"], "slices": planb["slices"],
                       "scan_tflops": fl / (scan_ms_big * 1e-3) / 1e12 if scan_ms_big else None,
                       "scan_frac_of_mfma_peak": fl / (scan_ms_big * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if scan_ms_big else None,
-                      "end_to_end_tflops": fl / dts / 1e12}
+                      "end_to_end_tflops_all_gpus": fl_all / dts / 1e12}
+        if world > 1 and rank == 0:
+            # the 1-GPU time of the SAME search in this process: the whole gallery on this one device
+            full = engine.Gallery(D, args.gallery, device=local_rank)
+            for r in range(world):
+                gr = torch.Generator(device=dev).manual_seed(42 + r)
+                rows_r = args.gallery // world + (1 if r < args.gallery % world else 0)
+                for s0 in range(0, rows_r, 131072):
+                    full.add(torch.randn(min(131072, rows_r - s0), D, generator=gr, device=dev))
+            full.search(qbig, args.k)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                full.search(qbig, args.k)
+            torch.cuda.synchronize()
+            one = (time.perf_counter() - t1) / reps
+            full.close()
+            search_big["one_gpu_ms_same_process"] = one * 1e3
+            search_big["speedup_vs_1gpu_model"] = one / dts
+        if world > 1:
+            dist.barrier()
 
     if rank == 0:
         res = {
@@ -273,10 +325,13 @@ def main():
             "config": {"workload": f"{cfg.name} embed of {B} synthetic {cfg.image_size}x{cfg.image_size} images per GPU "
                                    f"+ cosine top-{args.k} over a {args.gallery}x{D} gallery row-sharded {world}-way",
                        "batch_per_gpu": B, "gallery_rows": args.gallery, "dim": D, "k": args.k,
-                       "parallelism": f"dp{world} embed, gallery rows sharded {world}-way, all-gather top-k merge"},
+                       "parallelism": f"dp{world} embed, gallery rows sharded {world}-way, two all-gathers (admission scores, "
+                                      f"packed top-k) + merge"},
             "roofline": roofline,
             "kernel_ms_per_step": classes_ms,
             "embed_tflops": cfg.flops_per_image() * B * args.steps / dt / 1e12,
+            # whole step (embed + search) against the MFMA peak, SURVEY.md 8(d): images/s x FLOPs/image -- not the kernel-class `roofline.frac`
+            "embed_frac_of_peak": cfg.flops_per_image() * B * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS / world,
             "search_query_batch": search_big,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -14,9 +14,13 @@
  * failure; the message is available from revo_last_error() (thread-local).
  * Nothing throws across the boundary.  `stream` is a hipStream_t (NULL = the
  * default stream); work is enqueued asynchronously on it and the caller owns
- * ordering (revo_sync).  A handle is bound to one device and must not be used
- * from two threads at once; distinct handles are independent.  All device
- * pointers must belong to the handle's device.
+ * ordering (revo_sync).  A handle is bound to the device it was created on: every
+ * entry point that takes a handle makes that device current for the call and
+ * restores the caller's device on return, so handles on different GPUs can be
+ * used from one process; a handle must not be used from two threads at once;
+ * distinct handles are independent.  All device pointers (and the stream) passed
+ * with a handle must belong to the handle's device; functions without a handle
+ * (revo_topk_merge, revo_op_*, revo_preprocess_*) run on the current device.
  */
 #ifndef REVO_H
 #define REVO_H
@@ -36,6 +40,7 @@ typedef struct revo_vit_cfg {
     int32_t use_cls;    /* class token + (0,0) rope position */
     int32_t use_ls;     /* LayerScale tensors (ls_1.gamma / ls_2.gamma) present */
     float ln_eps, rope_theta;
+    int32_t pool_mlp_dim; /* hidden width of the attention-pool head's MLP (upstream: 4 * width, whatever mlp_dim is); 0 = 4 * width */
 } revo_vit_cfg;
 
 /* One checkpoint tensor: upstream name ("visual.conv1.weight", ...), fp32 values
@@ -60,14 +65,15 @@ int32_t revo_vit_destroy(revo_vit* vit);
  * the device; normalize != 0 applies embedding / embedding.norm() (core_system.py:447). */
 int32_t revo_vit_forward(revo_vit* vit, const void* images, int32_t image_dtype, int32_t batch, float* out,
                          int32_t normalize, void* stream);
-/* parity-test hooks: run only the first n transformer blocks (n < 0: all) and copy the
- * fp32 residual stream [batch*seq, width] of the last forward to dst (device). */
+/* parity-test hooks: run only the first n transformer blocks (n = -1: the whole forward; n = -2: stop after the
+ * patch embedding, before ln_pre) and copy the fp32 residual stream [batch*seq, width] of the last forward to dst (device). */
 int32_t revo_vit_set_debug_layers(revo_vit* vit, int32_t n_layers);
 int32_t revo_vit_read_residual(revo_vit* vit, int32_t batch, float* dst, void* stream);
+/* other intermediate buffers of the last forward (device to device): which = 0 the residual stream (fp32 [batch*seq, width]),
+ * 1 the output of the last LayerNorm -- ln_post after a whole forward -- (bf16 [batch*seq, width]), 2 the attention-pool
+ * output after its MLP residual, before proj (fp32 [batch, width]) */
+int32_t revo_vit_read_tap(revo_vit* vit, int32_t which, int32_t batch, void* dst, void* stream);
 int32_t revo_vit_seq_len(const revo_vit* vit);
-/* on != 0: forwards of >= 16 images run as two half batches on two streams (the caller's and an internal one,
- * fork/join by events on the caller's stream) so that one half's kernels fill the CUs the other half leaves idle */
-int32_t revo_vit_set_dual_stream(revo_vit* vit, int32_t on);
 
 /* ---- gallery: replaces recreate_collection(size=D, COSINE) + upsert (core_system.py:600-622) */
 int32_t revo_gallery_create(int32_t dim, int64_t capacity, int32_t device, int32_t keep_f32, revo_gallery** out);
@@ -89,11 +95,38 @@ int32_t revo_gallery_read(revo_gallery* g, int64_t start, int64_t n, float* dst,
 int32_t revo_search_topk(revo_gallery* g, const float* queries, int32_t n_queries, int32_t k, int32_t has_threshold,
                          float threshold, int64_t index_offset, float* scores, int64_t* indices, int32_t* counts,
                          void* stream);
+/* ---- the same search in two phases, for a gallery that is row-sharded over several GPUs / ranks (one shard per
+ * handle).  The reference has a single process and a single collection (core_system.py:659-664); this is the
+ * scale-out of that call.  Per rank:
+ *   1. revo_search_candidates: scan the shard (same kernels as revo_search_topk); the query's candidates stay in the
+ *      handle, and bounds [n_queries, top_m] receives the scan scores of the best top_m of them as order-preserving
+ *      uint32 (0 = none).  top_m <= revo_search_ksel(k); parts * top_m >= revo_search_ksel(k) makes the bound below tight.
+ *   2. all-gather `bounds` over the ranks -> all_bounds [parts, n_queries, top_m]   (RCCL; 4 * top_m bytes per query and rank)
+ *   3. revo_search_finish: only candidates that can still be among the best revo_search_ksel(k) of the WHOLE gallery
+ *      (scan score at or above the ksel-th largest published score) are re-scored in fp32; results as revo_search_topk.
+ *      all_bounds may be NULL (re-score every candidate).  Same queries, k and stream as step 1.
+ *   4. all-gather the per-rank results and revo_topk_merge / revo_topk_merge_packed them.
+ * The merged result equals the unsharded revo_search_topk of the concatenated gallery. */
+int32_t revo_search_ksel(int32_t k);     /* candidates the scan keeps per query for a top-k search (32 or 64) */
+/* how a search of n_queries against the gallery's current rows would run (reporting only): out4 = { 1 if the 256 x 256
+ * scan takes it (0: the small-gallery scan), rows covered by the pre-pass GEMM, gallery slices per query tile, ksel } */
+int32_t revo_search_plan(const revo_gallery* g, int32_t n_queries, int32_t k, int64_t* out4);
+int32_t revo_search_candidates(revo_gallery* g, const float* queries, int32_t n_queries, int32_t k, int32_t top_m,
+                               uint32_t* bounds, void* stream);
+int32_t revo_search_finish(revo_gallery* g, int32_t n_queries, int32_t k, int32_t has_threshold, float threshold,
+                           int64_t index_offset, const uint32_t* all_bounds, int32_t parts, int32_t top_m, float* scores,
+                           int64_t* indices, int32_t* counts, void* stream);
 /* merge `parts` result sets laid out [parts, n_queries, k] (the all-gathered per-shard
  * results of a row-sharded gallery) into one [n_queries, k] set, same ordering rule. */
 int32_t revo_topk_merge(const float* scores, const int64_t* indices, int32_t parts, int32_t n_queries, int32_t k,
                         int32_t has_threshold, float threshold, float* out_scores, int64_t* out_indices,
                         int32_t* out_counts, void* stream);
+
+/* One result set packed for a single all-gather: [n_queries, k] int64 indices followed by [n_queries, k] fp32 scores,
+ * padded to revo_topk_packed_bytes(n_queries, k) bytes; `packed` holds `parts` such blocks back to back. */
+int64_t revo_topk_packed_bytes(int32_t n_queries, int32_t k);
+int32_t revo_topk_merge_packed(const void* packed, int32_t parts, int32_t n_queries, int32_t k, int32_t has_threshold,
+                               float threshold, float* out_scores, int64_t* out_indices, int32_t* out_counts, void* stream);
 
 /* ---- single kernels, exposed for parity tests and micro-benchmarks (device pointers) */
 int32_t revo_op_gemm(int32_t epilogue, const void* a_bf16, int64_t lda, const void* b_bf16, int64_t ldb, int32_t m,
@@ -103,17 +136,24 @@ int32_t revo_op_gemm(int32_t epilogue, const void* a_bf16, int64_t lda, const vo
 int32_t revo_op_gemm_rope(const void* a_bf16, int64_t lda, const void* b_bf16, int64_t ldb, int32_t m, int32_t n, int32_t k,
                           void* c_bf16, int64_t ldc, const float* bias, const float* cos_sin, int32_t seq,
                           int32_t head_dim, int32_t rope_cols, void* stream);
-/* 0 = size heuristic (default), 128 or 256 = force that GEMM tile (tests, A/B timing) */
+/* ---- test hooks: kernel-variant selection.  Every variant computes the same result (split-K changes the
+ * fp32 summation order only).  Process-global, not thread-safe; the product path never calls them. */
+/* 0 = size heuristic (default), 128 or 256 = force that GEMM tile */
 int32_t revo_op_set_gemm_tile(int32_t tile);
-/* timing experiments only (scripts/): bit 0 = skip the epilogue stores, bit 1 = skip the main loop,
- * bits 4-7 = force the XCD arrangement (N-stripes 1, 2, 4 or 8; 0 = heuristic), bits 8-11 = force the
- * attention waves per workgroup, bit 12 = disable the GEMM tail split, bit 13 = skip the scan's selection
- * (wrong results), bit 14 = count scan events for revo_debug_scan_stats, bit 16 = one workgroup per tile instead of the
- * persistent 256 x 256 GEMM, bit 17 = no split-K for the leftover rows of a residual GEMM, bit 18 = 256 x 256 tiles also for
+/* bits 4-7 = force the XCD arrangement (N-stripes 1, 2, 4 or 8; 0 = heuristic), bits 8-11 = force the attention
+ * waves per workgroup, bit 12 = disable the GEMM tail split, bit 16 = one workgroup per tile instead of the persistent
+ * 256 x 256 GEMM, bit 17 = no split-K for the leftover rows of a residual GEMM, bit 18 = 256 x 256 tiles also for
  * problems with fewer than 100 of them; 0 = normal */
+int32_t revo_op_set_variant(int32_t flags);
+#ifdef REVO_EXPERIMENTS
+/* Timing experiments: compiled only into librevo_exp.so (`make exp`, used by scripts/), never into librevo.so.
+ * The variant bits above plus: bit 0 = skip the GEMM epilogue stores, bit 1 = skip the GEMM main loop,
+ * bit 13 = skip the scan's selection, bit 15 = skip the scan's slow path (all four: WRONG RESULTS),
+ * bit 14 = count scan events for revo_debug_scan_stats. */
 int32_t revo_op_set_gemm_debug(int32_t flags);
-/* counters of the fused scan when debug bit 14 is set: drains, queued entries, retry passes, slow fragments */
-int32_t revo_debug_scan_stats(int64_t* out4);
+/* counters of the fused scan when debug bit 14 is set */
+int32_t revo_debug_scan_stats(int64_t* out8);
+#endif
 int32_t revo_op_layernorm(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows,
                           int32_t width, void* out, int64_t ldo, int32_t out_is_bf16, void* stream);
 int32_t revo_op_rope(void* qkv_bf16, int64_t ld, const float* cos_sin, int32_t rows, int32_t seq, int32_t width,

@@ -128,3 +128,75 @@ def merge_topk(part_scores, part_indices, k, threshold=None):
         out_i[r, :c] = iv[o]
         out_c[r] = c
     return out_s, out_i, out_c
+
+
+# ---------------------------------------------------------------------------------------------
+# Two-phase sharded search (the build's scale-out of core_system.py:659-664; include/revo.h
+# "the same search in two phases").  A CPU restatement of what one rank does between the two
+# all-gathers, used by the gloo protocol test (tests/test_host_logic.py) and as the checker of
+# the HIP path's sharded results.  "Scan scores" here are the exact fp32 scores (the HIP scan
+# uses bf16 inputs; the protocol is the same).
+def f32_orderable(x):
+    """Order-preserving map float32 -> uint32 (include/revo.h: published scan scores)."""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32)
+    return np.where(u & np.uint32(0x80000000), ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+
+
+def packed_bytes(n_queries, k):
+    return (n_queries * k * 12 + 15) // 16 * 16
+
+
+class OracleShardBackend:
+    """The backend interface of revers-o_amd/sharded.py on numpy (rows already normalised)."""
+
+    def __init__(self, shard_rows):
+        import torch
+        self._torch = torch
+        self.shard = np.asarray(shard_rows, dtype=np.float32)
+        self._cand = None
+
+    def ksel(self, k):
+        return 32 if k <= 16 else 64
+
+    def packed_bytes(self, n_queries, k):
+        return packed_bytes(n_queries, k)
+
+    def candidates(self, queries, k, top_m):
+        q = np.asarray(queries, dtype=np.float32)
+        ksel = self.ksel(k)
+        s, i, c = search(self.shard, q, ksel, None, normalize=False)
+        self._cand = (q, s, i, c)
+        pub = np.zeros((q.shape[0], top_m), dtype=np.uint32)
+        for r in range(q.shape[0]):
+            n = min(int(c[r]), top_m)
+            pub[r, :n] = f32_orderable(s[r, :n])
+        return self._torch.from_numpy(pub.view(np.int32))
+
+    def finish(self, n_queries, k, all_bounds, index_offset):
+        q, s, i, c = self._cand
+        ksel = s.shape[1]
+        out = np.zeros((packed_bytes(n_queries, k),), dtype=np.uint8)
+        idx = np.full((n_queries, k), -1, dtype=np.int64)
+        sc = np.full((n_queries, k), -np.inf, dtype=np.float32)
+        for r in range(n_queries):
+            bound = np.uint32(0)
+            if all_bounds is not None:
+                pub = np.sort(all_bounds[:, r, :].numpy().view(np.uint32).reshape(-1))[::-1]
+                if pub.shape[0] >= ksel:
+                    bound = pub[ksel - 1]
+            keep = [j for j in range(int(c[r])) if f32_orderable(s[r, j]) >= bound][:k]
+            idx[r, :len(keep)] = i[r, keep] + index_offset
+            sc[r, :len(keep)] = s[r, keep]
+        out[: n_queries * k * 8] = idx.view(np.uint8).reshape(-1)
+        out[n_queries * k * 8: n_queries * k * 12] = sc.view(np.uint8).reshape(-1)
+        return self._torch.from_numpy(out)
+
+    def merge(self, packed_all, parts, n_queries, k, threshold):
+        pb = packed_bytes(n_queries, k)
+        buf = packed_all.numpy().reshape(parts, pb)
+        pi = np.stack([buf[p, : n_queries * k * 8].copy().view(np.int64).reshape(n_queries, k) for p in range(parts)])
+        ps = np.stack([buf[p, n_queries * k * 8: n_queries * k * 12].copy().view(np.float32).reshape(n_queries, k)
+                       for p in range(parts)])
+        s, i, c = merge_topk(ps, pi, k, threshold)
+        t = self._torch
+        return t.from_numpy(s), t.from_numpy(i), t.from_numpy(c)

@@ -17,7 +17,7 @@ class RevoError(RuntimeError):
 class VitCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "image_size", "patch_size", "width", "layers", "heads", "mlp_dim", "out_dim", "pool_heads",
-        "use_cls", "use_ls")] + [("ln_eps", C.c_float), ("rope_theta", C.c_float)]
+        "use_cls", "use_ls")] + [("ln_eps", C.c_float), ("rope_theta", C.c_float), ("pool_mlp_dim", C.c_int32)]
 
 
 class Tensor(C.Structure):
@@ -42,8 +42,8 @@ SIGNATURES = {
     "revo_vit_forward": (_i32, [_p, _p, _i32, _i32, _p, _i32, _p]),
     "revo_vit_set_debug_layers": (_i32, [_p, _i32]),
     "revo_vit_read_residual": (_i32, [_p, _i32, _p, _p]),
+    "revo_vit_read_tap": (_i32, [_p, _i32, _i32, _p, _p]),
     "revo_vit_seq_len": (_i32, [_p]),
-    "revo_vit_set_dual_stream": (_i32, [_p, _i32]),
     "revo_gallery_create": (_i32, [_i32, _i64, _i32, _i32, C.POINTER(_p)]),
     "revo_gallery_destroy": (_i32, [_p]),
     "revo_gallery_append": (_i32, [_p, _p, _i64, _i32, _i32, _p]),
@@ -51,12 +51,17 @@ SIGNATURES = {
     "revo_gallery_clear": (_i32, [_p]),
     "revo_gallery_read": (_i32, [_p, _i64, _i64, _p, _i32]),
     "revo_search_topk": (_i32, [_p, _p, _i32, _i32, _i32, _f32, _i64, _p, _p, _p, _p]),
+    "revo_search_ksel": (_i32, [_i32]),
+    "revo_search_plan": (_i32, [_p, _i32, _i32, C.POINTER(C.c_int64)]),
+    "revo_search_candidates": (_i32, [_p, _p, _i32, _i32, _i32, _p, _p]),
+    "revo_search_finish": (_i32, [_p, _i32, _i32, _i32, _f32, _i64, _p, _i32, _i32, _p, _p, _p, _p]),
     "revo_topk_merge": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p]),
+    "revo_topk_packed_bytes": (_i64, [_i32, _i32]),
+    "revo_topk_merge_packed": (_i32, [_p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p]),
     "revo_op_gemm": (_i32, [_i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p]),
     "revo_op_gemm_rope": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
     "revo_op_set_gemm_tile": (_i32, [_i32]),
-    "revo_op_set_gemm_debug": (_i32, [_i32]),
-    "revo_debug_scan_stats": (_i32, [C.POINTER(C.c_int64)]),
+    "revo_op_set_variant": (_i32, [_i32]),
     "revo_op_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i64, _i32, _p]),
     "revo_op_rope": (_i32, [_p, _i64, _p, _i32, _i32, _i32, _i32, _p]),
     "revo_op_attention": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),
@@ -66,6 +71,15 @@ SIGNATURES = {
     "revo_prof_report": (_i32, [C.c_char_p, _i32]),
     "revo_preprocess_crop_resize": (_i32, [C.POINTER(CropJob), _i32, _i32, _p, _p]),
 }
+
+# only in librevo_exp.so (built by `make exp` with -DREVO_EXPERIMENTS; timing scripts under scripts/)
+EXPERIMENT_SIGNATURES = {
+    "revo_op_set_gemm_debug": (_i32, [_i32]),
+    "revo_debug_scan_stats": (_i32, [C.POINTER(C.c_int64)]),
+}
+if os.environ.get("REVO_EXPERIMENTS") == "1":
+    LIB_PATH = os.path.join(_HERE, "librevo_exp.so")
+    SIGNATURES = dict(SIGNATURES, **EXPERIMENT_SIGNATURES)
 
 _lib = None
 

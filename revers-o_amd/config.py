@@ -23,6 +23,14 @@ class PEConfig:
     use_ls: bool = False          # LayerScale tensors present in the checkpoint
     ln_eps: float = 1e-5
     rope_theta: float = 10000.0
+    # hidden width of the attention-pool head's MLP.  Upstream AttentionPooling takes its own
+    # mlp_ratio (4.0), not the tower's: 4 * width.  B16 / L14 have mlp_dim == 4 * width anyway; G14
+    # (width 1536, mlp_dim 8960) has a 6144-wide pool MLP.  0 = 4 * width.
+    pool_mlp: int = 0
+
+    @property
+    def pool_mlp_dim(self) -> int:
+        return self.pool_mlp if self.pool_mlp > 0 else 4 * self.width
 
     @property
     def grid(self) -> int:
@@ -50,7 +58,7 @@ class PEConfig:
         G = self.grid * self.grid
         patch = 2.0 * G * self.patch_k * W
         per_layer = 2.0 * S * W * (3 * W) + 2.0 * S * W * W + 4.0 * S * W * M + 4.0 * S * S * W
-        pool = 2.0 * S * W * (2 * W) + 2.0 * W * W * 2 + 4.0 * S * W + 4.0 * W * M
+        pool = 2.0 * S * W * (2 * W) + 2.0 * W * W * 2 + 4.0 * S * W + 4.0 * W * self.pool_mlp_dim
         proj = 2.0 * W * D
         return patch + L * per_layer + pool + proj
 

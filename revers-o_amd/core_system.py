@@ -324,6 +324,8 @@ class SimpleReverso:
         db_path = os.path.join(self.db_root, database_name)
         ckpt_base = os.path.join(self.db_root, "checkpoints", f"{database_name}_checkpoint")
         processed_files = set()
+        # vectors left over from an earlier call (a stop, an exception) never leak into this collection
+        self._partial_embeddings, self._partial_metadata = [], []
         if resume_from_checkpoint and os.path.exists(ckpt_base + ".json"):
             try:
                 processed_files, self._partial_embeddings, self._partial_metadata = st.load_checkpoint(ckpt_base)
@@ -331,7 +333,17 @@ class SimpleReverso:
             except Exception as e:
                 log_status(f"⚠️ Error loading checkpoint: {str(e)}. Starting fresh.")
                 processed_files, self._partial_embeddings, self._partial_metadata = set(), [], []
+        try:
+            return self._create_database_body(folder_path, database_name, text_prompt, use_direct_pe, resume_from_checkpoint,
+                                              include_subfolders, log_status, status_messages, db_path, ckpt_base,
+                                              processed_files)
+        finally:
+            self._stop_requested = False
+            self._partial_embeddings = []
+            self._partial_metadata = []
 
+    def _create_database_body(self, folder_path, database_name, text_prompt, use_direct_pe, resume_from_checkpoint,
+                              include_subfolders, log_status, status_messages, db_path, ckpt_base, processed_files):
         log_status(f"📁 Creating database '{database_name}' from {folder_path}")
         image_files = []
         if include_subfolders:
@@ -346,9 +358,14 @@ class SimpleReverso:
             return str(log_status(f"❌ No images found in {folder_path}"))
         if resume_from_checkpoint:
             image_files = [f for f in image_files if f not in processed_files]
-            if not image_files:
+            if not image_files and not self._partial_embeddings:
                 return str(log_status("✅ All files already processed. Database is complete."))
-        log_status(f"📊 Found {len(image_files)} images to process", 0.1)
+            if not image_files:
+                # every file was embedded before the stop / crash, but the collection was never written
+                # (the last embed batch checkpoints before the storage phase): go straight to storage
+                log_status(f"📋 All files already embedded: storing {len(self._partial_embeddings)} vectors from the checkpoint")
+        if image_files:
+            log_status(f"📊 Found {len(image_files)} images to process", 0.1)
         if include_subfolders:
             log_status("📂 Including images from subfolders")
         log_status(f"🔧 Processing mode: {'Direct PE' if use_direct_pe else 'Detector + PE'}")
@@ -374,127 +391,122 @@ class SimpleReverso:
             except Exception as e:           # per-image failure: logged and skipped (core_system.py:585-591)
                 return e, None
 
-        try:
-            B = self.max_batch
+        B = self.max_batch
 
-            def submit(s0):
-                return [self._decode_pool.submit(open_rgb, p) for p in image_files[s0:s0 + B]]
+        def submit(s0):
+            return [self._decode_pool.submit(open_rgb, p) for p in image_files[s0:s0 + B]]
 
-            # the next batch is decoded by the pool while the device embeds the current one
-            pending = submit(0)
-            last_ckpt = time.monotonic()
-            for s in range(0, len(image_files), B):
-                if self._stop_requested:
-                    log_status("🛑 Stop requested. Saving progress...")
-                    checkpoint()
-                    return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
-                paths = image_files[s:s + B]
-                futures, pending = pending, (submit(s + B) if s + B < len(image_files) else [])
-                results = [f.result() for f in futures]
-                pils = [r[0] for r in results]
-                crop_mode = self.region_mode == "crop" and not use_direct_pe
-                good = [r for r in results if not isinstance(r[0], Exception)]
-                # global vectors of the whole batch in one forward (not needed when every region is cropped)
-                embs = None
-                if good and not crop_mode:
-                    if host_resize:
-                        with self._lock:
-                            embs = self.pe_model.embed(torch.stack([u8 for _, u8 in good]).to(self.device, non_blocking=True)).cpu()
-                    else:
-                        embs = self._embed_pils([im for im, _ in good])
-                gi = 0
-                batch_items = []                       # (path, filename, pil, metas, global vector or None)
-                for j, (path, im) in enumerate(zip(paths, pils)):
-                    i = s + j
-                    filename = os.path.basename(path)
-                    log_status(f"🔄 Processing {i + 1}/{len(image_files)}: {filename}", 0.1 + 0.7 * (i / len(image_files)))
-                    processed_files.add(path)
-                    if isinstance(im, Exception):
-                        log_status(f"❌ Error processing {filename}: {str(im)}")
+        # the next batch is decoded by the pool while the device embeds the current one
+        pending = submit(0)
+        last_ckpt = time.monotonic()
+        for s in range(0, len(image_files), B):
+            if self._stop_requested:
+                log_status("🛑 Stop requested. Saving progress...")
+                checkpoint()
+                return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
+            paths = image_files[s:s + B]
+            futures, pending = pending, (submit(s + B) if s + B < len(image_files) else [])
+            results = [f.result() for f in futures]
+            pils = [r[0] for r in results]
+            crop_mode = self.region_mode == "crop" and not use_direct_pe
+            good = [r for r in results if not isinstance(r[0], Exception)]
+            # global vectors of the whole batch in one forward (not needed when every region is cropped)
+            embs = None
+            if good and not crop_mode:
+                if host_resize:
+                    with self._lock:
+                        embs = self.pe_model.embed(torch.stack([u8 for _, u8 in good]).to(self.device, non_blocking=True)).cpu()
+                else:
+                    embs = self._embed_pils([im for im, _ in good])
+            gi = 0
+            batch_items = []                       # (path, filename, pil, metas, global vector or None)
+            for j, (path, im) in enumerate(zip(paths, pils)):
+                i = s + j
+                filename = os.path.basename(path)
+                log_status(f"🔄 Processing {i + 1}/{len(image_files)}: {filename}", 0.1 + 0.7 * (i / len(image_files)))
+                processed_files.add(path)
+                if isinstance(im, Exception):
+                    log_status(f"❌ Error processing {filename}: {str(im)}")
+                    failed += 1
+                    continue
+                e = None
+                if embs is not None:
+                    e = embs[gi]
+                    gi += 1
+                if use_direct_pe:
+                    metas = [{"region_id": str(uuid.uuid4()), "bbox": [0, 0, im.width, im.height], "area_ratio": 1.0,
+                              "detection_index": 0, "confidence": 1.0, "detected_class": "full_image"}]
+                    log_status(f"✅ Extracted global embedding for {filename}")
+                else:
+                    n_reg = self.detect_regions(im, text_prompt)
+                    if n_reg == 0:
+                        log_status(f"⚠️ No regions found in {filename}, skipping")
                         failed += 1
                         continue
-                    e = None
-                    if embs is not None:
-                        e = embs[gi]
-                        gi += 1
-                    if use_direct_pe:
-                        metas = [{"region_id": str(uuid.uuid4()), "bbox": [0, 0, im.width, im.height], "area_ratio": 1.0,
-                                  "detection_index": 0, "confidence": 1.0, "detected_class": "full_image"}]
-                        log_status(f"✅ Extracted global embedding for {filename}")
-                    else:
-                        n_reg = self.detect_regions(im, text_prompt)
-                        if n_reg == 0:
-                            log_status(f"⚠️ No regions found in {filename}, skipping")
-                            failed += 1
-                            continue
-                        _, metas = self._region_metadata(im, self.detected_regions)
-                        log_status(f"✅ Found {n_reg} regions, extracted {len(metas)} embeddings in {filename}")
-                    for m in metas:
-                        m["image_source"] = path
-                        m["filename"] = filename
-                        m["original_region_id"] = m.get("region_id", str(uuid.uuid4()))
-                        m["region_id"] = str(uuid.uuid4())
-                    batch_items.append((path, im, metas, e))
-                # region crops of the whole batch: frames go to the device once, one crop + resize launch,
-                # forwards of max_batch crops
-                region_vecs = self._embed_regions_batch([(im, metas) for _, im, metas, _ in batch_items]) if crop_mode else None
-                ri = 0
-                for path, im, metas, e in batch_items:
-                    if crop_mode:
-                        self._partial_embeddings.extend(region_vecs[ri + t].clone() for t in range(len(metas)))
-                        ri += len(metas)
-                    else:
-                        self._partial_embeddings.extend(e.clone() for _ in metas)
-                    self._partial_metadata.extend(metas)
-                    processed += 1
-                    self._last_processed_file = path
-                # checkpoints rewrite everything collected so far: at most one per interval, and one at the end
-                if time.monotonic() - last_ckpt >= self.checkpoint_interval_s or s + B >= len(image_files):
+                    _, metas = self._region_metadata(im, self.detected_regions)
+                    log_status(f"✅ Found {n_reg} regions, extracted {len(metas)} embeddings in {filename}")
+                for m in metas:
+                    m["image_source"] = path
+                    m["filename"] = filename
+                    m["original_region_id"] = m.get("region_id", str(uuid.uuid4()))
+                    m["region_id"] = str(uuid.uuid4())
+                batch_items.append((path, im, metas, e))
+            # region crops of the whole batch: frames go to the device once, one crop + resize launch,
+            # forwards of max_batch crops
+            region_vecs = self._embed_regions_batch([(im, metas) for _, im, metas, _ in batch_items]) if crop_mode else None
+            ri = 0
+            for path, im, metas, e in batch_items:
+                if crop_mode:
+                    self._partial_embeddings.extend(region_vecs[ri + t].clone() for t in range(len(metas)))
+                    ri += len(metas)
+                else:
+                    self._partial_embeddings.extend(e.clone() for _ in metas)
+                self._partial_metadata.extend(metas)
+                processed += 1
+                self._last_processed_file = path
+            # checkpoints rewrite everything collected so far: at most one per interval, and one at the end
+            if time.monotonic() - last_ckpt >= self.checkpoint_interval_s or s + B >= len(image_files):
+                checkpoint()
+                last_ckpt = time.monotonic()
+
+        if not self._partial_embeddings:
+            return str(log_status("❌ No embeddings extracted from any images"))
+
+        vector_dim = self._partial_embeddings[0].shape[0]
+        collection_name = f"simple_reverso_{database_name}"
+        with self._lock:
+            if os.path.isdir(db_path):
+                shutil.rmtree(db_path)                          # recreate_collection: start fresh
+            store = st.GalleryStore(vector_dim, device=self.device.index or 0,
+                                    capacity=len(self._partial_embeddings), collection=collection_name, path=db_path)
+            log_status(f"📦 Recreated collection: {collection_name}", 0.8)
+            n = len(self._partial_embeddings)
+            batch = 100
+            for j in range(0, n, batch):
+                if self._stop_requested:
+                    log_status("🛑 Stop requested during database storage. Progress saved.")
                     checkpoint()
-                    last_ckpt = time.monotonic()
-
-            if not self._partial_embeddings:
-                return str(log_status("❌ No embeddings extracted from any images"))
-
-            vector_dim = self._partial_embeddings[0].shape[0]
-            collection_name = f"simple_reverso_{database_name}"
-            with self._lock:
-                if os.path.isdir(db_path):
-                    shutil.rmtree(db_path)                          # recreate_collection: start fresh
-                store = st.GalleryStore(vector_dim, device=self.device.index or 0,
-                                        capacity=len(self._partial_embeddings), collection=collection_name, path=db_path)
-                log_status(f"📦 Recreated collection: {collection_name}", 0.8)
-                n = len(self._partial_embeddings)
-                batch = 100
-                for j in range(0, n, batch):
-                    if self._stop_requested:
-                        log_status("🛑 Stop requested during database storage. Progress saved.")
-                        checkpoint()
-                        store.close()
-                        return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
-                    vec = torch.stack(self._partial_embeddings[j:j + batch])
-                    metas = self._partial_metadata[j:j + batch]
-                    store.upsert(vec, [m["region_id"] for m in metas], metas)
-                    log_status(f"💾 Stored batch {j // batch + 1}/{(n + batch - 1) // batch} ({len(metas)} points)",
-                               0.8 + 0.1 * (j / n))
-                store.save()
-                if self.vector_db is not None:
-                    self.vector_db.close()
-                self.vector_db = store
-                self.current_database = collection_name
-            if os.path.exists(ckpt_base + ".json"):
-                st.remove_checkpoint(ckpt_base)
-                log_status("🧹 Cleaned up checkpoint file")
-            log_status("\n📊 Final Summary:", 0.9)
-            log_status(f"✅ Successfully processed: {processed} images")
-            if failed > 0:
-                log_status(f"⚠️ Failed to process: {failed} images")
-            log_status(f"🔍 Total embeddings stored: {len(self._partial_embeddings)}")
-            log_status(f"🎯 Database '{database_name}' ready for searching!", 1.0)
-        finally:
-            self._stop_requested = False
-            self._partial_embeddings = []
-            self._partial_metadata = []
+                    store.close()
+                    return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
+                vec = torch.stack(self._partial_embeddings[j:j + batch])
+                metas = self._partial_metadata[j:j + batch]
+                store.upsert(vec, [m["region_id"] for m in metas], metas)
+                log_status(f"💾 Stored batch {j // batch + 1}/{(n + batch - 1) // batch} ({len(metas)} points)",
+                           0.8 + 0.1 * (j / n))
+            store.save()
+            if self.vector_db is not None:
+                self.vector_db.close()
+            self.vector_db = store
+            self.current_database = collection_name
+        if os.path.exists(ckpt_base + ".json"):
+            st.remove_checkpoint(ckpt_base)
+            log_status("🧹 Cleaned up checkpoint file")
+        log_status("\n📊 Final Summary:", 0.9)
+        log_status(f"✅ Successfully processed: {processed} images")
+        if failed > 0:
+            log_status(f"⚠️ Failed to process: {failed} images")
+        log_status(f"🔍 Total embeddings stored: {len(self._partial_embeddings)}")
+        log_status(f"🎯 Database '{database_name}' ready for searching!", 1.0)
         return "\n".join(status_messages)
 
     # ---------------------------------------------------------------- search --

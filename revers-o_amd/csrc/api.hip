@@ -35,6 +35,23 @@ extern "C" int32_t revo_version(void) { return 100; }
         if (_rc) return _rc;      \
     } while (0)
 
+// A handle is bound to the device it was created on: every entry point that takes one makes that
+// device current for the duration of the call (allocations, kernel attributes and launches all go
+// to the current device) and puts the caller's device back afterwards.
+namespace {
+struct DeviceGuard {
+    int prev = -1; bool switched = false; hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) { err = hipSetDevice(device); switched = err == hipSuccess; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+}  // namespace
+#define REVO_ON_DEVICE(dev)                 \
+    DeviceGuard dg_(dev);                   \
+    REVO_HIP_CHECK(dg_.err)
+
 extern "C" int32_t revo_sync(void* stream) {
     REVO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return 0;
@@ -150,10 +167,10 @@ struct LayerW {
     float *b_qkv, *b_o, *b_fc1, *b_fc2, *ln1w, *ln1b, *ln2w, *ln2b, *ls1, *ls2;
 };
 
-constexpr size_t SPLITK_WS_ELEMS = 16u << 20;     // 64 MiB of fp32 per stream
+constexpr size_t SPLITK_WS_ELEMS = 16u << 20;     // 64 MiB of fp32
 struct revo_vit {
     revo_vit_cfg cfg;
-    int device = 0, max_batch = 0, S = 0, G2 = 0, Kp = 0, hd = 0, phd = 0, debug_layers = -1;
+    int device = 0, max_batch = 0, S = 0, G2 = 0, Kp = 0, hd = 0, phd = 0, PM = 0, debug_layers = -1;
     std::vector<void*> owned;
     // weights
     bf16_t* w_patch = nullptr; float *cls = nullptr, *pos = nullptr, *lnpre_w = nullptr, *lnpre_b = nullptr,
@@ -167,8 +184,6 @@ struct revo_vit {
            *pool_h = nullptr, *pool_m = nullptr, *pool_ob = nullptr;
     float *x = nullptr, *pool_o = nullptr, *feat = nullptr;
     float* splitk_ws = nullptr;        // fp32 partial planes of the split-K residual GEMMs, one region per stream
-    int dual_stream = 0;               // revo_vit_set_dual_stream
-    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     template <class T> int dalloc(T** out, size_t count) {
         void* p = nullptr;
@@ -179,7 +194,6 @@ struct revo_vit {
     }
     ~revo_vit() {
         for (void* p : owned) (void)hipFree(p);
-        if (side) { (void)hipStreamDestroy(side); (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); }
     }
 };
 
@@ -228,12 +242,16 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
     REVO_REQUIRE(c.out_dim % 4 == 0, "vit_create: out_dim must be a multiple of 4");
     REVO_REQUIRE(c.width / c.heads == 64 || c.width / c.heads == 96,
                  "vit_create: body head_dim must be 64 (PE-Core B16 / L14) or 96 (G14)");
-    REVO_HIP_CHECK(hipSetDevice(device));
+    REVO_ON_DEVICE(device);
     std::unique_ptr<revo_vit> v(new revo_vit());
     v->cfg = c; v->device = device; v->max_batch = max_batch;
     const int W = c.width, M = c.mlp_dim, D = c.out_dim, P = c.patch_size, G = c.image_size / P;
     v->G2 = G * G; v->S = v->G2 + (c.use_cls ? 1 : 0);
     v->hd = W / c.heads; v->phd = W / c.pool_heads;
+    // the pool head's MLP has its own width (upstream AttentionPooling: mlp_ratio 4), not the tower's mlp_dim
+    const int PM = c.pool_mlp_dim > 0 ? c.pool_mlp_dim : 4 * W;
+    REVO_REQUIRE(PM % 64 == 0, "vit_create: pool_mlp_dim must be a multiple of 64");
+    v->PM = PM;
     const int Kreal = 3 * P * P;
     v->Kp = (Kreal + 63) / 64 * 64;
     const int S = v->S;
@@ -242,7 +260,7 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
     for (int i = 0; i < n_weights; ++i) wm.m[weights[i].name] = &weights[i];
 
     // staging buffer for fp32 -> bf16 conversion: the largest matrix
-    size_t stage_elems = (size_t)std::max({(long)3 * W * W, (long)M * W, (long)W * Kreal, (long)W * D});
+    size_t stage_elems = (size_t)std::max({(long)3 * W * W, (long)M * W, (long)PM * W, (long)W * Kreal, (long)W * D});
     float* stage = nullptr;
     REVO_HIP_CHECK(hipMalloc((void**)&stage, stage_elems * 4));
     struct StageGuard { float* p; ~StageGuard() { (void)hipFree(p); } } sg{stage};
@@ -302,11 +320,11 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
         CHECK_RC(up_f32(v.get(), wm, p + "attn.out_proj.bias", W, &v->b_po));
         CHECK_RC(up_f32(v.get(), wm, p + "layernorm.weight", W, &v->pln_w));
         CHECK_RC(up_f32(v.get(), wm, p + "layernorm.bias", W, &v->pln_b));
-        if (!(t = wm.get(p + "mlp.c_fc.weight", (int64_t)M * W))) return -2;
-        CHECK_RC(up_bf16(v.get(), stage, t->data, M, W, W, &v->w_pfc1));
-        CHECK_RC(up_f32(v.get(), wm, p + "mlp.c_fc.bias", M, &v->b_pfc1));
-        if (!(t = wm.get(p + "mlp.c_proj.weight", (int64_t)W * M))) return -2;
-        CHECK_RC(up_bf16(v.get(), stage, t->data, W, M, M, &v->w_pfc2));
+        if (!(t = wm.get(p + "mlp.c_fc.weight", (int64_t)PM * W))) return -2;
+        CHECK_RC(up_bf16(v.get(), stage, t->data, PM, W, W, &v->w_pfc1));
+        CHECK_RC(up_f32(v.get(), wm, p + "mlp.c_fc.bias", PM, &v->b_pfc1));
+        if (!(t = wm.get(p + "mlp.c_proj.weight", (int64_t)W * PM))) return -2;
+        CHECK_RC(up_bf16(v.get(), stage, t->data, W, PM, PM, &v->w_pfc2));
         CHECK_RC(up_f32(v.get(), wm, p + "mlp.c_proj.bias", W, &v->b_pfc2));
     }
     if (!(t = wm.get("visual.proj", (int64_t)W * D))) return -2;
@@ -349,10 +367,10 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
     CHECK_RC(v->dalloc(&v->pool_att, B * W));
     CHECK_RC(v->dalloc(&v->pool_o, B * W));
     CHECK_RC(v->dalloc(&v->pool_h, B * W));
-    CHECK_RC(v->dalloc(&v->pool_m, B * M));
+    CHECK_RC(v->dalloc(&v->pool_m, B * PM));
     CHECK_RC(v->dalloc(&v->pool_ob, B * W));
     CHECK_RC(v->dalloc(&v->feat, B * D));
-    CHECK_RC(v->dalloc(&v->splitk_ws, 2 * SPLITK_WS_ELEMS));
+    CHECK_RC(v->dalloc(&v->splitk_ws, SPLITK_WS_ELEMS));
     REVO_HIP_CHECK(hipDeviceSynchronize());
     *out = v.release();
     return 0;
@@ -361,7 +379,7 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
 
 extern "C" int32_t revo_vit_destroy(revo_vit* vit) {
     API_BEGIN
-    if (vit) { (void)hipSetDevice(vit->device); delete vit; }
+    if (vit) { DeviceGuard dg(vit->device); delete vit; }
     return 0;
     API_END
 }
@@ -371,15 +389,27 @@ extern "C" int32_t revo_vit_set_debug_layers(revo_vit* vit, int32_t n) {
     vit->debug_layers = n;
     return 0;
 }
-extern "C" int32_t revo_vit_set_dual_stream(revo_vit* vit, int32_t on) {
-    REVO_REQUIRE(vit, "null handle");
-    vit->dual_stream = on != 0;
-    return 0;
-}
 extern "C" int32_t revo_vit_read_residual(revo_vit* vit, int32_t batch, float* dst, void* stream) {
     REVO_REQUIRE(vit && dst && batch >= 1 && batch <= vit->max_batch, "read_residual: bad arguments");
+    REVO_ON_DEVICE(vit->device);
     REVO_HIP_CHECK(hipMemcpyAsync(dst, vit->x, (size_t)batch * vit->S * vit->cfg.width * 4, hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int32_t revo_vit_read_tap(revo_vit* vit, int32_t which, int32_t batch, void* dst, void* stream) {
+    REVO_REQUIRE(vit && dst && batch >= 1 && batch <= vit->max_batch, "read_tap: bad arguments");
+    REVO_ON_DEVICE(vit->device);
+    const size_t rows = (size_t)batch * vit->S, W = vit->cfg.width;
+    const void* src = nullptr;
+    size_t bytes = 0;
+    switch (which) {
+        case 0: src = vit->x; bytes = rows * W * 4; break;                  // fp32 residual stream
+        case 1: src = vit->h; bytes = rows * W * 2; break;                  // bf16 output of the last LayerNorm (ln_post after a full forward)
+        case 2: src = vit->pool_o; bytes = (size_t)batch * W * 4; break;    // fp32 attention-pool output (after its MLP residual, before proj)
+        default: REVO_REQUIRE(false, "read_tap: which must be 0 (residual), 1 (last LayerNorm output, bf16) or 2 (pooled)");
+    }
+    REVO_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
 
@@ -395,11 +425,11 @@ int gemm(const char* cls, int epi, const bf16_t* A, long lda, const bf16_t* B, l
 }  // namespace
 
 // Forward of images [b0, b0 + B) of the call's batch on stream st; every workspace buffer is
-// addressed at the rows of those images, so two disjoint ranges can run on two streams at once.
+// addressed at the rows of those images.
 static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image_dtype, int b0, int B, float* out_all,
                              int32_t normalize, hipStream_t st) {
     const revo_vit_cfg& c = vv->cfg;
-    const int W = c.width, Md = c.mlp_dim, D = c.out_dim, S = vv->S;
+    const int W = c.width, Md = c.mlp_dim, D = c.out_dim, S = vv->S, PM = vv->PM;
     const int rows = B * S;
     using namespace revo;
     // views of the workspace at this range
@@ -412,7 +442,7 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
     w.x = vv->x + r0 * W; w.h = vv->h + r0 * W; w.qkv = vv->qkv + r0 * 3 * W; w.att = vv->att + r0 * W;
     w.mlp = vv->mlp + r0 * Md;
     w.pool_att = vv->pool_att + (size_t)b0 * W; w.pool_o = vv->pool_o + (size_t)b0 * W;
-    w.pool_h = vv->pool_h + (size_t)b0 * W; w.pool_m = vv->pool_m + (size_t)b0 * Md;
+    w.pool_h = vv->pool_h + (size_t)b0 * W; w.pool_m = vv->pool_m + (size_t)b0 * PM;
     w.pool_ob = vv->pool_ob + (size_t)b0 * W; w.feat = vv->feat + (size_t)b0 * D;
     const size_t img_elems = (size_t)3 * c.image_size * c.image_size;
     const void* images = (const char*)images_all + (size_t)b0 * img_elems * (image_dtype == 1 ? 1 : 4);
@@ -441,6 +471,7 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
         { ProfScope ps("gemm_patch", st); CHECK_RC(launch_gemm(EPI_PATCH, a, st)); }
         if (c.use_cls) { ProfScope ps("elementwise", st); CHECK_RC(launch_cls_rows(v->x, W, v->cls, v->pos, B, S, W, st)); }
     }
+    if (v->debug_layers == -2) return 0;   // parity hook: the embedded tokens (patch embed + position + class token), before ln_pre
     { ProfScope ps("layernorm", st);
       CHECK_RC(launch_layernorm(v->x, W, v->lnpre_w, v->lnpre_b, c.ln_eps, rows, W, v->x, W, 0, st)); }
 
@@ -466,7 +497,7 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
         CHECK_RC(gemm("gemm_fc1", EPI_BF16_GELU, v->h, W, L.w_fc1, W, rows, Md, W, v->mlp, Md, L.b_fc1, nullptr, st));
         // scratch for the split-K forms of fc2 (leftover rows at large batch, the whole GEMM at small batch)
         CHECK_RC(gemm("gemm_fc2", EPI_RESID_F32, v->mlp, Md, L.w_fc2, Md, rows, W, Md, v->x, W, L.b_fc2, L.ls2, st,
-                      vv->splitk_ws + (b0 ? SPLITK_WS_ELEMS : 0), (long)SPLITK_WS_ELEMS));
+                      vv->splitk_ws, (long)SPLITK_WS_ELEMS));
     }
     if (v->debug_layers >= 0) return 0;   // parity hook: residual stream only
 
@@ -479,8 +510,8 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
     CHECK_RC(gemm("gemm_pool", EPI_F32, v->pool_att, W, v->w_po, W, B, W, W, v->pool_o, W, v->b_po, nullptr, st));
     { ProfScope ps("layernorm", st);
       CHECK_RC(launch_layernorm(v->pool_o, W, v->pln_w, v->pln_b, c.ln_eps, B, W, v->pool_h, W, 1, st)); }
-    CHECK_RC(gemm("gemm_pool", EPI_BF16_GELU, v->pool_h, W, v->w_pfc1, W, B, Md, W, v->pool_m, Md, v->b_pfc1, nullptr, st));
-    CHECK_RC(gemm("gemm_pool", EPI_RESID_F32, v->pool_m, Md, v->w_pfc2, Md, B, W, Md, v->pool_o, W, v->b_pfc2, nullptr, st));
+    CHECK_RC(gemm("gemm_pool", EPI_BF16_GELU, v->pool_h, W, v->w_pfc1, W, B, PM, W, v->pool_m, PM, v->b_pfc1, nullptr, st));
+    CHECK_RC(gemm("gemm_pool", EPI_RESID_F32, v->pool_m, PM, v->w_pfc2, PM, B, W, PM, v->pool_o, W, v->b_pfc2, nullptr, st));
     { ProfScope ps("elementwise", st); CHECK_RC(launch_f32_to_bf16(v->pool_o, W, v->pool_ob, W, B, W, st)); }
     float* feat = normalize ? v->feat : out;
     CHECK_RC(gemm("gemm_pool", EPI_F32, v->pool_ob, W, v->w_proj, W, B, D, W, feat, D, nullptr, nullptr, st));
@@ -497,24 +528,9 @@ extern "C" int32_t revo_vit_forward(revo_vit* v, const void* images, int32_t ima
     REVO_REQUIRE(v && images && out, "vit_forward: null argument");
     REVO_REQUIRE(batch >= 1 && batch <= v->max_batch, "vit_forward: batch exceeds max_batch of the handle");
     REVO_REQUIRE(image_dtype == 0 || image_dtype == 1, "vit_forward: image_dtype must be 0 (f32) or 1 (u8)");
+    REVO_ON_DEVICE(v->device);
     hipStream_t st = (hipStream_t)stream;
-    if (!v->dual_stream || batch < 16 || v->debug_layers >= 0)
-        return vit_forward_range(v, images, image_dtype, 0, batch, out, normalize, st);
-    // Two halves of the batch on two streams: while one half sits in a GEMM's last, partly empty round of
-    // workgroups (or in a latency-bound kernel), the other half's kernels fill the idle CUs.
-    if (!v->side) {
-        REVO_HIP_CHECK(hipStreamCreateWithFlags(&v->side, hipStreamNonBlocking));
-        REVO_HIP_CHECK(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
-        REVO_HIP_CHECK(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
-    }
-    const int b1 = batch / 2;
-    REVO_HIP_CHECK(hipEventRecord(v->ev_fork, st));
-    REVO_HIP_CHECK(hipStreamWaitEvent(v->side, v->ev_fork, 0));
-    CHECK_RC(vit_forward_range(v, images, image_dtype, 0, b1, out, normalize, st));
-    CHECK_RC(vit_forward_range(v, images, image_dtype, b1, batch - b1, out, normalize, v->side));
-    REVO_HIP_CHECK(hipEventRecord(v->ev_join, v->side));
-    REVO_HIP_CHECK(hipStreamWaitEvent(st, v->ev_join, 0));
-    return 0;
+    return vit_forward_range(v, images, image_dtype, 0, batch, out, normalize, st);
     API_END
 }
 
@@ -528,6 +544,8 @@ struct revo_gallery {
     float* qf = nullptr; bf16_t* qb = nullptr; uint32_t* tau0 = nullptr; int q_cap = 0;
     uint64_t* part = nullptr; size_t part_cap = 0;
     float* stage = nullptr; size_t stage_cap = 0;
+    // candidates of the last scan (inside `part`), consumed by the finish step
+    const uint64_t* cand = nullptr; long cand_stride = 0; int cand_Q = 0, cand_ksel = 0;
     ~revo_gallery() {
         (void)hipFree(gb); (void)hipFree(gf); (void)hipFree(qf); (void)hipFree(qb); (void)hipFree(part);
         (void)hipFree(tau0);
@@ -541,7 +559,7 @@ extern "C" int32_t revo_gallery_create(int32_t dim, int64_t capacity, int32_t de
     REVO_REQUIRE(out, "gallery_create: null argument");
     REVO_REQUIRE(dim >= 64 && dim % 64 == 0, "gallery_create: dim must be a positive multiple of 64");
     REVO_REQUIRE(capacity >= 1 && capacity < (1ll << 32), "gallery_create: capacity must be in [1, 2^32)");
-    REVO_HIP_CHECK(hipSetDevice(device));
+    REVO_ON_DEVICE(device);
     std::unique_ptr<revo_gallery> g(new revo_gallery());
     g->D = dim; g->device = device; g->capacity = capacity; g->keep_f32 = keep_f32 != 0;
     REVO_HIP_CHECK(hipMalloc((void**)&g->gb, (size_t)capacity * dim * 2));
@@ -552,7 +570,7 @@ extern "C" int32_t revo_gallery_create(int32_t dim, int64_t capacity, int32_t de
 }
 extern "C" int32_t revo_gallery_destroy(revo_gallery* g) {
     API_BEGIN
-    if (g) { (void)hipSetDevice(g->device); delete g; }
+    if (g) { DeviceGuard dg(g->device); delete g; }
     return 0;
     API_END
 }
@@ -569,6 +587,7 @@ extern "C" int32_t revo_gallery_append(revo_gallery* g, const float* vecs, int64
     REVO_REQUIRE(g && (vecs || n == 0), "gallery_append: null argument");
     REVO_REQUIRE(n >= 0 && g->size + n <= g->capacity, "gallery_append: exceeds the capacity given at create");
     if (n == 0) return 0;
+    REVO_ON_DEVICE(g->device);
     hipStream_t st = (hipStream_t)stream;
     const int D = g->D;
     const int64_t chunk_rows = std::max<int64_t>(1, (64ll << 20) / (D * 4));
@@ -608,26 +627,31 @@ extern "C" int32_t revo_gallery_read(revo_gallery* g, int64_t start, int64_t n, 
     REVO_REQUIRE(g->keep_f32, "gallery_read: gallery was created without the fp32 master copy");
     REVO_REQUIRE(start >= 0 && n >= 0 && start + n <= g->size, "gallery_read: range outside the gallery");
     if (n == 0) return 0;
+    REVO_ON_DEVICE(g->device);
     REVO_HIP_CHECK(hipMemcpy(dst, g->gf + start * g->D, (size_t)n * g->D * 4,
                              dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return 0;
     API_END
 }
 
-extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32_t Q, int32_t k, int32_t has_thr,
-                                    float thr, int64_t index_offset, float* scores, int64_t* indices, int32_t* counts,
-                                    void* stream) {
-    API_BEGIN
-    REVO_REQUIRE(g && scores && indices && counts && (queries || Q == 0), "search: null argument");
-    REVO_REQUIRE(Q >= 0, "search: negative query count");
-    REVO_REQUIRE(k >= 1 && k <= 50, "search: k must be in [1, 50]");
-    if (Q == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
+// Rows of the pre-pass of the 256 x 256 scan: about one round of GEMM tiles, at most a quarter of the gallery
+static long search_prepass_rows(int Q, long N) {
+    const long qtiles = (Q + 255) / 256;
+    long n_pre = (65536 / qtiles) / 256 * 256;
+    n_pre = n_pre > 65536 ? 65536 : (n_pre < 8192 ? 8192 : n_pre);
+    if (n_pre > N / 4) n_pre = (N / 4) / 256 * 256;
+    const long cap_pre = ((512l << 20) / (4l * Q)) / 256 * 256;
+    if (n_pre > cap_pre) n_pre = cap_pre;
+    if (n_pre < 1024) n_pre = 1024;
+    return n_pre;
+}
+constexpr long SEARCH_SMALL_ROWS = 16384;     // below this the 128 x 128 scan with LDS lists takes the gallery
+
+// Phase 1 of a search: normalise the queries, scan the gallery (bf16 MFMA scores) and leave each query's best
+// ksel candidates, sorted best first, in the handle (cand / cand_stride).  The gallery must not be empty.
+static int search_candidates(revo_gallery* g, const float* queries, int Q, int ksel, hipStream_t st) {
     using namespace revo;
-    if (g->size == 0) return launch_topk_fill_empty(scores, (long long*)indices, counts, Q, k, st);
     const int D = g->D;
-    // over-selection: the bf16 scan keeps ksel >= k + margin candidates, the fp32 re-score decides
-    const int ksel = (k <= 16) ? 32 : 64;
     const long N = g->size;
     if (g->q_cap < Q) {
         REVO_HIP_CHECK(hipStreamSynchronize(st));
@@ -635,7 +659,7 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
         g->qf = nullptr; g->qb = nullptr; g->tau0 = nullptr; g->q_cap = 0;
         REVO_HIP_CHECK(hipMalloc((void**)&g->qf, (size_t)Q * D * 4));
         REVO_HIP_CHECK(hipMalloc((void**)&g->qb, (size_t)Q * D * 2));
-        REVO_HIP_CHECK(hipMalloc((void**)&g->tau0, (size_t)Q * 4));
+        REVO_HIP_CHECK(hipMalloc((void**)&g->tau0, (size_t)Q * 4 * 2));   // pre-pass bounds | live bounds
         g->q_cap = Q;
     }
     auto need_part = [&](size_t bytes) -> int {
@@ -647,63 +671,142 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
         }
         return 0;
     };
+    g->cand = nullptr; g->cand_Q = 0;
     { ProfScope ps("search_prep", st);
       CHECK_RC(launch_l2norm_rows(queries, D, g->qf, D, g->qb, D, Q, D, st)); }
 
-    if (N >= 16384) {
+    if (N >= SEARCH_SMALL_ROWS) {
         // ---- 256 x 256 scan.  Pre-pass: a plain GEMM of the queries against the first n_pre rows and a
         // per-row selection seed the admission scores; the fused scan covers rows [n_pre, N).
-        // Pre-pass size: about one round of 256 x 256 GEMM tiles.  Few queries mean short gallery
-        // slices per CU whose own 32nd-best scores stay loose (a slice of 4 k rows only reaches the 0.8 %
-        // quantile); a 64 k-row pre-pass seeds the 0.05 % quantile instead (Q = 256: 9 300 -> ~500 queued
-        // entries per slice, scan 1.11 -> 0.7 ms).
-        const long qtiles = (Q + 255) / 256;
-        long n_pre = (65536 / qtiles) / 256 * 256;
-        n_pre = n_pre > 65536 ? 65536 : (n_pre < 8192 ? 8192 : n_pre);
-        if (n_pre > N / 4) n_pre = (N / 4) / 256 * 256;
-        const long cap_pre = ((512l << 20) / (4l * Q)) / 256 * 256;
-        if (n_pre > cap_pre) n_pre = cap_pre;
-        if (n_pre < 1024) n_pre = 1024;
+        // Pre-pass size: about one round of 256 x 256 GEMM tiles; with few queries (short gallery slices
+        // per CU) up to 64 k rows, which seed the 0.05 % quantile.
+        const long n_pre = search_prepass_rows(Q, N);
         const int splits = topk_scan256_splits(Q, N - n_pre);
-        const int lists = splits + 1;
-        const size_t list_bytes = (size_t)Q * lists * ksel * 8;
-        const size_t gtop_bytes = (size_t)Q * splits * topk_scan256_top_m(splits, ksel) * 4;
-        const size_t part_bytes = list_bytes + gtop_bytes;          // zeroed together
-        const size_t pre_off = (part_bytes + 255) / 256 * 256;
-        CHECK_RC(need_part(pre_off + (size_t)Q * n_pre * 4));
-        uint64_t* part = g->part;
-        float* pre_scores = (float*)((char*)g->part + pre_off);
+        const int NB = topk_scan256_hist_buckets();
+        // workspace: histograms (zeroed) | segment counts | segments | pre-pass lists | final lists | pre-pass scores
+        auto up256 = [](size_t x) { return (x + 255) / 256 * 256; };
+        const size_t hist_off = 0, hist_bytes = (size_t)Q * NB * 4;
+        const size_t cnt_off = up256(hist_off + hist_bytes), cnt_bytes = (size_t)Q * splits * 4;
+        const size_t seg_off = up256(cnt_off + cnt_bytes), seg_bytes = (size_t)Q * splits * (2 * ksel) * 8;
+        const size_t pre_off = up256(seg_off + seg_bytes), pre_bytes = (size_t)Q * ksel * 8;
+        const size_t fin_off = up256(pre_off + pre_bytes), fin_bytes = (size_t)Q * ksel * 8;
+        const size_t sco_off = up256(fin_off + fin_bytes);
+        CHECK_RC(need_part(sco_off + (size_t)Q * n_pre * 4));
+        char* wsb = (char*)g->part;
+        uint32_t* hist = (uint32_t*)(wsb + hist_off);
+        int* seg_cnt = (int*)(wsb + cnt_off);
+        uint64_t* seg = (uint64_t*)(wsb + seg_off);
+        uint64_t* prelist = (uint64_t*)(wsb + pre_off);
+        uint64_t* final_lists = (uint64_t*)(wsb + fin_off);
+        float* pre_scores = (float*)(wsb + sco_off);
+        uint32_t* tau_base = g->tau0, *tau_live = g->tau0 + g->q_cap;
         {
             ProfScope ps("topk_prepass", st);
             GemmArgs ga{};
             ga.A = g->qb; ga.lda = D; ga.B = g->gb; ga.ldb = D; ga.M = Q; ga.N = (int)n_pre; ga.K = D;
             ga.C = pre_scores; ga.ldc = n_pre; ga.prefer256 = 1;
             CHECK_RC(launch_gemm(EPI_F32, ga, st));
-            REVO_HIP_CHECK(hipMemsetAsync(part, 0, part_bytes, st));
-            CHECK_RC(launch_topk_select_rows(pre_scores, n_pre, (int)n_pre, Q, part, (long)lists * ksel, splits,
-                                             g->tau0, ksel, st));
+            REVO_HIP_CHECK(hipMemsetAsync(hist, 0, hist_bytes, st));
+            CHECK_RC(launch_topk_select_rows(pre_scores, n_pre, (int)n_pre, Q, prelist, ksel, 0, tau_base, ksel, hist, NB,
+                                             topk_scan256_hist_shift(), st));
+            REVO_HIP_CHECK(hipMemcpyAsync(tau_live, tau_base, (size_t)Q * 4, hipMemcpyDeviceToDevice, st));
         }
         { ProfScope ps("topk_scan", st);
-          CHECK_RC(launch_topk_scan256(g->qb, D, g->gb, D, Q, N, D, n_pre, splits, part, lists, g->tau0,
-                                       (uint32_t*)((char*)part + list_bytes), ksel, st)); }
-        { ProfScope ps("topk_reduce", st); CHECK_RC(launch_topk_reduce(part, Q, lists, ksel, st)); }
-        { ProfScope ps("topk_finish", st);
-          CHECK_RC(launch_topk_finish(part, (long)lists * ksel, ksel, g->qf, D, g->keep_f32 ? g->gf : nullptr, D, D, Q,
-                                      k, has_thr, thr, index_offset, scores, (long long*)indices, counts, st)); }
+          CHECK_RC(launch_topk_scan256(g->qb, D, g->gb, D, Q, N, D, n_pre, splits, seg, seg_cnt, tau_live, tau_base, hist,
+                                       ksel, st)); }
+        { ProfScope ps("topk_reduce", st);
+          CHECK_RC(launch_topk_reduce_segs(seg, seg_cnt, splits, prelist, final_lists, Q, ksel, st)); }
+        g->cand = final_lists; g->cand_stride = ksel;
+    } else {
+        // ---- small galleries: 128 x 128 scan with per-wave LDS lists
+        const int splits = topk_scan_workspace_splits(Q, N);
+        CHECK_RC(need_part((size_t)Q * splits * ksel * 8));
+        ScanArgs a{};
+        a.Qb = g->qb; a.ldq = D; a.Gb = g->gb; a.ldg = D; a.Q = Q; a.N = N; a.D = D; a.ksel = ksel;
+        a.splits = splits; a.part = g->part;
+        { ProfScope ps("topk_scan", st); CHECK_RC(launch_topk_scan(a, st)); }
+        { ProfScope ps("topk_reduce", st); CHECK_RC(launch_topk_reduce(g->part, Q, splits, ksel, st)); }
+        g->cand = g->part; g->cand_stride = (long)splits * ksel;
+    }
+    g->cand_Q = Q; g->cand_ksel = ksel;
+    return 0;
+}
+
+// over-selection: the bf16 scan keeps ksel >= k + margin candidates, the fp32 re-score decides
+static int search_ksel(int k) { return (k <= 16) ? 32 : 64; }
+extern "C" int32_t revo_search_ksel(int32_t k) { return (k >= 1 && k <= 50) ? search_ksel(k) : -1; }
+extern "C" int32_t revo_search_plan(const revo_gallery* g, int32_t Q, int32_t k, int64_t* out4) {
+    REVO_REQUIRE(g && out4 && Q >= 1 && k >= 1 && k <= 50, "search_plan: bad arguments");
+    const long N = g->size;
+    const bool big = N >= SEARCH_SMALL_ROWS;
+    const long n_pre = big ? search_prepass_rows(Q, N) : 0;
+    out4[0] = big ? 1 : 0;
+    out4[1] = n_pre;
+    out4[2] = big ? revo::topk_scan256_splits(Q, N - n_pre) : revo::topk_scan_workspace_splits(Q, N);
+    out4[3] = search_ksel(k);
+    return 0;
+}
+
+extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32_t Q, int32_t k, int32_t has_thr,
+                                    float thr, int64_t index_offset, float* scores, int64_t* indices, int32_t* counts,
+                                    void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(g && scores && indices && counts && (queries || Q == 0), "search: null argument");
+    REVO_REQUIRE(Q >= 0, "search: negative query count");
+    REVO_REQUIRE(k >= 1 && k <= 50, "search: k must be in [1, 50]");
+    if (Q == 0) return 0;
+    REVO_ON_DEVICE(g->device);
+    hipStream_t st = (hipStream_t)stream;
+    using namespace revo;
+    if (g->size == 0) return launch_topk_fill_empty(scores, (long long*)indices, counts, Q, k, st);
+    const int ksel = search_ksel(k);
+    CHECK_RC(search_candidates(g, queries, Q, ksel, st));
+    ProfScope ps("topk_finish", st);
+    return launch_topk_finish(g->cand, g->cand_stride, ksel, g->qf, g->D, g->keep_f32 ? g->gf : nullptr, g->D, g->D, Q, k,
+                              has_thr, thr, index_offset, nullptr, 0, 0, scores, (long long*)indices, counts, st);
+    API_END
+}
+
+// ---- the same search in two phases, for a gallery that is row-sharded over several GPUs (include/revo.h)
+extern "C" int32_t revo_search_candidates(revo_gallery* g, const float* queries, int32_t Q, int32_t k, int32_t top_m,
+                                          uint32_t* bounds, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(g && bounds && (queries || Q == 0), "search_candidates: null argument");
+    REVO_REQUIRE(Q >= 0, "search_candidates: negative query count");
+    REVO_REQUIRE(k >= 1 && k <= 50, "search_candidates: k must be in [1, 50]");
+    const int ksel = search_ksel(k);
+    REVO_REQUIRE(top_m >= 1 && top_m <= ksel, "search_candidates: top_m must be in [1, revo_search_ksel(k)]");
+    if (Q == 0) return 0;
+    REVO_ON_DEVICE(g->device);
+    hipStream_t st = (hipStream_t)stream;
+    g->cand = nullptr; g->cand_Q = Q; g->cand_ksel = ksel;
+    if (g->size == 0) {                                   // an empty shard publishes nothing
+        REVO_HIP_CHECK(hipMemsetAsync(bounds, 0, (size_t)Q * top_m * 4, st));
         return 0;
     }
-    // ---- small galleries: 128 x 128 scan with per-wave LDS lists
-    const int splits = topk_scan_workspace_splits(Q, N);
-    CHECK_RC(need_part((size_t)Q * splits * ksel * 8));
-    ScanArgs a{};
-    a.Qb = g->qb; a.ldq = D; a.Gb = g->gb; a.ldg = D; a.Q = Q; a.N = N; a.D = D; a.ksel = ksel;
-    a.splits = splits; a.part = g->part;
-    { ProfScope ps("topk_scan", st); CHECK_RC(launch_topk_scan(a, st)); }
-    { ProfScope ps("topk_reduce", st); CHECK_RC(launch_topk_reduce(g->part, Q, splits, ksel, st)); }
-    { ProfScope ps("topk_finish", st);
-      CHECK_RC(launch_topk_finish(g->part, (long)splits * ksel, ksel, g->qf, D, g->keep_f32 ? g->gf : nullptr, D, D, Q,
-                                  k, has_thr, thr, index_offset, scores, (long long*)indices, counts, st)); }
-    return 0;
+    CHECK_RC(search_candidates(g, queries, Q, ksel, st));
+    ProfScope ps("topk_bounds", st);
+    return revo::launch_topk_publish(g->cand, g->cand_stride, Q, top_m, bounds, st);
+    API_END
+}
+extern "C" int32_t revo_search_finish(revo_gallery* g, int32_t Q, int32_t k, int32_t has_thr, float thr,
+                                      int64_t index_offset, const uint32_t* all_bounds, int32_t parts, int32_t top_m,
+                                      float* scores, int64_t* indices, int32_t* counts, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(g && scores && indices && counts, "search_finish: null argument");
+    REVO_REQUIRE(k >= 1 && k <= 50 && Q >= 0, "search_finish: bad k or query count");
+    REVO_REQUIRE(Q == g->cand_Q && search_ksel(k) == g->cand_ksel,
+                 "search_finish: no matching revo_search_candidates call on this handle");
+    REVO_REQUIRE(!all_bounds || (parts >= 1 && top_m >= 1 && top_m <= g->cand_ksel), "search_finish: bad bounds layout");
+    if (Q == 0) return 0;
+    REVO_ON_DEVICE(g->device);
+    hipStream_t st = (hipStream_t)stream;
+    using namespace revo;
+    if (g->size == 0 || !g->cand) return launch_topk_fill_empty(scores, (long long*)indices, counts, Q, k, st);
+    ProfScope ps("topk_finish", st);
+    return launch_topk_finish(g->cand, g->cand_stride, g->cand_ksel, g->qf, g->D, g->keep_f32 ? g->gf : nullptr, g->D, g->D,
+                              Q, k, has_thr, thr, index_offset, all_bounds, parts, top_m, scores, (long long*)indices,
+                              counts, st);
     API_END
 }
 
@@ -715,6 +818,23 @@ extern "C" int32_t revo_topk_merge(const float* scores, const int64_t* indices, 
     ProfScope ps("topk_merge", (hipStream_t)stream);
     return revo::launch_topk_merge(scores, (const long long*)indices, parts, Q, k, has_thr, thr, out_scores,
                                    (long long*)out_indices, out_counts, (hipStream_t)stream);
+    API_END
+}
+
+extern "C" int64_t revo_topk_packed_bytes(int32_t Q, int32_t k) {
+    return Q < 0 || k < 1 ? -1 : (((int64_t)Q * k * 12 + 15) / 16) * 16;
+}
+extern "C" int32_t revo_topk_merge_packed(const void* packed, int32_t parts, int32_t Q, int32_t k, int32_t has_thr, float thr,
+                                          float* out_scores, int64_t* out_indices, int32_t* out_counts, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(packed && out_scores && out_indices && out_counts, "merge: null argument");
+    REVO_REQUIRE(Q >= 0 && k >= 1, "merge: bad sizes");
+    const int64_t pb = revo_topk_packed_bytes(Q, k);
+    ProfScope ps("topk_merge", (hipStream_t)stream);
+    // part p: [Q][k] int64 indices, then [Q][k] fp32 scores
+    return revo::launch_topk_merge_strided((const float*)((const char*)packed + (size_t)Q * k * 8), pb / 4,
+                                           (const long long*)packed, pb / 8, parts, Q, k, has_thr, thr, out_scores,
+                                           (long long*)out_indices, out_counts, (hipStream_t)stream);
     API_END
 }
 
@@ -749,16 +869,22 @@ extern "C" int32_t revo_op_gemm_rope(const void* a, int64_t lda, const void* b, 
     return revo::launch_gemm(revo::EPI_BF16_ROPE, g, (hipStream_t)stream);
     API_END
 }
-extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
-    revo::gemm_set_debug(flags & 3);
+// result-preserving kernel-variant switches (test hooks; see revo.h)
+extern "C" int32_t revo_op_set_variant(int32_t flags) {
     revo::gemm_force_gy((flags >> 4) & 15);
     revo::attention_force_nw((flags >> 8) & 15);
     revo::gemm_set_tail_split(((flags >> 12) & 1) ? 0 : 1);
-    revo::topk_scan256_set_debug((flags >> 13) & 7);
     revo::gemm_set_persistent(((flags >> 16) & 1) ? 0 : 1);
     revo::gemm_set_splitk(((flags >> 17) & 1) ? 0 : 1);
     revo::gemm_set_min_tiles256(((flags >> 18) & 1) ? 0 : 100);
     return 0;
+}
+#ifdef REVO_EXPERIMENTS
+// timing experiments (librevo_exp.so only): the variant bits plus the switches that skip work
+extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
+    revo::gemm_set_debug(flags & 3);
+    revo::topk_scan256_set_debug(((flags >> 13) & 7) | (((flags >> 20) & 255) << 3));
+    return revo_op_set_variant(flags);
 }
 extern "C" int32_t revo_debug_scan_stats(int64_t* out4) {
     REVO_HIP_CHECK(hipDeviceSynchronize());
@@ -766,6 +892,7 @@ extern "C" int32_t revo_debug_scan_stats(int64_t* out4) {
     REVO_HIP_CHECK(hipMemset(revo::topk_scan256_stats(), 0, 64));
     return 0;
 }
+#endif
 extern "C" int32_t revo_op_set_gemm_tile(int32_t tile) {
     REVO_REQUIRE(tile == 0 || tile == 128 || tile == 256, "set_gemm_tile: 0, 128 or 256");
     revo::gemm_force_tile(tile);

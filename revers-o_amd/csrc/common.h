@@ -79,3 +79,17 @@ void revo_set_error(const std::string& msg);
             return -2;                                                               \
         }                                                                            \
     } while (0)
+
+// Opt-in to more than 64 KiB of dynamic LDS for a kernel.  The attribute is per DEVICE, so the
+// "already done" flag is kept per device (a process may hold handles on several GPUs).
+#define REVO_MAX_DEVICES 64
+#define REVO_FUNC_LDS(fn, bytes)                                                                   \
+    do {                                                                                           \
+        static bool done_[REVO_MAX_DEVICES] = {};                                                  \
+        int dev_ = 0;                                                                              \
+        REVO_HIP_CHECK(hipGetDevice(&dev_));                                                       \
+        if (dev_ < 0 || dev_ >= REVO_MAX_DEVICES || !done_[dev_]) {                                \
+            REVO_HIP_CHECK(hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
+            if (dev_ >= 0 && dev_ < REVO_MAX_DEVICES) done_[dev_] = true;                          \
+        }                                                                                          \
+    } while (0)

@@ -472,12 +472,7 @@ static int g_force_gy = 0;     // timing experiments only: force the XCD arrange
 void gemm_force_gy(int gy) { g_force_gy = gy; }
 template <int EPI, int DBG>
 static int launch_256d(const GemmArgs& a, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<EPI, DBG>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
-        attr_done = true;
-    }
+    REVO_FUNC_LDS((gemm256_kernel<EPI, DBG>), G256_LDS);
     // XCD arrangement (measured on MI355X, scripts/gemm_gy.py): with few N tiles every XCD sweeps
     // all of N for its M stripe (gy = 1); from 12 N tiles on, four N stripes keep a weight stripe
     // L2 resident and cut the fabric traffic (qkv 933 -> 1122, fc1 859 -> 920, 8192^3 1322 -> 1453 TF)
@@ -497,12 +492,7 @@ static int g_persistent = 1;   // timing experiments only: 0 = one workgroup per
 void gemm_set_persistent(int on) { g_persistent = on; }
 template <int EPI>
 static int launch_256p(const GemmArgs& a, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           G256P_LDS));
-        attr_done = true;
-    }
+    REVO_FUNC_LDS(gemm256p_kernel<EPI>, G256P_LDS);
     GemmArgs b = a;
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
     int gy = tiles_n >= 12 ? 4 : (tiles_n >= 8 ? 2 : 1);
@@ -515,10 +505,13 @@ static int launch_256p(const GemmArgs& a, hipStream_t st) {
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
-static int g_dbg = 0;          // timing experiments only (EPI_BF16): 1 = no epilogue stores, 2 = no main loop
+#ifdef REVO_EXPERIMENTS
+static int g_dbg = 0;          // timing experiments only (EPI_BF16, librevo_exp.so): 1 = no epilogue stores, 2 = no main loop
 void gemm_set_debug(int d) { g_dbg = d; }
+#endif
 template <int EPI>
 static int launch_256(const GemmArgs& a, hipStream_t st) {
+#ifdef REVO_EXPERIMENTS
     if (EPI == EPI_BF16 && g_dbg) {
         switch (g_dbg) {
             case 1: return launch_256d<EPI_BF16, 1>(a, st);
@@ -526,6 +519,7 @@ static int launch_256(const GemmArgs& a, hipStream_t st) {
             default: return launch_256d<EPI_BF16, 3>(a, st);
         }
     }
+#endif
     if (g_persistent && a.K >= 128 && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) > 256) return launch_256p<EPI>(a, st);
     return launch_256d<EPI, 0>(a, st);
 }
@@ -594,12 +588,7 @@ static int try_splitk_tail(const GemmArgs& a, hipStream_t st) {
     if (S < 2) return 0;
     const long plane = (long)a.M * a.N;
     if (plane * S > a.ws_elems) return 0;
-    static bool attr_done = false;
-    if (!attr_done) {
-        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<EPI_F32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           G256_LDS));
-        attr_done = true;
-    }
+    REVO_FUNC_LDS((gemm256_kernel<EPI_F32, 4>), G256_LDS);
     GemmArgs b = a;
     b.C = a.ws; b.ldc = a.N; b.bias = nullptr; b.gamma = nullptr;
     b.ksplit = S; b.c_split_stride = plane;
@@ -674,12 +663,7 @@ static int launch_t(const GemmArgs& a, hipStream_t st) {
 
 template <int EPI>
 static int launch_128(const GemmArgs& a, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        REVO_HIP_CHECK(hipFuncSetAttribute((const void*)gemm128_kernel<EPI, 128>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * 128));
-        attr_done = true;
-    }
+    REVO_FUNC_LDS((gemm128_kernel<EPI, 128>), 2 * (128 + 128) * 128);
     const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
     // at most about one 128 x 128 tile per CU: one latency-bound workgroup each; 128 x 64 tiles halve the work per
     // K step of a workgroup and put two or three of them on a CU

@@ -33,7 +33,9 @@ struct GemmArgs {
 // true when launch_gemm would run the 256 x 256 kernel with the row-coalesced epilogue for these sizes
 bool gemm_uses_wide_epilogue(int M, int N, long lda, long ldb, long ldc);
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
-void gemm_set_debug(int d);
+#ifdef REVO_EXPERIMENTS
+void gemm_set_debug(int d);           // timing experiments (results are wrong): librevo_exp.so only
+#endif
 void gemm_force_gy(int gy);
 void gemm_set_tail_split(int on);
 void gemm_force_tile(int t);   // 0 = heuristic, 128 or 256 = forced
@@ -86,24 +88,42 @@ int launch_topk_scan(const ScanArgs& a, hipStream_t st);
 int launch_topk_reduce(uint64_t* part, int Q, int splits, int ksel, hipStream_t st);
 // exact fp32 re-score of the ksel candidates of each query, final order (score desc, index asc),
 // threshold cut, write k results.  Gf may be null: then the bf16-scan scores are returned.
+// all_bounds (optional): [parts][Q][top_m] order-preserving u32 scores published by every shard of a row-sharded
+// gallery; only candidates at or above their ksel-th largest (a lower bound of the global ksel-th best) are re-scored.
 int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const float* Qf, long ldqf, const float* Gf,
-                       long ldgf, int D, int Q, int k, int has_thr, float thr, long idx_offset, float* out_scores,
-                       long long* out_idx, int* out_counts, hipStream_t st);
-// 256 x 256 tile scan with queue + drain selection (topk256.hip); KSEL = 32
+                       long ldgf, int D, int Q, int k, int has_thr, float thr, long idx_offset, const uint32_t* all_bounds,
+                       int parts, int top_m, float* out_scores, long long* out_idx, int* out_counts, hipStream_t st);
+// bounds[q][0..top_m) = order-preserving u32 scores of the query's best top_m candidates (0 = none)
+int launch_topk_publish(const uint64_t* part, long part_stride, int Q, int top_m, uint32_t* bounds, hipStream_t st);
+// 256 x 256 tile scan (topk256.hip): survivors are appended to per-(query, slice) segments of 2 * ksel keys and
+// counted in per-query score histograms; launch_topk_reduce_segs then picks each query's best ksel keys
 int topk_scan256_splits(int Q, long rows);
-void topk_scan256_set_debug(int d);   // timing experiments only
+int topk_scan256_hist_buckets();      // u32 counters per query in `hist`
+int topk_scan256_hist_shift();        // bucket width = 2^shift ulps of the fp32 score above the pre-pass bound
+#ifdef REVO_EXPERIMENTS
+void topk_scan256_set_debug(int d);   // timing experiments (bit 0 / 2: results are wrong): librevo_exp.so only
 unsigned long long* topk_scan256_stats();
+#endif
+// seg [Q][splits][2 ksel] keys, seg_cnt [Q][splits]; tau_g [Q] live admission bounds (in: = tau_base), tau_base [Q]
+// the pre-pass bound (constant), hist [Q][buckets] zeroed and then seeded by launch_topk_select_rows
 int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
-                        int splits, uint64_t* part, int lists_per_query, uint32_t* tau_g, uint32_t* gtop, int ksel,
-                        hipStream_t st);
-int topk_scan256_top_m(int splits, int ksel);   // best scores each slice publishes for the cross-slice bound
-// pre-pass of the 256 x 256 scan: KSEL best columns of every row of a [Q][n] fp32 score matrix
+                        int splits, uint64_t* seg, int* seg_cnt, uint32_t* tau_g, const uint32_t* tau_base, uint32_t* hist,
+                        int ksel, hipStream_t st);
+// out[q][ksel] = best ksel distinct keys (sorted, best first) of prelist[q][ksel] and the query's segments
+int launch_topk_reduce_segs(const uint64_t* seg, const int* seg_cnt, int splits, const uint64_t* prelist, uint64_t* out,
+                            int Q, int ksel, hipStream_t st);
+// pre-pass of the 256 x 256 scan: KSEL best columns of every row of a [Q][n] fp32 score matrix -> part[q][slot];
+// tau0[q] = the KSEL-th score; hist (optional): the kept scores are counted into the query's histogram
 int launch_topk_select_rows(const float* scores, long ld, int n, int Q, uint64_t* part, long part_row_stride, int slot,
-                            uint32_t* tau0, int ksel, hipStream_t st);
+                            uint32_t* tau0, int ksel, uint32_t* hist, int hist_buckets, int hist_shift, hipStream_t st);
 // all-padding result for an empty gallery
 int launch_topk_fill_empty(float* s, long long* i, int* c, int Q, int k, hipStream_t st);
 // merge P per-shard result lists [P][Q][k] -> [Q][k]
 int launch_topk_merge(const float* scores, const long long* idx, int P, int Q, int k, int has_thr, float thr,
                       float* out_scores, long long* out_idx, int* out_counts, hipStream_t st);
+// the same with explicit distances (in elements) between the parts of the two arrays
+int launch_topk_merge_strided(const float* scores, long score_part_stride, const long long* idx, long idx_part_stride, int P,
+                              int Q, int k, int has_thr, float thr, float* out_scores, long long* out_idx, int* out_counts,
+                              hipStream_t st);
 
 }  // namespace revo

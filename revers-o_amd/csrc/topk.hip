@@ -190,21 +190,11 @@ int launch_topk_scan(const ScanArgs& a, hipStream_t st) {
     dim3 grid((a.Q + SCAN_BM - 1) / SCAN_BM, a.splits), block(GEMM_THREADS);
     if (a.ksel == 32) {
         constexpr int LDS = SCAN_GEMM_LDS + SCAN_BM * 32 * 8;
-        static bool done = false;
-        if (!done) {
-            REVO_HIP_CHECK(hipFuncSetAttribute((const void*)topk_scan_kernel<32>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-            done = true;
-        }
+        REVO_FUNC_LDS(topk_scan_kernel<32>, LDS);
         hipLaunchKernelGGL((topk_scan_kernel<32>), grid, block, LDS, st, a);
     } else {
         constexpr int LDS = SCAN_GEMM_LDS + SCAN_BM * 64 * 8;
-        static bool done = false;
-        if (!done) {
-            REVO_HIP_CHECK(hipFuncSetAttribute((const void*)topk_scan_kernel<64>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-            done = true;
-        }
+        REVO_FUNC_LDS(topk_scan_kernel<64>, LDS);
         hipLaunchKernelGGL((topk_scan_kernel<64>), grid, block, LDS, st, a);
     }
     REVO_HIP_CHECK(hipGetLastError());
@@ -259,17 +249,56 @@ int launch_topk_reduce(uint64_t* part, int Q, int splits, int ksel, hipStream_t 
 }
 
 // ----------------------------------------------------------- the finish ----
+// the 64 lane values sorted, largest in lane 0 (32-bit)
+__device__ __forceinline__ uint32_t wave_sort_desc_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const uint32_t o = __shfl_xor(v, j, 64);
+            const bool take_max = (((lane & j) == 0) == ((lane & k2) == 0));
+            v = take_max ? (v > o ? v : o) : (v < o ? v : o);
+        }
+    }
+    return v;
+}
 __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __restrict__ part, long part_stride, int ksel,
                                                           const float* __restrict__ Qf, long ldqf,
                                                           const float* __restrict__ Gf, long ldgf, int D, int Q, int k,
                                                           int has_thr, float thr, long idx_offset,
+                                                          const uint32_t* __restrict__ all_bounds, int parts, int top_m,
                                                           float* __restrict__ out_scores,
                                                           long long* __restrict__ out_idx, int* __restrict__ out_counts) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
     const uint64_t key = lane < ksel ? part[(long)q * part_stride + lane] : 0ull;
-    const bool valid = key != 0ull;
+    // Row-sharded gallery: every shard has published the (bf16-scan) scores of its best top_m candidates for this
+    // query.  They belong to distinct gallery rows, so the ksel-th largest of all of them is a lower bound of the
+    // ksel-th best scan score over the WHOLE gallery: a candidate of this shard below it is not among the global
+    // best ksel, which is all the unsharded search would re-score.  (About ksel / parts candidates per query
+    // survive instead of ksel: the fp32 row gathers shrink by the same factor.)
+    uint32_t bound = 0u;
+    if (all_bounds) {
+        uint32_t run = 0u;                                       // best 64 so far, descending
+        const int total = parts * top_m;
+        for (int base = 0; base < total; base += 64) {
+            const int e = base + lane;
+            uint32_t v = 0u;
+            if (e < total) v = all_bounds[((long)(e / top_m) * Q + q) * top_m + (e % top_m)];
+            v = wave_sort_desc_u32(v, lane);
+            const uint32_t rev = __shfl_xor(v, 63, 64);
+            uint32_t mx = run > rev ? run : rev;                 // best 64 of both, bitonic
+#pragma unroll
+            for (int j = 32; j > 0; j >>= 1) {
+                const uint32_t o = __shfl_xor(mx, j, 64);
+                mx = ((lane & j) == 0) ? (mx > o ? mx : o) : (mx < o ? mx : o);
+            }
+            run = mx;
+        }
+        bound = (uint32_t)__builtin_amdgcn_readlane((int)run, ksel - 1);     // 0 while fewer than ksel were published
+    }
+    const bool valid = key != 0ull && (uint32_t)(key >> 32) >= bound;
     const uint32_t idx = key_index(key);
     float score = valid ? key_score(key) : -INFINITY;
     if (Gf) {
@@ -319,13 +348,30 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __rest
     if (lane == 0) out_counts[q] = cnt;
 }
 int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const float* Qf, long ldqf, const float* Gf,
-                       long ldgf, int D, int Q, int k, int has_thr, float thr, long idx_offset, float* out_scores,
-                       long long* out_idx, int* out_counts, hipStream_t st) {
+                       long ldgf, int D, int Q, int k, int has_thr, float thr, long idx_offset, const uint32_t* all_bounds,
+                       int parts, int top_m, float* out_scores, long long* out_idx, int* out_counts, hipStream_t st) {
     REVO_REQUIRE(k >= 1 && k <= ksel && ksel <= 64, "search: need 1 <= k <= ksel <= 64");
     REVO_REQUIRE(!Gf || (D % 4 == 0 && ldqf % 4 == 0 && ldgf % 4 == 0), "search: fp32 rows must be 16-byte aligned");
     if (Q <= 0) return 0;
     hipLaunchKernelGGL(topk_finish_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, part, part_stride, ksel, Qf, ldqf, Gf,
-                       ldgf, D, Q, k, has_thr, thr, idx_offset, out_scores, out_idx, out_counts);
+                       ldgf, D, Q, k, has_thr, thr, idx_offset, all_bounds, parts, top_m, out_scores, out_idx, out_counts);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// bounds[q][j] = order-preserving u32 score of candidate j of query q (lists are sorted best first; 0 = empty slot)
+__global__ __launch_bounds__(256) void topk_publish_kernel(const uint64_t* __restrict__ part, long part_stride, int Q, int top_m,
+                                                           uint32_t* __restrict__ bounds) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)Q * top_m) return;
+    const long q = t / top_m;
+    const int j = (int)(t - q * top_m);
+    bounds[t] = (uint32_t)(part[q * part_stride + j] >> 32);
+}
+int launch_topk_publish(const uint64_t* part, long part_stride, int Q, int top_m, uint32_t* bounds, hipStream_t st) {
+    if (Q <= 0) return 0;
+    const long n = (long)Q * top_m;
+    hipLaunchKernelGGL(topk_publish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, part_stride, Q, top_m, bounds);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -334,83 +380,120 @@ int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const f
 // scores [Q][n] fp32 (a plain GEMM of the queries against the first n gallery rows) ->
 // the KSEL best (score, column) keys of every row, best first, written to
 // part[q][slot][KSEL], and tau0[q] = the KSEL-th score (-inf if fewer than KSEL columns).
-// One wave per query; a 64-column chunk is sorted and merged only if it can change the result.
-constexpr int SW = 16;      // waves per query in the pre-pass selection
-constexpr int SU = 8;       // 64-column chunks of loads in flight per wave
+//
+// One workgroup per query, one wave per strip of 8192 columns, the strip held in registers (32 x 16-byte
+// loads per lane, all in flight at once).  Pass 1: every lane takes the maximum of its 128 scores; those 64
+// maxima belong to 64 different columns, so their KSEL-th largest is a lower bound T of the strip's KSEL-th
+// best score -- one 64-value sort instead of a running list.  Pass 2: the few scores >= T (about 45 of 8192 for
+// KSEL = 32) are compacted into LDS and sorted once.  (The previous form walked 64-column chunks against a
+// running bound and sorted whenever 64 survivors had gathered, 16 waves per query with a serial 15-step
+// merge at the end: 0.59 ms for 10 000 x 8192 scores; this one is bound by reading the scores.)
+// sort the wave's compacted survivors, fold them into the running list, raise the bound (a real call: inlined
+// 256 times into the unrolled walk over the registers it made the compiler keep the strip in scratch memory)
 template <int KSEL>
-__global__ __launch_bounds__(SW * 64) void topk_select_rows_kernel(const float* __restrict__ scores, long lds_, int n,
-                                                                  int Q, uint64_t* __restrict__ part,
-                                                                  long part_row_stride, int slot,
-                                                                  uint32_t* __restrict__ tau0) {
-    // one workgroup of SW waves per query: wave w takes the 64-column chunks w, w + SW, ...; SU chunks of
-    // loads are in flight per wave (the walk is a chain of global-load latencies otherwise)
-    __shared__ uint64_t partial[SW][64];
-    __shared__ uint64_t cand[SW][64];     // per wave: columns that beat the wave's running 32nd-best, compacted
+__device__ __noinline__ void sel_flush(uint64_t& run, float& tau, int& cnt, const uint64_t* cand, int lane) {
+    uint64_t x = lane < cnt ? cand[lane] : 0ull;
+    x = wave_sort_desc(x, lane);
+    const uint64_t rev = shfl_xor_u64(x, 63);
+    const uint64_t m2 = run > rev ? run : rev;
+    uint64_t r = wave_bitonic_merge_desc(m2, lane);
+    if (lane >= KSEL) r = 0ull;
+    const uint64_t last = readlane_u64(r, KSEL - 1);
+    if (last) tau = fmaxf(tau, key_score(last));
+    run = r;
+    cnt = 0;
+}
+constexpr int SEL_STRIP = 8192;     // columns per wave
+constexpr int SEL_MAXW = 8;         // waves per query: n <= 65536
+template <int KSEL>
+__global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const float* __restrict__ scores, long lds_, int n,
+                                                                        int Q, uint64_t* __restrict__ part,
+                                                                        long part_row_stride, int slot,
+                                                                        uint32_t* __restrict__ tau0, uint32_t* __restrict__ hist,
+                                                                        int hist_buckets, int hist_shift) {
+    __shared__ uint64_t partial[SEL_MAXW][64];
+    __shared__ uint64_t cand[SEL_MAXW][64];     // per wave: survivors of pass 2, compacted
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
     const int q = blockIdx.x;
-    const float* row = scores + (long)q * lds_;
-    uint64_t run = 0ull;
-    float tau = -INFINITY;
-    int cnt = 0;                           // wave-uniform
-    // Survivors are rare once tau has risen (a 64-column chunk holds ~0.5 of them): instead of sorting
-    // every chunk that has one, they are appended to the wave's buffer and sorted + merged per 64.
-    auto flush = [&]() {
-        uint64_t v = lane < cnt ? cand[w][lane] : 0ull;
-        v = wave_sort_desc(v, lane);
-        const uint64_t rev = shfl_xor_u64(v, 63);
-        const uint64_t mx = run > rev ? run : rev;
-        run = wave_bitonic_merge_desc(mx, lane);
-        if (lane >= KSEL) run = 0ull;
-        const uint64_t last = readlane_u64(run, KSEL - 1);
-        tau = last ? key_score(last) : -INFINITY;
-        cnt = 0;
-    };
-    for (int base0 = w * 64; base0 < n; base0 += SU * SW * 64) {
-        float sv[SU];
+    const int c0 = w * SEL_STRIP;
+    const float* row = scores + (long)q * lds_ + c0;
+    const int left = n - c0;                                   // columns of this strip (may be <= 0 or > SEL_STRIP)
+    f32x4 v[32];
+    float mx = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < SU; ++u) {
-            const int c = base0 + u * SW * 64 + lane;
-            sv[u] = c < n ? row[c] : -INFINITY;
+    for (int i = 0; i < 32; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        // n and the row stride are multiples of 4 (checked by the launcher): a 16-byte chunk is all in or all out
+        v[i] = c < left ? *(const f32x4*)(row + c) : (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) mx = fmaxf(fmaxf(mx, fmaxf(v[i][0], v[i][1])), fmaxf(v[i][2], v[i][3]));
+    // T = KSEL-th largest of the 64 lane maxima (order-preserving u32; NaN scores cannot occur: unit rows)
+    uint32_t o = f32_orderable(mx);
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const uint32_t x = __shfl_xor(o, j, 64);
+            const bool take_max = (((lane & j) == 0) == ((lane & k2) == 0));
+            o = take_max ? (o > x ? o : x) : (o < x ? o : x);
         }
+    }
+    float tau = orderable_f32((uint32_t)__builtin_amdgcn_readlane((int)o, KSEL - 1));
+    uint64_t run = 0ull;
+    int cnt = 0;                           // wave-uniform
 #pragma unroll
-        for (int u = 0; u < SU; ++u) {
-            const int c = base0 + u * SW * 64 + lane;
-            const float s = sv[u];
-            const bool take = s >= tau && c < n;
+    for (int i = 0; i < 32; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sv = v[i][e];
+            const bool take = sv >= tau && sv > -INFINITY;
             const unsigned long long mask = __ballot(take);
             if (mask == 0ull) continue;
             const int add = __popcll(mask);
-            if (cnt + add > 64) flush();                  // (entries kept under the old tau stay valid candidates)
-            if (take) cand[w][cnt + __popcll(mask & ((1ull << lane) - 1ull))] = make_key(s, (uint32_t)c);
+            if (cnt + add > 64) sel_flush<KSEL>(run, tau, cnt, cand[w], lane);   // (entries kept under the old tau stay valid candidates)
+            if (take) cand[w][cnt + __popcll(mask & ((1ull << lane) - 1ull))] = make_key(sv, (uint32_t)(c0 + (i * 64 + lane) * 4 + e));
             cnt += add;
-            if (cnt == 64) flush();
+            if (cnt == 64) sel_flush<KSEL>(run, tau, cnt, cand[w], lane);
         }
     }
-    if (cnt > 0) flush();
+    if (cnt > 0) sel_flush<KSEL>(run, tau, cnt, cand[w], lane);
     partial[w][lane] = run;
     __syncthreads();
     if (w == 0) {
 #pragma unroll 1
-        for (int o = 1; o < SW; ++o) {
-            const uint64_t rev = partial[o][63 - lane];
-            const uint64_t mx = run > rev ? run : rev;
-            run = wave_bitonic_merge_desc(mx, lane);
+        for (int ow = 1; ow < nw; ++ow) {
+            const uint64_t rev = partial[ow][63 - lane];
+            const uint64_t m2 = run > rev ? run : rev;
+            run = wave_bitonic_merge_desc(m2, lane);
             if (lane >= KSEL) run = 0ull;
         }
         if (lane < KSEL) part[(long)q * part_row_stride + (long)slot * KSEL + lane] = run;
         const uint64_t last = readlane_u64(run, KSEL - 1);
-        if (lane == 0) tau0[q] = f32_orderable(last ? key_score(last) : -INFINITY);   // order-preserving u32
+        const uint32_t base = f32_orderable(last ? key_score(last) : -INFINITY);      // order-preserving u32
+        if (lane == 0) tau0[q] = base;
+        // seed the query's score histogram (origin = this bound) with the kept scores: the scan counts its
+        // survivors into the same buckets, so "KSEL scores at or above an edge" includes the pre-pass rows
+        if (hist && last && lane < KSEL && run) {
+            uint32_t b = ((uint32_t)(run >> 32) - base) >> hist_shift;
+            b = b < (uint32_t)(hist_buckets - 1) ? b : (uint32_t)(hist_buckets - 1);
+            atomicAdd(hist + (long)q * hist_buckets + b, 1u);
+        }
     }
 }
 int launch_topk_select_rows(const float* scores, long ld, int n, int Q, uint64_t* part, long part_row_stride, int slot,
-                            uint32_t* tau0, int ksel, hipStream_t st) {
+                            uint32_t* tau0, int ksel, uint32_t* hist, int hist_buckets, int hist_shift, hipStream_t st) {
     if (Q <= 0) return 0;
+    REVO_REQUIRE(n >= 1 && n <= SEL_STRIP * SEL_MAXW, "search: the pre-pass selection takes at most 65536 columns");
+    REVO_REQUIRE(n % 4 == 0 && ld % 4 == 0 && (((uintptr_t)scores) & 15) == 0, "search: pre-pass score rows must be 16-byte aligned");
+    const int nw = (n + SEL_STRIP - 1) / SEL_STRIP;
     if (ksel == 32)
-        hipLaunchKernelGGL((topk_select_rows_kernel<32>), dim3(Q), dim3(SW * 64), 0, st, scores, ld, n, Q, part,
-                           part_row_stride, slot, tau0);
+        hipLaunchKernelGGL((topk_select_rows_kernel<32>), dim3(Q), dim3(nw * 64), 0, st, scores, ld, n, Q, part,
+                           part_row_stride, slot, tau0, hist, hist_buckets, hist_shift);
     else
-        hipLaunchKernelGGL((topk_select_rows_kernel<64>), dim3(Q), dim3(SW * 64), 0, st, scores, ld, n, Q, part,
-                           part_row_stride, slot, tau0);
+        hipLaunchKernelGGL((topk_select_rows_kernel<64>), dim3(Q), dim3(nw * 64), 0, st, scores, ld, n, Q, part,
+                           part_row_stride, slot, tau0, hist, hist_buckets, hist_shift);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -431,46 +514,93 @@ int launch_topk_fill_empty(float* s, long long* i, int* c, int Q, int k, hipStre
 
 // ------------------------------------------------------------ the merge ----
 // [P][Q][k] per-shard results (global indices, -inf/-1 padded) -> [Q][k].
-__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ scores,
-                                                         const long long* __restrict__ idx, int P, int Q, int k,
+// Global row ids are 64-bit here (a sharded gallery may hold more than 2^32 rows in total), so the merge
+// orders 96-bit keys: (order-preserving score, ~index) -- score descending, then index ascending.
+struct Key96 {
+    uint64_t a;      // orderable(score) << 32 | high word of ~index
+    uint32_t b;      // low word of ~index
+};
+__device__ __forceinline__ bool key96_less(const Key96& x, const Key96& y) { return x.a < y.a || (x.a == y.a && x.b < y.b); }
+__device__ __forceinline__ Key96 key96_shfl_xor(const Key96& v, int m) {
+    Key96 o;
+    o.a = shfl_xor_u64(v.a, m);
+    o.b = __shfl_xor(v.b, m, 64);
+    return o;
+}
+__device__ __forceinline__ Key96 key96_sort_desc(Key96 v, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const Key96 o = key96_shfl_xor(v, j);
+            const bool take_max = (((lane & j) == 0) == ((lane & k2) == 0));
+            const bool less = key96_less(v, o);
+            v = (take_max == less) ? o : v;
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ Key96 key96_bitonic_merge_desc(Key96 v, int lane) {
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const Key96 o = key96_shfl_xor(v, j);
+        const bool take_max = (lane & j) == 0;
+        const bool less = key96_less(v, o);
+        v = (take_max == less) ? o : v;
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ scores, long score_part_stride,
+                                                         const long long* __restrict__ idx, long idx_part_stride, int P, int Q, int k,
                                                          int has_thr, float thr, float* __restrict__ out_scores,
                                                          long long* __restrict__ out_idx, int* __restrict__ out_counts) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
     const int total = P * k;
-    uint64_t run = 0ull;
+    Key96 run{0ull, 0u};                       // all-zero = empty slot (a real entry has a non-zero score word)
     for (int base = 0; base < total; base += 64) {
         const int e = base + lane;
-        uint64_t v = 0ull;
+        Key96 v{0ull, 0u};
         if (e < total) {
             const int pz = e / k, j = e - pz * k;
-            const long off = ((long)pz * Q + q) * k + j;
-            const long long gi = idx[off];
-            if (gi >= 0) v = make_key(scores[off], (uint32_t)gi);
+            const long off = (long)q * k + j;
+            const long long gi = idx[(long)pz * idx_part_stride + off];
+            if (gi >= 0) {
+                const uint64_t ni = ~(uint64_t)gi;
+                v.a = ((uint64_t)f32_orderable(scores[(long)pz * score_part_stride + off]) << 32) | (ni >> 32);
+                v.b = (uint32_t)ni;
+            }
         }
-        v = wave_sort_desc(v, lane);
-        const uint64_t rev = shfl_xor_u64(v, 63);       // chunk worst-first
-        const uint64_t mx = run > rev ? run : rev;      // top 64 of both, bitonic
-        run = wave_bitonic_merge_desc(mx, lane);
+        v = key96_sort_desc(v, lane);
+        const Key96 rev = key96_shfl_xor(v, 63);                    // chunk worst-first
+        const Key96 mx = key96_less(run, rev) ? rev : run;          // top 64 of both, bitonic
+        run = key96_bitonic_merge_desc(mx, lane);
     }
-    const bool ok = run != 0ull && lane < k && (!has_thr || key_score(run) >= thr);
+    const float sc = orderable_f32((uint32_t)(run.a >> 32));
+    const bool ok = (run.a != 0ull || run.b != 0u) && lane < k && (!has_thr || sc >= thr);
     const int cnt = __popcll(__ballot(ok));
     if (lane < k) {
-        out_scores[(long)q * k + lane] = ok ? key_score(run) : -INFINITY;
-        out_idx[(long)q * k + lane] = ok ? (long long)key_index(run) : -1ll;
+        out_scores[(long)q * k + lane] = ok ? sc : -INFINITY;
+        out_idx[(long)q * k + lane] = ok ? (long long)~((run.a << 32) | (uint64_t)run.b) : -1ll;
     }
     if (lane == 0) out_counts[q] = cnt;
 }
-int launch_topk_merge(const float* scores, const long long* idx, int P, int Q, int k, int has_thr, float thr,
-                      float* out_scores, long long* out_idx, int* out_counts, hipStream_t st) {
+int launch_topk_merge_strided(const float* scores, long score_part_stride, const long long* idx, long idx_part_stride, int P,
+                              int Q, int k, int has_thr, float thr, float* out_scores, long long* out_idx, int* out_counts,
+                              hipStream_t st) {
     REVO_REQUIRE(k >= 1 && k <= 64, "merge: need 1 <= k <= 64");
     REVO_REQUIRE(P >= 1, "merge: need at least one part");
     if (Q <= 0) return 0;
-    hipLaunchKernelGGL(topk_merge_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, scores, idx, P, Q, k, has_thr, thr,
-                       out_scores, out_idx, out_counts);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, scores, score_part_stride, idx, idx_part_stride,
+                       P, Q, k, has_thr, thr, out_scores, out_idx, out_counts);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
+}
+int launch_topk_merge(const float* scores, const long long* idx, int P, int Q, int k, int has_thr, float thr,
+                      float* out_scores, long long* out_idx, int* out_counts, hipStream_t st) {
+    return launch_topk_merge_strided(scores, (long)Q * k, idx, (long)Q * k, P, Q, k, has_thr, thr, out_scores, out_idx,
+                                     out_counts, st);
 }
 
 }  // namespace revo

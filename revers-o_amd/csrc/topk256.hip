@@ -3,25 +3,64 @@
 //
 // One workgroup = 256 queries x one contiguous slice of the gallery, walked in 256-row
 // tiles.  After each tile a lane compares its 128 scores with the admission score of its
-// 8 query rows (running KSEL-th best: a lower bound of the final one, so nothing that can
-// end up in the top KSEL is ever dropped).  Survivors are rare after the first tiles; they
-// are appended to a 2048-entry LDS queue as 64-bit entries  row | score | ~index.  When the
-// queue holds 1792 entries (or the slice ends) the workgroup drains it: a bitonic sort of the queue groups the
-// entries by query row (best first), and each row's best <= KSEL entries are merged into
-// that row's candidate list, which lives in global memory (L2 resident, touched only at
-// drains) because the 128 KiB main-loop image leaves no room for 256 lists in LDS.  The
-// admission scores are seeded by a pre-pass over the first rows of the gallery (topk.hip),
-// so even the first tile admits only a handful of entries per row.
-// The next tile's first DMA is issued before the selection runs, so its HBM latency is
-// hidden behind the compares.
+// 8 query rows (a lower bound of the query's final KSEL-th best score, so nothing that can
+// end up in the top KSEL is ever dropped).  Survivors are rare; a survivor is
+//   * appended to its row's SEGMENT of this slice in global memory ([Q][slices][2 KSEL] keys,
+//     slot from a per-row LDS counter, fire-and-forget store: no sorting in the scan), and
+//   * counted in the query's global score HISTOGRAM (64 buckets of 2^17 fp32 ulps above the
+//     pre-pass bound, shared by all slices of the query: one non-returning L2 atomic).
+// Every few tiles a workgroup re-reads the histograms of its 256 queries: the lower edge of
+// the highest bucket with KSEL or more scores at or above it is a valid admission bound that
+// reflects what ALL slices have seen so far -- close to the bound a sequential scan would
+// have (measured: ~4x fewer survivors than per-slice running bounds give, and no sorted
+// lists to maintain).  A separate kernel picks each query's best KSEL out of its segments.
+// Only when a row's segment is full do its survivors go to a 2048-entry LDS queue, which is
+// drained by sorting it and merging each row's entries with its segment (the slow, exact
+// path: adversarially ordered galleries, huge tie groups); if even the queue overflows, the
+// tile is recomputed by column groups.  The admission scores are seeded by a pre-pass over
+// the first rows of the gallery (topk.hip).  The next tile's first DMA is issued before the
+// selection runs, so its HBM latency is hidden behind the compares.
 #include "gemm256_core.h"
 #include "kernels.h"
 
 namespace revo {
 
-constexpr int S256_QCAP = 2048;          // queue entries
+constexpr int S256_QCAP = 2048;          // overflow-queue entries
 constexpr int S256_DRAIN = 1792;         // drain once this many are queued (256 slots of slack for the next tile)
-constexpr int S256_LDS = G256_LDS + S256_QCAP * 8 + 256 * 4 * 3 + 64 + 8 * 128 * 8 + 256 * 8;   // + queue, tau/start/end, ctrl, merge scratch, wkey
+constexpr int S256_NB = 64;              // histogram buckets per query
+constexpr int S256_SH = 17;              // bucket width: 2^17 ulps of the fp32 score (1.6 % of the value; 64 buckets = one binade)
+// Scope of the histogram traffic.  Workgroup scope makes the counters live in the L2 of the issuing XCD (atomics
+// always execute in L2; the load only skips the CU's L1): ~0.6 us instead of a trip over the fabric to memory, which
+// is what agent scope costs on a part with one L2 per XCD, and what every wave then waits for at the first
+// vmcnt wait of its next main loop.  The price: the eight XCDs hold eight partial copies of a histogram.  That is
+// safe -- a copy is "what memory held when the line was fetched" plus this XCD's own increments, so it never
+// exceeds the true count and the derived bound only lags -- and nearly free: the launcher maps all slices of a
+// query tile to one XCD whenever there are at least 8 query tiles (fewer query tiles: each XCD tightens on its
+// own eighth of the gallery, and the scan is HBM-bound there anyway).
+#define S256_HIST_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+// main-loop image + queue + tau / base / start / end / cnt (256 x 4 B each) + ctrl + merge scratch + wkey
+constexpr int S256_LDS = G256_LDS + S256_QCAP * 8 + 256 * 4 * 5 + 64 + 8 * 128 * 8 + 256 * 8;
+static_assert(S256_LDS <= 163840, "the scan needs more LDS than a CU has");
+
+// LDS byte offsets of the selection state behind the main-loop image (the dynamic LDS block starts at 0: no
+// static LDS in these kernels; gemm256_core.h addresses its fragments the same way)
+constexpr uint32_t S256_TAU_OFF = G256_LDS + S256_QCAP * 8;
+constexpr uint32_t S256_CNT_OFF = S256_TAU_OFF + 256 * 4 * 4;
+constexpr uint32_t S256_CTRL_OFF = S256_CNT_OFF + 256 * 4;
+// atomicAdd(&cnt, 1) on LDS as raw ISA.  Through the compiler every LDS atomic here is preceded by
+// s_waitcnt vmcnt(0): the next tile's operand DMA (buffer_load ... lds) is in flight and the waitcnt pass cannot
+// tell that it writes a different part of LDS -- so every survivor waited for that DMA AND for the global store and
+// histogram atomic of the survivor before it (a full L2 round trip each: this was most of the selection's cost).
+__device__ __forceinline__ int s256_lds_inc(uint32_t lds_byte_addr) {
+    int old;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(lds_byte_addr), "v"(1) : "memory");
+    return old;
+}
+// workgroup barrier that orders LDS traffic only (__syncthreads() also drains vmcnt: the next tile's operand DMA and
+// the selection's fire-and-forget global stores would have to land first)
+__device__ __forceinline__ void s256_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ __forceinline__ uint64_t s256_entry(int row, float score, uint32_t relidx) {
     return ((uint64_t)row << 56) | ((uint64_t)f32_orderable(score) << 24) | (uint64_t)((~relidx) & 0xffffffu);
@@ -40,94 +79,139 @@ __device__ __forceinline__ uint64_t s256_shfl_up1(uint64_t v) {
     const uint32_t lo = __shfl_up((uint32_t)v, 1, 64), hi = __shfl_up((uint32_t)(v >> 32), 1, 64);
     return ((uint64_t)hi << 32) | lo;
 }
-
-struct S256Lds {
-    uint64_t* queue;     // [S256_QCAP]
-    float* tau;          // [256] admission score per query row of the tile
-    int* start;          // [256]
-    int* end;            // [256]
-    int* ctrl;           // [0] queue count (may exceed the capacity: overflow), [1..] spare
-    uint64_t* scratch;   // [8][64] wave-private
-    uint64_t* wkey;      // [256] key of the row's KSEL-th list entry (0 while the list is not full)
-};
-
-__device__ __forceinline__ uint32_t s256_sort_desc_u32(uint32_t v, int lane) {
+__device__ __forceinline__ uint64_t s256_readlane(uint64_t v, int l) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)v, l) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(v >> 32), l) << 32);
+}
+// the 64 lane values sorted, largest in lane 0
+__device__ __forceinline__ uint64_t s256_sort_desc(uint64_t v, int lane) {
 #pragma unroll
     for (int k2 = 2; k2 <= 64; k2 <<= 1) {
 #pragma unroll
         for (int j = k2 >> 1; j > 0; j >>= 1) {
-            const uint32_t o = __shfl_xor(v, j, 64);
+            const uint64_t o = s256_shfl_xor(v, j);
             const bool take_max = (((lane & j) == 0) == ((lane & k2) == 0));
             v = take_max ? (v > o ? v : o) : (v < o ? v : o);
         }
     }
     return v;
 }
-__device__ __forceinline__ uint32_t s256_merge_desc_u32(uint32_t v, int lane) {   // v bitonic across the wave
+// v bitonic across the wave -> sorted, largest in lane 0
+__device__ __forceinline__ uint64_t s256_bitonic_merge_desc(uint64_t v, int lane) {
 #pragma unroll
     for (int j = 32; j > 0; j >>= 1) {
-        const uint32_t o = __shfl_xor(v, j, 64);
+        const uint64_t o = s256_shfl_xor(v, j);
         v = ((lane & j) == 0) ? (v > o ? v : o) : (v < o ? v : o);
     }
     return v;
 }
 
-// Cross-slice admission bound.  Every slice of a query publishes the scores of its best `top_m` list
-// entries (gtop[q][slice][top_m], order-preserving u32, written at drains).  Those are distinct gallery
-// rows, so the KSEL-th largest of their union is a lower bound of the query's final KSEL-th best score --
-// and a tight one: the global top KSEL is spread over the slices, few slices hold more than top_m of it.
-// One slice's own KSEL-th best only reaches the KSEL / slice-rows quantile (measured: ~6x more queued
-// entries than necessary at 32 slices).  All 512 threads; one wave per row, rows strided by 8.
+// One step of "list := best KSEL distinct keys of (list u new keys)".
+//   KSEL = 32: cur = the list in lanes 0..31 (best first, 0 = empty), fresh = up to 32 new keys in lanes 32..63,
+//              WORST FIRST (lane 63 holds the best new key).
+//   KSEL = 64: cur = the list in all 64 lanes, fresh = up to 64 new keys in all lanes, worst first.
+// Keys may repeat (a tile that is recomputed after a queue overflow finds its survivors again): equal keys
+// are dropped after the merge and the survivors are compacted through the wave's LDS scratch `ws` (128 slots;
+// LDS operations of one wave complete in order).
 template <int KSEL>
-__device__ __noinline__ void s256_refresh_bounds(const S256Lds& L, const uint32_t* gtop, int q0, int qvalid, int nvals,
-                                                 int tid, unsigned long long* stats) {
+__device__ __forceinline__ uint64_t s256_merge_step(uint64_t cur, uint64_t fresh, uint64_t* ws, int lane) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (KSEL == 32) {
+        uint64_t v = lane < 32 ? cur : fresh;       // best-first then worst-first: bitonic
+        v = s256_bitonic_merge_desc(v, lane);
+        const uint64_t prev = s256_shfl_up1(v);
+        const bool keep = v != 0ull && (lane == 0 || v != prev);
+        const unsigned long long km = __ballot(keep);
+        ws[lane] = 0ull;
+        if (keep) ws[__popcll(km & below)] = v;
+        return lane < KSEL ? ws[lane] : 0ull;
+    } else {
+        // a 128-element bitonic merge held in two registers: hi = element-wise maximum (the best 64, bitonic),
+        // lo = minimum (the rest, bitonic); both are sorted, duplicates dropped across the whole 128, and the
+        // first 64 survivors are the new list
+        uint64_t hi = cur > fresh ? cur : fresh, lo = cur > fresh ? fresh : cur;
+        hi = s256_bitonic_merge_desc(hi, lane);
+        lo = s256_bitonic_merge_desc(lo, lane);
+        const uint64_t hprev = s256_shfl_up1(hi), lprev = s256_shfl_up1(lo);
+        const uint64_t hlast = s256_readlane(hi, 63);
+        const bool keep_h = hi != 0ull && (lane == 0 || hi != hprev);
+        const bool keep_l = lo != 0ull && lo != (lane == 0 ? hlast : lprev);
+        const unsigned long long mh = __ballot(keep_h), ml = __ballot(keep_l);
+        const int nh = __popcll(mh);
+        ws[lane] = 0ull;
+        ws[64 + lane] = 0ull;
+        if (keep_h) ws[__popcll(mh & below)] = hi;
+        if (keep_l) ws[nh + __popcll(ml & below)] = lo;
+        return ws[lane];
+    }
+}
+
+struct S256Lds {
+    uint64_t* queue;     // [S256_QCAP] overflow queue
+    float* tau;          // [256] admission score per query row of the tile
+    uint32_t* base;      // [256] order-preserving u32 of the pre-pass bound: histogram origin of the row
+    int* start;          // [256]
+    int* end;            // [256]
+    int* cnt;            // [256] entries appended to the row's segment so far (may run past the capacity: those went to the queue)
+    int* ctrl;           // [0] queue count (may exceed the capacity: overflow), [1..] spare
+    uint64_t* scratch;   // [8][128] wave-private
+    uint64_t* wkey;      // [256] key of the row's KSEL-th best entry as of its last drain (0 = never drained / fewer than KSEL)
+};
+
+// Admission bounds from the global histograms.  hist[q][b] counts the scores of query q that any slice
+// has appended so far (plus the pre-pass list) whose order-preserving u32 lies in
+// [base + (b << SH), base + ((b + 1) << SH))  (the last bucket is open-ended).  If the buckets b.. hold at
+// least KSEL scores, KSEL distinct gallery rows score at least the lower edge of bucket b: a valid lower
+// bound of the query's final KSEL-th best.  Counts only ever lag (a store may not have landed yet): stale
+// reads give weaker bounds, never wrong ones.  One wave per row, rows strided by 8, eight rows of loads in flight.
+template <int KSEL>
+__device__ __noinline__ void s256_refresh_hist(const S256Lds& L, const uint32_t* hist, const uint32_t* tau_g, int q0,
+                                               int qvalid, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
-    for (int r = wave; r < qvalid; r += 8) {
-        const uint32_t* row = gtop + (long)(q0 + r) * nvals;
-        uint32_t run = 0u;                                        // lanes 0..31: best KSEL so far, descending
-        for (int base = 0; base < nvals; base += 128) {
-            const int i0 = base + lane * 2;
-            uint32_t v0 = 0u, v1 = 0u;
-            if (i0 < nvals) v0 = __hip_atomic_load(row + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (i0 + 1 < nvals) v1 = __hip_atomic_load(row + i0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t a = s256_sort_desc_u32(v0 > v1 ? v0 : v1, lane);
-            const uint32_t b = s256_sort_desc_u32(v0 > v1 ? v1 : v0, lane);
-            // best 32 of the chunk: a[0..31] descending next to b[31..0] ascending is bitonic
-            const uint32_t brev = __shfl(b, 63 - lane, 64);      // all lanes take part: a shuffle reads 0 from inactive lanes
-            if (KSEL == 32) {
-                uint32_t x = lane < 32 ? a : brev;
-                x = s256_merge_desc_u32(x, lane);
-                const uint32_t xrev = __shfl(x, 63 - lane, 64);
-                uint32_t y = lane < 32 ? run : xrev;
-                y = s256_merge_desc_u32(y, lane);
-                run = lane < 32 ? y : 0u;
-            } else {
-                // best 64 of the 128: the element-wise maximum of a descending and an ascending run is bitonic
-                uint32_t x = a > brev ? a : brev;
-                x = s256_merge_desc_u32(x, lane);
-                const uint32_t xrev = __shfl(x, 63 - lane, 64);
-                uint32_t y = run > xrev ? run : xrev;
-                run = s256_merge_desc_u32(y, lane);
-            }
+    // the drain-published bounds of this wave's 32 rows (rows wave + 8 i), one per lane
+    uint32_t tgv = 0u;
+    if (lane < 32 && wave + 8 * lane < qvalid)
+        tgv = __hip_atomic_load(tau_g + q0 + wave + 8 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i0 = 0; i0 < 32; i0 += 8) {
+        uint32_t h[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = wave + 8 * (i0 + u);
+            h[u] = r < qvalid ? __hip_atomic_load(hist + (long)(q0 + r) * S256_NB + lane, __ATOMIC_RELAXED, S256_HIST_SCOPE) : 0u;
         }
-        const uint32_t bound = (uint32_t)__builtin_amdgcn_readlane((int)run, KSEL - 1);
-        if (lane == 0 && bound != 0u) {
-            const float b = orderable_f32(bound);
-            if (stats) atomicAdd(stats + (b > L.tau[r] ? 4 : 5), 1ull);
-            if (b > L.tau[r]) L.tau[r] = b;
-        } else if (lane == 0 && stats) {
-            atomicAdd(stats + 6, 1ull);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = wave + 8 * (i0 + u);
+            if (r >= qvalid) break;                                   // wave-uniform
+            // suffix sums: s[lane] = h[lane] + h[lane + 1] + ... + h[63]
+            uint32_t sfx = h[u];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_down(sfx, o, 64);
+                sfx += (lane + o < 64) ? t : 0u;
+            }
+            const unsigned long long m = __ballot(sfx >= (uint32_t)KSEL);
+            if (lane == 0) {
+                float t = orderable_f32((uint32_t)__builtin_amdgcn_readlane((int)tgv, i0 + u));
+                if (m) {
+                    const int b = 63 - __builtin_clzll(m);
+                    const float th = orderable_f32(L.base[r] + ((uint32_t)b << S256_SH));
+                    t = th > t ? th : t;
+                }
+                if (t > L.tau[r]) L.tau[r] = t;
+            }
         }
     }
     __syncthreads();
 }
 
-// All 512 threads.  Sort the queue (row, score, index descending), merge every row's best
-// entries into its global list, refresh the admission scores, empty the queue.
+// All 512 threads; the slow, exact path.  Sort the overflow queue (row, score, index descending) and, for
+// every row that has queued entries, merge them with the row's segment into the row's best KSEL distinct
+// keys: those go back to the head of the segment (sorted, best first), the rest of it is free again.
 template <int KSEL>
-__device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* part, long part_row_stride, int q0, int qvalid,
-                                        uint32_t idx_base, int tid, uint32_t* tau_g, uint32_t* gtop_mine, int gtop_stride,
-                                        int top_m) {
+__device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* seg0, long seg_row_stride, int q0, int qvalid,
+                                        uint32_t idx_base, int tid, uint32_t* tau_g) {
+    constexpr int SEG = 2 * KSEL;
     const int wave = tid >> 6, lane = tid & 63;
     __syncthreads();
     int n = L.ctrl[0];
@@ -158,87 +242,55 @@ __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* part, long p
     }
     __syncthreads();
     uint64_t* ws = L.scratch + wave * 128;
-    // the lists live in global memory (L2): the next row's list is requested before the current row is
-    // merged, so the round trips of a wave's ~32 rows overlap instead of adding up
-    uint64_t nxt = 0ull;
-    if (wave < qvalid && lane < KSEL) nxt = part[(long)(q0 + wave) * part_row_stride + lane];
     for (int r = wave; r < qvalid; r += 8) {
-        uint64_t cur = nxt;                                     // lanes 0..KSEL-1: the row's list, best first
-        if (r + 8 < qvalid && lane < KSEL) nxt = part[(long)(q0 + r + 8) * part_row_stride + lane];
         const int s0 = L.start[r];
         const int cnt = L.end[r] - s0;
         if (cnt <= 0) continue;
-        uint64_t* list = part + (long)(q0 + r) * part_row_stride;
-        // The row's queued entries are merged KSEL at a time, duplicates removed after every merge: a tile
-        // that is computed again after a queue overflow re-queues entries the list already holds, and
-        // truncating the queue side before de-duplication could push new entries out.
-        for (int off = 0; off < cnt; off += KSEL) {
-            const int c = (cnt - off) < KSEL ? (cnt - off) : KSEL;
-            const uint64_t best = s256_entry_to_key(L.queue[s0 + off], idx_base);
-            const uint64_t worst_kept = __builtin_amdgcn_readlane((uint32_t)cur, KSEL - 1) |
-                                        ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(cur >> 32), KSEL - 1) << 32);
-            if (off > 0 && worst_kept != 0ull && best < worst_kept) break;   // nothing further down can enter
-            if (KSEL == 32) {
-                uint64_t v;
-                if (lane < 32) {
-                    v = cur;
-                } else {
-                    const int jx = 63 - lane;                   // lane 63 takes the chunk's best entry
-                    v = jx < c ? s256_entry_to_key(L.queue[s0 + off + jx], idx_base) : 0ull;
-                }
-                // lanes 0..31 best-first, lanes 32..63 worst-first: bitonic -> sorted best-first
-#pragma unroll
-                for (int j = 32; j > 0; j >>= 1) {
-                    const uint64_t o = s256_shfl_xor(v, j);
-                    v = ((lane & j) == 0) ? (v > o ? v : o) : (v < o ? v : o);
-                }
-                const uint64_t prev = s256_shfl_up1(v);
-                const bool keep = v != 0ull && (lane == 0 || v != prev);
-                const unsigned long long km = __ballot(keep);
-                const int pos = __popcll(km & ((1ull << lane) - 1ull));
-                ws[lane] = 0ull;
-                if (keep) ws[pos] = v;            // LDS operations of one wave complete in order
-                cur = lane < KSEL ? ws[lane] : 0ull;
-            } else {
-                // 64-entry list + up to 64 queued entries: a 128-element bitonic merge held in two registers.
-                // hi = element-wise maximum (the best 64, bitonic), lo = minimum (the rest, bitonic); both are
-                // sorted, duplicates dropped across the whole 128, and the first 64 survivors are the new list.
-                const int jx = 63 - lane;
-                const uint64_t q1 = jx < c ? s256_entry_to_key(L.queue[s0 + off + jx], idx_base) : 0ull;   // worst-first
-                uint64_t hi = cur > q1 ? cur : q1, lo = cur > q1 ? q1 : cur;
-#pragma unroll
-                for (int j = 32; j > 0; j >>= 1) {
-                    const uint64_t oh = s256_shfl_xor(hi, j), ol = s256_shfl_xor(lo, j);
-                    hi = ((lane & j) == 0) ? (hi > oh ? hi : oh) : (hi < oh ? hi : oh);
-                    lo = ((lane & j) == 0) ? (lo > ol ? lo : ol) : (lo < ol ? lo : ol);
-                }
-                const uint64_t hprev = s256_shfl_up1(hi), lprev = s256_shfl_up1(lo);
-                const uint64_t hlast = __builtin_amdgcn_readlane((uint32_t)hi, 63) |
-                                       ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(hi >> 32), 63) << 32);
-                const bool keep_h = hi != 0ull && (lane == 0 || hi != hprev);
-                const bool keep_l = lo != 0ull && lo != (lane == 0 ? hlast : lprev);
-                const unsigned long long mh = __ballot(keep_h), ml = __ballot(keep_l);
-                const unsigned long long below = (1ull << lane) - 1ull;
-                const int nh = __popcll(mh);
-                ws[lane] = 0ull;
-                ws[64 + lane] = 0ull;
-                if (keep_h) ws[__popcll(mh & below)] = hi;
-                if (keep_l) ws[nh + __popcll(ml & below)] = lo;
-                cur = ws[lane];
-            }
+        uint64_t* seg = seg0 + (long)r * seg_row_stride;
+        int c = L.cnt[r];
+        c = c < SEG ? c : SEG;
+        // the segment as it stands (appended by any wave of this workgroup, unsorted): sort it, drop repeats
+        uint64_t cur;
+        if (KSEL == 32) {
+            uint64_t v = lane < c ? __hip_atomic_load(seg + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            v = s256_sort_desc(v, lane);
+            // as a merge step with an empty list: keeps the best 32 distinct keys
+            const uint64_t lo32 = s256_shfl_xor(v, 63);          // lanes 32..63 <- v[31..0]: the best 32, worst first
+            cur = s256_merge_step<32>(0ull, lane >= 32 ? lo32 : 0ull, ws, lane);
+            // the other 32 (v[32..63]) can only matter if the best 32 held repeats
+            const uint64_t rest = s256_shfl_xor(v, 31);          // lanes 32..63 <- v[63..32]
+            if (s256_readlane(cur, 31) == 0ull) cur = s256_merge_step<32>(cur, lane >= 32 ? rest : 0ull, ws, lane);
+        } else {
+            uint64_t v0 = lane < c ? __hip_atomic_load(seg + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            uint64_t v1 = lane + 64 < c ? __hip_atomic_load(seg + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            v0 = s256_sort_desc(v0, lane);
+            v1 = s256_sort_desc(v1, lane);
+            cur = s256_merge_step<64>(0ull, s256_shfl_xor(v0, 63), ws, lane);
+            cur = s256_merge_step<64>(cur, s256_shfl_xor(v1, 63), ws, lane);
         }
-        if (lane < KSEL) list[lane] = cur;
-        if (lane == KSEL - 1) L.wkey[r] = cur;                // 0 while the list is not full
-        if (lane < top_m)                                       // publish this slice's best scores (see s256_refresh_bounds)
-            __hip_atomic_store(gtop_mine + (long)(q0 + r) * gtop_stride + lane, (uint32_t)(cur >> 32), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(cur >> 32), KSEL - 1);
-        if (lane == 0 && last != 0u) {
-            // this slice's KSEL-th best is a lower bound of the query's final KSEL-th best: publish it
-            // for the other slices of the same query (stale reads only admit a few more candidates)
-            const uint32_t seen = __hip_atomic_fetch_max(tau_g + q0 + r, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float t = orderable_f32(seen > last ? seen : last);
-            if (t > L.tau[r]) L.tau[r] = t;
+        // the row's queued entries, KSEL at a time (best chunks first)
+        for (int off = 0; off < cnt; off += KSEL) {
+            const int cc = (cnt - off) < KSEL ? (cnt - off) : KSEL;
+            const uint64_t best = s256_entry_to_key(L.queue[s0 + off], idx_base);
+            const uint64_t worst_kept = s256_readlane(cur, KSEL - 1);
+            if (worst_kept != 0ull && best < worst_kept) break;   // nothing further down can enter
+            const int jx = 63 - lane;                             // lane 63 takes the chunk's best entry
+            const uint64_t fresh = jx < cc ? s256_entry_to_key(L.queue[s0 + off + jx], idx_base) : 0ull;
+            cur = s256_merge_step<KSEL>(cur, fresh, ws, lane);
+        }
+        if (lane < KSEL) seg[lane] = cur;
+        const int kept = __popcll(__ballot(cur != 0ull));
+        const uint64_t last = s256_readlane(cur, KSEL - 1);
+        if (lane == 0) {
+            L.cnt[r] = kept;
+            L.wkey[r] = last;                                     // 0 while fewer than KSEL
+            if (last != 0ull) {
+                // this slice's KSEL-th best is a lower bound of the query's final KSEL-th best: publish it
+                const uint32_t lo = (uint32_t)(last >> 32);
+                (void)__hip_atomic_fetch_max(tau_g + q0 + r, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float t = orderable_f32(lo);
+                if (t > L.tau[r]) L.tau[r] = t;
+            }
         }
     }
     __syncthreads();
@@ -252,67 +304,86 @@ struct Scan256Args {
     int Q; long N; int D;
     long n_begin;                 // rows [0, n_begin) are covered by the pre-pass
     int splits;
-    uint64_t* part;               // [Q][lists_per_query][KSEL]; this kernel owns slots [0, splits)
-    int lists_per_query;
-    uint32_t* tau_g;              // [Q] shared admission scores (order-preserving u32 of the score), seeded by the pre-pass
-    int dbg;                      // timing experiments only: 1 = skip the selection (results are wrong)
-    uint32_t* gtop;               // [Q][splits][top_m] best list scores of every slice (zeroed before the launch)
-    int top_m;
-    unsigned long long* stats;    // optional counters: [0] drains, [1] queued entries, [2] retry passes, [3] fragments scanned slowly
+    int qt_pad;                   // query tiles per slice in the block order (the real count, rounded up to 8 when >= 8)
+    uint64_t* seg;                // [Q][splits][2 KSEL] appended keys (score desc / index asc order, unsorted)
+    int* seg_cnt;                 // [Q][splits] valid entries of each segment (written when the slice is done)
+    uint32_t* tau_g;              // [Q] shared admission scores (order-preserving u32), seeded by the pre-pass, raised by drains
+    const uint32_t* tau_base;     // [Q] the pre-pass bound, constant during the scan: origin of the histogram buckets
+    uint32_t* hist;               // [Q][S256_NB] score histogram shared by all slices (seeded with the pre-pass list)
+    int dbg;                      // timing experiments only (REVO_EXPERIMENTS): 1 = skip the selection, 4 = skip the slow path, 8 = no global stores / atomics from the selection, 16 = no refreshes (wrong results)
+    unsigned long long* stats;    // optional counters (REVO_EXPERIMENTS): [0] drains, [1] queued entries, [2] retry passes, [3] fragments scanned slowly, [4] appended entries, [5] refreshes
 };
 
 // ROWS: 0 = all 256 query rows of a tile may be valid; 64 / 128 = the whole search has at most that many
 // queries (one query tile), and the main loop skips the MFMA work of the rows that cannot be valid.
 template <int KSEL, int ROWS>
 __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Args p) {
+    constexpr int SEG = 2 * KSEL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     S256Lds L;
     L.queue = (uint64_t*)(smem + G256_LDS);
     L.tau = (float*)(smem + G256_LDS + S256_QCAP * 8);
-    L.start = (int*)(L.tau + 256);
+    L.base = (uint32_t*)(L.tau + 256);
+    L.start = (int*)(L.base + 256);
     L.end = L.start + 256;
-    L.ctrl = L.end + 256;
+    L.cnt = L.end + 256;
+    L.ctrl = L.cnt + 256;
     L.scratch = (uint64_t*)(L.ctrl + 16);
     L.wkey = L.scratch + 8 * 128;
+    static_assert(S256_CNT_OFF == G256_LDS + S256_QCAP * 8 + (256 + 256 + 256 + 256) * 4, "cnt follows tau, base, start, end");
 
+#ifndef REVO_EXPERIMENTS
+    // the product build has no timing switches and no counters: these fold to constants
+    p.dbg = 0;
+    p.stats = nullptr;
+#endif
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = tid & 63;
-    const int q0 = blockIdx.x * 256;
-    const int sp = blockIdx.y;
+    // 1-D grid, block b -> (query tile b % qt_pad, slice b / qt_pad).  Blocks are dealt to the 8 XCDs round-robin,
+    // so with qt_pad a multiple of 8 all slices of a query tile run on one XCD (shared L2: histograms, query rows)
+    const int qtile = blockIdx.x % p.qt_pad;
+    const int sp = blockIdx.x / p.qt_pad;
+    const int q0 = qtile * 256;
+    if (q0 >= p.Q) return;                                  // padding block
     const int qvalid = (p.Q - q0) < 256 ? (p.Q - q0) : 256;
 
+    // slices: the tiles are dealt out as evenly as possible (the first `rem` slices take one more)
     const long span = p.N - p.n_begin;
     const long tiles = (span + 255) / 256;
-    const long per = (tiles + p.splits - 1) / p.splits;
-    const long t0 = sp * per;
-    const long t1 = (t0 + per) < tiles ? (t0 + per) : tiles;
+    const long per = tiles / p.splits, rem = tiles - per * p.splits;
+    const long t0 = sp * per + (sp < rem ? sp : rem);
+    const long t1 = t0 + per + (sp < rem ? 1 : 0);
     const long row_begin = p.n_begin + t0 * 256;            // first gallery row of this slice
     const uint32_t idx_base = (uint32_t)row_begin;
-    uint64_t* mypart = p.part + (long)sp * KSEL;
-    const long part_row_stride = (long)p.lists_per_query * KSEL;
+    const long seg_row_stride = (long)p.splits * SEG;
+    uint64_t* myseg = p.seg + ((long)q0 * p.splits + sp) * SEG;      // row r of the tile: + r * seg_row_stride
+    uint32_t* myhist = p.hist + (long)q0 * S256_NB;
 
-    if (tid < 256) L.tau[tid] = tid < qvalid ? orderable_f32(p.tau_g[q0 + tid]) : INFINITY;
-    if (tid < 256) L.wkey[tid] = 0ull;
+    if (tid < 256) {
+        L.tau[tid] = tid < qvalid ? orderable_f32(p.tau_g[q0 + tid]) : INFINITY;
+        L.base[tid] = tid < qvalid ? p.tau_base[q0 + tid] : 0u;
+        L.wkey[tid] = 0ull;
+        L.cnt[tid] = 0;
+    }
     if (tid == 0) L.ctrl[0] = 0;
     __syncthreads();
-    if (t0 >= t1) return;
+    if (t0 >= t1) {
+        if (tid < qvalid) p.seg_cnt[(long)(q0 + tid) * p.splits + sp] = 0;
+        return;
+    }
 
     G256Operand A, B;
     g256_operand_init(A, p.Qb, p.ldq, p.Q, q0, wave, lane);
     g256_operand_init(B, p.Gb + row_begin * p.ldg, p.ldg, p.N - row_begin, 0, wave, lane);
     g256_issue_prologue(A, B, smem, p.D, wave);
 
-    // Normal mode: one pass per tile (groups == 1).  If a pass admits more entries than the queue holds
-    // (a badly seeded or adversarially ordered gallery), the tile is recomputed in 2, 4, ... 32 column
-    // groups, one pass and one drain per group; at 32 groups a pass can admit at most 256 x 8 = 2048
-    // entries, so the retry always terminates.  Entries queued twice are removed when lists are merged.
+    // Normal mode: one pass per tile (groups == 1).  If a pass pushes more entries to the overflow queue than
+    // it holds (an adversarially ordered gallery), the tile is recomputed in 2, 4, ... 32 column groups, one
+    // pass and one drain per group; at 32 groups a pass can admit at most 256 x 8 = 2048 entries, so the
+    // retry always terminates.  Entries found twice are dropped when lists are merged (drain, final reduce).
     long t = t0;
     int groups = 1, grp = 0;
-    // (Measured with the debug counters: ~8100 entries are queued per workgroup at Q = 10k, N = 1M, 32
-    //  slices.  That number is set by how tight a bound ONE slice's KSEL-th best can give, about the
-    //  KSEL / slice-rows quantile; draining earlier or more often does not lower it.)
-    const int drain_thr = S256_DRAIN;
     while (t < t1) {
         const long n0 = p.n_begin + t * 256;
         {
@@ -338,32 +409,46 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
             const uint32_t rel0 = (uint32_t)(n0 - row_begin);
             float taum[8];
             unsigned hitm = 0;             // bit m: some lane of this wave has a candidate in row fragment m
-            if (p.dbg & 1) {
-                asm volatile("" :: "v"(acc[0][0]), "v"(acc[7][3]));
-            } else
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                taum[m] = L.tau[rbase + m * 16];
-                float mx = -INFINITY;
+            if (left < 256) {
+                // the gallery's last, ragged tile: columns past the end become NaN (never admitted, ignored by
+                // fmaxf).  One uniform branch per tile; inside the loops below the same test cost two scalar
+                // instructions and a branch per score.
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        // columns past the gallery end become NaN: never admitted, ignored by fmaxf
-                        if (left < 256 && cbase + n * 16 + j >= left) acc[m][n][j] = __builtin_nanf("");
-                        mx = fmaxf(mx, acc[m][n][j]);
+                        const bool past = cbase + n * 16 + j >= left;
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) acc[m][n][j] = past ? __builtin_nanf("") : acc[m][n][j];
                     }
-                if (__ballot(mx >= taum[m]) != 0ull) hitm |= 1u << m;
+            }
+            if (p.dbg & 1) {
+                asm volatile("" :: "v"(acc[0][0]), "v"(acc[7][3]));
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) taum[m] = L.tau[rbase + m * 16];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, acc[m][n][j]);
+                    if (__ballot(mx >= taum[m]) != 0ull) hitm |= 1u << m;
+                }
             }
             if (hitm && !(p.dbg & 4)) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     if (!(hitm & (1u << m))) continue;          // wave-uniform
                     if (p.stats && lane == 0) atomicAdd(p.stats + 3, 1ull);
-                    // the row's current KSEL-th entry as (score, index); an empty slot admits everything
-                    const uint64_t wk = L.wkey[rbase + m * 16];
+                    const int row = rbase + m * 16;
+                    // the row's KSEL-th best as of its last drain, as (score, index); none yet admits everything
+                    const uint64_t wk = L.wkey[row];
                     const float ws = wk ? key_score(wk) : -INFINITY;
                     const uint32_t widx = wk ? key_index(wk) : 0xffffffffu;
+                    const uint32_t bo = L.base[row];
+                    uint64_t* segrow = myseg + (long)row * seg_row_stride;
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -371,46 +456,57 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
                             const float v = acc[m][n][j];
                             const int col = cbase + n * 16 + j;
                             // admission score (shared across slices) first, then the strict test against the
-                            // row's own KSEL-th entry: an equal score enters only with a smaller index, so
-                            // ties cannot keep the queue full forever.  Survivors are rare: each lane queues
-                            // its own (one LDS atomic per survivor) under a mostly empty exec mask.
-                            if (v >= taum[m] && (col & (groups - 1)) == grp &&
+                            // row's own KSEL-th entry: an equal score enters only with a smaller index, so a
+                            // huge tie group cannot keep the queue full forever.  Survivors are rare: each lane
+                            // places its own under a mostly empty exec mask.
+                            const bool pass = v >= taum[m];
+                            if (__ballot(pass) == 0ull) continue;       // wave-uniform: most elements of a hit fragment fail too
+                            if (pass && (col & (groups - 1)) == grp &&
                                 (v > ws || (v == ws && idx_base + rel0 + col < widx))) {
-                                const int pos = atomicAdd(&L.ctrl[0], 1);
-                                if (pos < S256_QCAP) L.queue[pos] = s256_entry(rbase + m * 16, v, rel0 + col);
+                                const int slot = s256_lds_inc(S256_CNT_OFF + row * 4);
+                                if (slot < SEG) {
+                                    if (p.dbg & 8) continue;       // timing experiment: no global traffic from the selection
+                                    if (!(p.dbg & 32)) segrow[slot] = make_key(v, idx_base + rel0 + col);
+                                    if (groups == 1) {             // a recomputed tile must not be counted twice
+                                        uint32_t b = (f32_orderable(v) - bo) >> S256_SH;
+                                        b = b < (uint32_t)(S256_NB - 1) ? b : (uint32_t)(S256_NB - 1);
+                                        (void)__hip_atomic_fetch_add(myhist + (long)row * S256_NB + b, 1u, __ATOMIC_RELAXED,
+                                                                     S256_HIST_SCOPE);
+                                    }
+                                    if (p.stats) atomicAdd(p.stats + 4, 1ull);
+                                } else {
+                                    const int pos = s256_lds_inc(S256_CTRL_OFF);
+                                    if (pos < S256_QCAP) L.queue[pos] = s256_entry(row, v, rel0 + col);
+                                }
                             }
                         }
                 }
             }
         }
-        // the accumulators are dead from here on (the drain is a real call)
-        __syncthreads();
+        // the accumulators are dead from here on (refresh and drain are real calls)
+        s256_barrier_lds();
         const int qc = L.ctrl[0];
-        // pick up what the other slices of these queries have learnt meanwhile (ordered before the next
-        // selection by the barriers of the next main loop)
-        // (every fourth tile: the load is an L2 round trip that four waves would otherwise sit on after every tile)
-        if ((t & 3) == 0 && tid < qvalid) {
-            const float tg = orderable_f32(__hip_atomic_load(p.tau_g + q0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (tg > L.tau[tid]) L.tau[tid] = tg;
-        }
         const bool overflow = qc > S256_QCAP;
-        if (groups == 1 && !overflow && (t & 15) == 15)
-            s256_refresh_bounds<KSEL>(L, p.gtop, q0, qvalid, p.splits * p.top_m, tid, p.stats);
         if (p.stats && tid == 0) {
             if (overflow || groups > 1) atomicAdd(p.stats + 2, 1ull);
-            if (overflow || groups > 1 || qc >= drain_thr || t + 1 >= t1) { atomicAdd(p.stats + 0, 1ull); atomicAdd(p.stats + 1, (unsigned long long)qc); }
+            if (overflow || groups > 1 || qc >= S256_DRAIN || (t + 1 >= t1 && qc > 0)) { atomicAdd(p.stats + 0, 1ull); atomicAdd(p.stats + 1, (unsigned long long)qc); }
         }
         if (groups == 1 && !overflow) {
-            if (qc >= drain_thr || t + 1 >= t1) {
-                s256_drain<KSEL>(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g, p.gtop + sp * p.top_m, p.splits * p.top_m,
-                           p.top_m);
+            if (qc >= S256_DRAIN || (t + 1 >= t1 && qc > 0))
+                s256_drain<KSEL>(L, myseg, seg_row_stride, q0, qvalid, idx_base, tid, p.tau_g);
+            // what all slices of these queries have learnt meanwhile: after the first two tiles (the bound moves
+            // fastest early on: it follows KSEL / rows seen), then every fourth tile, every 16th from tile 32 on
+            // (each refresh is an L2 round trip plus ~3 us of wave scans)
+            const long tl = t - t0;
+            if (t + 1 < t1 && !(p.dbg & 17) && (tl < 2 || ((tl & 3) == 3 && tl < 32) || (tl & 15) == 15)) {
+                if (p.stats && tid == 0) atomicAdd(p.stats + 5, 1ull);
+                s256_refresh_hist<KSEL>(L, p.hist, p.tau_g, q0, qvalid, tid);
             }
             ++t;
             continue;
         }
         // retry mode (or entering it): merge what was queued, then recompute this tile / its next column group
-        s256_drain<KSEL>(L, mypart, part_row_stride, q0, qvalid, idx_base, tid, p.tau_g, p.gtop + sp * p.top_m, p.splits * p.top_m,
-                           p.top_m);
+        s256_drain<KSEL>(L, myseg, seg_row_stride, q0, qvalid, idx_base, tid, p.tau_g);
         if (overflow) {
             groups = groups < 32 ? groups * 2 : 32;
             grp = 0;
@@ -427,8 +523,92 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
             g256_issue_prologue(A, B, smem, p.D, wave);
         }
     }
+    if (tid < qvalid) {
+        const int c = L.cnt[tid];
+        p.seg_cnt[(long)(q0 + tid) * p.splits + sp] = c < SEG ? c : SEG;
+    }
 }
 
+// ---------------------------------------------------------------- the final selection ----
+// One workgroup of RW waves per query: the query's best KSEL distinct keys out of the pre-pass list and the
+// segments of all slices.  Wave w packs the segments of slices w, w + RW, ... into 64-key chunks (whole
+// segments, so that a repeated key always sits in one chunk or in consecutive ones), sorts each chunk
+// and merges it into its running list; the RW partial lists meet in LDS and wave 0 merges them.
+constexpr int S256_RW = 8;
+template <int KSEL>
+__device__ __forceinline__ uint64_t s256_fold_chunk(uint64_t run, uint64_t chunk, uint64_t* ws, int lane) {
+    chunk = s256_sort_desc(chunk, lane);
+    if (KSEL == 32) {
+        // best 32 of the chunk, then (only if they can matter) the other 32
+        run = s256_merge_step<32>(run, s256_shfl_xor(chunk, 63), ws, lane);          // lanes 32..63 <- chunk[31..0]
+        const uint64_t worst = s256_readlane(run, 31), next = s256_readlane(chunk, 32);
+        if (next != 0ull && (worst == 0ull || next > worst))
+            run = s256_merge_step<32>(run, s256_shfl_xor(chunk, 31), ws, lane);      // lanes 32..63 <- chunk[63..32]
+        return run;
+    } else {
+        return s256_merge_step<64>(run, s256_shfl_xor(chunk, 63), ws, lane);
+    }
+}
+template <int KSEL>
+__global__ __launch_bounds__(S256_RW * 64) void topk_reduce_segs_kernel(const uint64_t* __restrict__ seg,
+                                                                       const int* __restrict__ seg_cnt, int splits,
+                                                                       const uint64_t* __restrict__ prelist,
+                                                                       uint64_t* __restrict__ out) {
+    constexpr int SEG = 2 * KSEL;
+    __shared__ uint64_t partial[S256_RW][64];
+    __shared__ uint64_t wsb[S256_RW][128];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long q = blockIdx.x;
+    uint64_t* ws = wsb[w];
+    uint64_t run = (w == 0 && lane < KSEL) ? prelist[q * KSEL + lane] : 0ull;
+    uint64_t chunk = 0ull;
+    int fill = 0;                                      // wave-uniform
+    const int* cq = seg_cnt + q * splits;
+    const uint64_t* sq = seg + q * (long)splits * SEG;
+    // this wave's counts, one slice per lane (slices w + RW * lane), 64 slices at a time
+    for (int sb = w; sb < splits; sb += S256_RW * 64) {
+        const int my = sb + S256_RW * lane;
+        const int cl = my < splits ? cq[my] : 0;
+        const int nlan = (splits - sb + S256_RW - 1) / S256_RW;
+        for (int i = 0; i < (nlan < 64 ? nlan : 64); ++i) {
+            int c = __builtin_amdgcn_readlane(cl, i);
+            if (c <= 0) continue;
+            const uint64_t* sp = sq + (long)(sb + S256_RW * i) * SEG;
+            int done = 0;
+            while (done < c) {
+                int take = c - done;
+                if (fill + take > 64) {
+                    if (fill > 0) { run = s256_fold_chunk<KSEL>(run, chunk, ws, lane); chunk = 0ull; fill = 0; }
+                    take = take < 64 ? take : 64;
+                }
+                if (lane >= fill && lane < fill + take) chunk = sp[done + lane - fill];
+                fill += take;
+                done += take;
+            }
+        }
+    }
+    if (fill > 0) run = s256_fold_chunk<KSEL>(run, chunk, ws, lane);
+    partial[w][lane] = run;
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll 1
+        for (int o = 1; o < S256_RW; ++o) {
+            const uint64_t other = partial[o][63 - lane];              // worst first; KSEL = 32: lanes 32..63 <- entries 31..0
+            run = s256_merge_step<KSEL>(run, other, ws, lane);
+        }
+        if (lane < KSEL) out[q * KSEL + lane] = run;
+    }
+}
+int launch_topk_reduce_segs(const uint64_t* seg, const int* seg_cnt, int splits, const uint64_t* prelist, uint64_t* out,
+                            int Q, int ksel, hipStream_t st) {
+    if (Q <= 0) return 0;
+    if (ksel == 32) hipLaunchKernelGGL((topk_reduce_segs_kernel<32>), dim3(Q), dim3(S256_RW * 64), 0, st, seg, seg_cnt, splits, prelist, out);
+    else hipLaunchKernelGGL((topk_reduce_segs_kernel<64>), dim3(Q), dim3(S256_RW * 64), 0, st, seg, seg_cnt, splits, prelist, out);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+#ifdef REVO_EXPERIMENTS
 static int g_scan_dbg = 0;
 static unsigned long long* g_scan_stats = nullptr;
 unsigned long long* topk_scan256_stats() {
@@ -436,31 +616,33 @@ unsigned long long* topk_scan256_stats() {
     return g_scan_stats;
 }
 void topk_scan256_set_debug(int d) { g_scan_dbg = d; }
-// per-slice scores published for the cross-slice bound: enough that splits x top_m comfortably exceeds KSEL
-int topk_scan256_top_m(int splits, int ksel) { return (splits >= 128 ? 1 : (splits > 32 ? 2 : 4)) * (ksel / 32); }
+#else
+constexpr int g_scan_dbg = 0;
+static unsigned long long* topk_scan256_stats() { return nullptr; }
+#endif
+int topk_scan256_hist_buckets() { return S256_NB; }
+int topk_scan256_hist_shift() { return S256_SH; }
 
 int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
-                        int splits, uint64_t* part, int lists_per_query, uint32_t* tau_g, uint32_t* gtop, int ksel,
-                        hipStream_t st) {
+                        int splits, uint64_t* seg, int* seg_cnt, uint32_t* tau_g, const uint32_t* tau_base, uint32_t* hist,
+                        int ksel, hipStream_t st) {
     REVO_REQUIRE(ksel == 32 || ksel == 64, "search: the 256 x 256 scan keeps 32 or 64 candidates per query");
     REVO_REQUIRE(D % 64 == 0 && ldq % 8 == 0 && ldg % 8 == 0, "search: D must be a multiple of 64");
     REVO_REQUIRE(N < (1ll << 32), "search: a shard holds at most 2^32 rows");
     REVO_REQUIRE(256l * ldg * 2 < (1l << 31) && 256l * ldq * 2 < (1l << 31), "search: row too long for the DMA window");
+    REVO_REQUIRE(splits >= 1 && splits <= 65535, "search: bad slice count");
     const long tiles = (N - n_begin + 255) / 256;
     const long per = (tiles + splits - 1) / splits;
     REVO_REQUIRE(per * 256 <= (1l << 24), "search: a gallery slice holds at most 2^24 rows; use more splits");
     if (Q <= 0 || N <= n_begin) return 0;
-    Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, part, lists_per_query, tau_g, g_scan_dbg, gtop,
-                  topk_scan256_top_m(splits, ksel), (g_scan_dbg & 2) ? topk_scan256_stats() : nullptr};
-    const dim3 grid((Q + 255) / 256, splits), block(G256_THREADS);
+    const int qtiles = (Q + 255) / 256;
+    const int qt_pad = qtiles >= 8 ? (qtiles + 7) / 8 * 8 : qtiles;
+    Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, qt_pad, seg, seg_cnt, tau_g, tau_base, hist, g_scan_dbg,
+                  (g_scan_dbg & 2) ? topk_scan256_stats() : nullptr};
+    const dim3 grid((unsigned)((long)qt_pad * splits)), block(G256_THREADS);
 #define S256_LAUNCH(KS, RW)                                                                                    \
     do {                                                                                                       \
-        static bool attr_ = false;                                                                             \
-        if (!attr_) {                                                                                          \
-            REVO_HIP_CHECK(hipFuncSetAttribute((const void*)topk_scan256_kernel<KS, RW>,                        \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, S256_LDS));         \
-            attr_ = true;                                                                                      \
-        }                                                                                                      \
+        REVO_FUNC_LDS((topk_scan256_kernel<KS, RW>), S256_LDS);                                                  \
         hipLaunchKernelGGL((topk_scan256_kernel<KS, RW>), grid, block, S256_LDS, st, a);                       \
     } while (0)
     const int rows_mode = Q <= 64 ? 64 : (Q <= 128 ? 128 : 0);
@@ -478,23 +660,23 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
     return 0;
 }
 
-// (query tiles x splits) should fill 256 CUs in whole rounds; slices of >= 32 tiles amortise the drains
+// Slices per query tile.  Workgroups run one per CU in rounds of 256; a slice costs its tiles plus about one
+// tile time of fixed work (pipeline fill, refreshes, the tail), and the slices of a launch are dealt out evenly,
+// so the scan takes about  rounds x (ceil(tiles / s) + 1)  tile times.  Fewer, longer slices on a tie.
 int topk_scan256_splits(int Q, long rows) {
     const int qtiles = (Q + 255) / 256;
     const long tiles = (rows + 255) / 256;
     if (tiles <= 0) return 1;
     int best = 1;
-    double best_score = -1.0;
+    double best_cost = 1e300;
     for (int s = 1; s <= 512; ++s) {
         if (s > tiles) break;
         const long per = (tiles + s - 1) / s;
-        if (s > 1 && per < 3) break;         // (short slices are fine: the pre-pass and the cross-slice bound seed the admission scores)
+        if (s > 1 && per < 3) break;
         const long wgs = (long)qtiles * s;
         const long rounds = (wgs + 255) / 256;
-        const double eff = (double)wgs / (double)(rounds * 256);
-        // prefer full rounds; among equals prefer fewer, longer slices (fewer lists, fewer drains)
-        const double score = eff - 1e-4 * s;
-        if (score > best_score) { best_score = score; best = s; }
+        const double cost = (double)rounds * ((double)per + 1.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
     }
     return best;
 }

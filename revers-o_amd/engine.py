@@ -22,9 +22,16 @@ IMAGE_F32 = 0
 IMAGE_U8 = 1
 
 
-def _require_cuda(t, name):
+def _require_cuda(t, name, device=None):
     if not t.is_cuda:
         raise _lib.RevoError(f"{name} must be a device tensor (the hot path has no CPU fallback)")
+    if device is not None and t.device != device:
+        raise _lib.RevoError(f"{name} is on {t.device} but the handle is bound to {device}")
+
+
+def _as_device(device):
+    d = device if isinstance(device, torch.device) else torch.device("cuda", int(device))
+    return torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
 
 
 class VitEngine:
@@ -32,7 +39,7 @@ class VitEngine:
 
     def __init__(self, cfg: PEConfig, state_dict, device=0, max_batch=64):
         self.cfg = cfg
-        self.device = torch.device("cuda", device) if not isinstance(device, torch.device) else device
+        self.device = _as_device(device)
         self.max_batch = int(max_batch)
         self._lock = threading.Lock()
         lib = _lib.load()
@@ -47,7 +54,7 @@ class VitEngine:
             arr[i].data = t.data_ptr()
             arr[i].numel = t.numel()
         c = _lib.VitCfg(cfg.image_size, cfg.patch_size, cfg.width, cfg.layers, cfg.heads, cfg.mlp_dim, cfg.out_dim,
-                        cfg.pool_heads, int(cfg.use_cls), int(cfg.use_ls), cfg.ln_eps, cfg.rope_theta)
+                        cfg.pool_heads, int(cfg.use_cls), int(cfg.use_ls), cfg.ln_eps, cfg.rope_theta, cfg.pool_mlp_dim)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             torch.cuda.synchronize()
@@ -74,17 +81,13 @@ class VitEngine:
         except Exception:
             pass
 
-    def set_dual_stream(self, on=True):
-        """Run forwards of >= 16 images as two half batches on two HIP streams."""
-        _lib.check(self._lib.revo_vit_set_dual_stream(self._h, int(bool(on))))
-
     # -- the embed entry point ------------------------------------------------
     def embed(self, images, normalize=True, out=None):
         """images: uint8 or float32 ``[B,3,H,W]`` device tensor at the model
         resolution (float input already normalised to [-1,1], i.e. what
         ``self.preprocess`` yields at core_system.py:439).  Returns fp32
         ``[B, out_dim]`` on the device, L2-normalised (core_system.py:447)."""
-        _require_cuda(images, "images")
+        _require_cuda(images, "images", self.device)
         cfg = self.cfg
         if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != cfg.image_size or images.shape[3] != cfg.image_size:
             raise ValueError(f"images must be [B,3,{cfg.image_size},{cfg.image_size}], got {tuple(images.shape)}")
@@ -98,7 +101,7 @@ class VitEngine:
         B = images.shape[0]
         if out is None:
             out = torch.empty((B, cfg.out_dim), dtype=torch.float32, device=images.device)
-        with self._lock, torch.cuda.device(images.device):
+        with self._lock, torch.cuda.device(self.device):
             st = _lib.current_stream()
             for s in range(0, B, self.max_batch):
                 e = min(B, s + self.max_batch)
@@ -109,12 +112,13 @@ class VitEngine:
     # -- parity-test hook -----------------------------------------------------
     def residual_after(self, images, n_layers):
         """fp32 residual stream [B, S, W] after ln_pre and the first n blocks."""
+        _require_cuda(images, "images", self.device)
         B = images.shape[0]
         assert B <= self.max_batch
         kind = IMAGE_U8 if images.dtype == torch.uint8 else IMAGE_F32
         x = torch.empty((B, self.cfg.seq, self.cfg.width), dtype=torch.float32, device=images.device)
         dummy = torch.empty((B, self.cfg.out_dim), dtype=torch.float32, device=images.device)
-        with self._lock, torch.cuda.device(images.device):
+        with self._lock, torch.cuda.device(self.device):
             st = _lib.current_stream()
             _lib.check(self._lib.revo_vit_set_debug_layers(self._h, int(n_layers)))
             try:
@@ -126,6 +130,26 @@ class VitEngine:
         return x
 
 
+    def taps(self, images):
+        """Parity-test hook: intermediate activations of one forward as fp32 CPU-comparable tensors:
+        ``embed`` [B,S,W] (patch embed + position + class token, before ln_pre), ``ln_post`` [B,S,W] (bf16 in the
+        engine), ``pooled`` [B,W] (attention-pool output before proj) and the ``embedding`` [B,D]."""
+        _require_cuda(images, "images", self.device)
+        B = images.shape[0]
+        assert B <= self.max_batch
+        cfg = self.cfg
+        out = {"embed": self.residual_after(images, -2)}
+        emb = self.embed(images)
+        lnp = torch.empty((B, cfg.seq, cfg.width), dtype=torch.bfloat16, device=self.device)
+        pooled = torch.empty((B, cfg.width), dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            st = _lib.current_stream()
+            _lib.check(self._lib.revo_vit_read_tap(self._h, 1, B, _lib.ptr(lnp), st), "revo_vit_read_tap")
+            _lib.check(self._lib.revo_vit_read_tap(self._h, 2, B, _lib.ptr(pooled), st), "revo_vit_read_tap")
+        out.update(ln_post=lnp.float(), pooled=pooled, embedding=emb)
+        return out
+
+
 class Gallery:
     """Device-resident cosine gallery: normalised rows as bf16 (scan copy) plus an
     fp32 master copy used for exact re-scoring and persistence."""
@@ -133,7 +157,7 @@ class Gallery:
     def __init__(self, dim, capacity, device=0, keep_f32=True):
         self.dim = int(dim)
         self.capacity = int(capacity)
-        self.device = torch.device("cuda", device) if not isinstance(device, torch.device) else device
+        self.device = _as_device(device)
         self._lock = threading.Lock()
         self._lib = _lib.load()
         h = C.c_void_p()
@@ -165,6 +189,8 @@ class Gallery:
         v = vectors.detach().to(torch.float32).contiguous()
         if v.dim() != 2 or v.shape[1] != self.dim:
             raise ValueError(f"vectors must be [n, {self.dim}], got {tuple(v.shape)}")
+        if v.is_cuda:
+            _require_cuda(v, "vectors", self.device)
         start = len(self)
         with self._lock, torch.cuda.device(self.device):
             _lib.check(self._lib.revo_gallery_append(self._h, _lib.ptr(v), v.shape[0], int(bool(normalize)),
@@ -186,7 +212,7 @@ class Gallery:
         indices [Q,k] int64, counts [Q] int32), best first, padded with -inf/-1
         past ``counts`` (the reference's ``limit`` / ``score_threshold`` semantics,
         core_system.py:659-664)."""
-        _require_cuda(queries, "queries")
+        _require_cuda(queries, "queries", self.device)
         q = queries.detach().to(torch.float32).contiguous()
         if q.dim() == 1:
             q = q[None]
@@ -196,12 +222,89 @@ class Gallery:
         scores = torch.empty((Q, k), dtype=torch.float32, device=q.device)
         idx = torch.empty((Q, k), dtype=torch.int64, device=q.device)
         counts = torch.empty((Q,), dtype=torch.int32, device=q.device)
-        with self._lock, torch.cuda.device(q.device):
+        with self._lock, torch.cuda.device(self.device):
             _lib.check(self._lib.revo_search_topk(
                 self._h, _lib.ptr(q), Q, int(k), int(score_threshold is not None),
                 float(score_threshold if score_threshold is not None else 0.0), int(index_offset),
                 _lib.ptr(scores), _lib.ptr(idx), _lib.ptr(counts), _lib.current_stream()), "revo_search_topk")
         return scores, idx, counts
+
+
+    def search_plan(self, n_queries, k=5):
+        """How a search would run (reporting): dict with the scan form, the pre-pass rows, slices and ksel."""
+        out = (C.c_int64 * 4)()
+        _lib.check(self._lib.revo_search_plan(self._h, int(n_queries), int(k), out), "revo_search_plan")
+        return {"scan256": bool(out[0]), "prepass_rows": int(out[1]), "slices": int(out[2]), "ksel": int(out[3])}
+
+    # -- the same search in two phases (row-sharded gallery; see sharded.py and include/revo.h) --------------
+    def search_candidates(self, queries, k=5, top_m=8):
+        """Phase 1: scan this shard, keep the candidates in the handle.  Returns int32 ``[Q, top_m]``: the bit
+        patterns of the order-preserving uint32 scan scores of each query's best ``top_m`` candidates."""
+        _require_cuda(queries, "queries", self.device)
+        q = queries.detach().to(torch.float32).contiguous()
+        if q.dim() == 1:
+            q = q[None]
+        if q.shape[1] != self.dim:
+            raise ValueError(f"queries must be [Q, {self.dim}], got {tuple(q.shape)}")
+        bounds = torch.empty((q.shape[0], int(top_m)), dtype=torch.int32, device=q.device)
+        with self._lock, torch.cuda.device(self.device):
+            _lib.check(self._lib.revo_search_candidates(self._h, _lib.ptr(q), q.shape[0], int(k), int(top_m),
+                                                        _lib.ptr(bounds), _lib.current_stream()), "revo_search_candidates")
+        return bounds
+
+    def search_finish(self, n_queries, k, all_bounds=None, score_threshold=None, index_offset=0, out_packed=None):
+        """Phase 2: fp32 re-score of the candidates that can still be among the best of the whole gallery
+        (``all_bounds``: int32 ``[parts, Q, top_m]``, the all-gathered phase-1 outputs; None = every candidate).
+        Returns (scores, indices, counts); with ``out_packed`` (uint8 ``[packed_bytes(Q, k)]``) scores and indices
+        are views into that buffer, laid out for :func:`merge_topk_packed`."""
+        Q, k = int(n_queries), int(k)
+        if out_packed is not None:
+            idx = out_packed[: Q * k * 8].view(torch.int64).view(Q, k)
+            scores = out_packed[Q * k * 8: Q * k * 12].view(torch.float32).view(Q, k)
+        else:
+            scores = torch.empty((Q, k), dtype=torch.float32, device=self.device)
+            idx = torch.empty((Q, k), dtype=torch.int64, device=self.device)
+        counts = torch.empty((Q,), dtype=torch.int32, device=self.device)
+        parts = top_m = 0
+        if all_bounds is not None:
+            _require_cuda(all_bounds, "all_bounds", self.device)
+            all_bounds = all_bounds.contiguous()
+            parts, top_m = int(all_bounds.shape[0]), int(all_bounds.shape[2])
+            if all_bounds.dtype != torch.int32 or all_bounds.shape[1] != Q:
+                raise ValueError("all_bounds must be int32 [parts, Q, top_m]")
+        with self._lock, torch.cuda.device(self.device):
+            _lib.check(self._lib.revo_search_finish(
+                self._h, Q, k, int(score_threshold is not None),
+                float(score_threshold if score_threshold is not None else 0.0), int(index_offset), _lib.ptr(all_bounds),
+                parts, top_m, _lib.ptr(scores), _lib.ptr(idx), _lib.ptr(counts), _lib.current_stream()), "revo_search_finish")
+        return scores, idx, counts
+
+
+def search_ksel(k):
+    """Candidates the scan keeps per query for a top-k search (32 or 64)."""
+    return int(_lib.load().revo_search_ksel(int(k)))
+
+
+def packed_bytes(n_queries, k):
+    """Size of one packed result block ([Q, k] int64 indices, then [Q, k] fp32 scores, padded to 16 bytes)."""
+    return int(_lib.load().revo_topk_packed_bytes(int(n_queries), int(k)))
+
+
+def merge_topk_packed(packed, parts, n_queries, k, score_threshold=None):
+    """Merge ``parts`` packed result blocks (uint8, back to back: one all-gather) into [Q, k]; K14."""
+    _require_cuda(packed, "packed")
+    Q, k = int(n_queries), int(k)
+    assert packed.dtype == torch.uint8 and packed.numel() == parts * packed_bytes(Q, k)
+    scores = torch.empty((Q, k), dtype=torch.float32, device=packed.device)
+    idx = torch.empty((Q, k), dtype=torch.int64, device=packed.device)
+    counts = torch.empty((Q,), dtype=torch.int32, device=packed.device)
+    lib = _lib.load()
+    with torch.cuda.device(packed.device):
+        _lib.check(lib.revo_topk_merge_packed(_lib.ptr(packed), int(parts), Q, k, int(score_threshold is not None),
+                                              float(score_threshold if score_threshold is not None else 0.0),
+                                              _lib.ptr(scores), _lib.ptr(idx), _lib.ptr(counts), _lib.current_stream()),
+                   "revo_topk_merge_packed")
+    return scores, idx, counts
 
 
 def merge_topk(part_scores, part_indices, k, score_threshold=None):

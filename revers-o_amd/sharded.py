@@ -1,27 +1,67 @@
 """Row-sharded gallery search across the GPUs of one node.
 
-One process per GPU; rank r owns gallery rows [offset_r, offset_r + n_r).  A
-search is: (optionally) all-gather the data-parallel query blocks, every rank scans
-its own shard for ALL queries with global row ids, one all-gather of the per-shard
-top-k (k * 12 bytes per query and rank -- latency bound on xGMI, no all-reduce),
-then the same merge on every rank.  The reference has no distributed code at all
-(single process, core_system.py:650-664); this is the build's scale-out of that call.
+One process per GPU; rank r owns gallery rows [offset_r, offset_r + n_r).  The reference has no
+distributed code at all (single process, one collection, core_system.py:650-664); this is the build's
+scale-out of that call.  A search of Q queries (identical on every rank) for the best k:
 
-The two compute steps are injected (``local_search`` / ``merge``) so that the
-protocol -- offsets, gather layout, ordering -- can be exercised on CPU with the
-gloo backend by the tests; the product wiring (:func:`from_gallery`) uses the HIP
-kernels and nothing else.
+  1. every rank scans its own shard for ALL queries (bf16 MFMA scan, the same kernels as the single-GPU
+     search) and keeps its best ``ksel`` candidates per query; it publishes the scan scores of the best
+     ``top_m`` of them                                                        [Q, top_m] int32
+  2. all-gather #1 of those scores (4 * top_m bytes per query and rank)        [P, Q, top_m]
+     -> the ksel-th largest is a lower bound of the ksel-th best scan score over the whole gallery
+  3. every rank re-scores in fp32 only its candidates at or above that bound (about ksel / P per query
+     instead of ksel: the fp32 row gathers, the part of a search that does not shrink with the shard,
+     shrink with it) and takes its local top k with global row ids
+  4. all-gather #2 of the packed per-rank results (12 * k bytes per query and rank, one buffer)
+  5. the same merge on every rank (score descending, global row id ascending).
+
+Both exchanges are latency-bound on xGMI (kilobytes to a few MB, no all-reduce).  The result equals the
+unsharded search of the concatenated gallery.
+
+The compute steps come from a *backend* object so that the protocol -- offsets, gather layouts, ordering --
+can be exercised on CPU with the gloo backend by the tests; the product wiring (:func:`from_gallery`) uses
+the HIP kernels and nothing else.  Backend interface:
+
+    ksel(k) -> int
+    candidates(queries, k, top_m) -> int32 [Q, top_m]
+    finish(n_queries, k, all_bounds [P, Q, top_m], index_offset) -> uint8 [packed_bytes(Q, k)]
+    packed_bytes(n_queries, k) -> int
+    merge(packed_all uint8 [P * packed_bytes], parts, n_queries, k, threshold) -> (scores, indices, counts)
 """
 import torch
 import torch.distributed as dist
 
 
+class GalleryBackend:
+    """The product backend: a device-resident :class:`engine.Gallery` shard."""
+
+    def __init__(self, gallery):
+        from . import engine
+        self._engine = engine
+        self.gallery = gallery
+
+    def ksel(self, k):
+        return self._engine.search_ksel(k)
+
+    def packed_bytes(self, n_queries, k):
+        return self._engine.packed_bytes(n_queries, k)
+
+    def candidates(self, queries, k, top_m):
+        return self.gallery.search_candidates(queries, k, top_m)
+
+    def finish(self, n_queries, k, all_bounds, index_offset):
+        out = torch.empty((self.packed_bytes(n_queries, k),), dtype=torch.uint8, device=self.gallery.device)
+        # the threshold is applied after the merge (a per-element predicate: same result, one code path)
+        self.gallery.search_finish(n_queries, k, all_bounds, None, index_offset, out_packed=out)
+        return out
+
+    def merge(self, packed_all, parts, n_queries, k, threshold):
+        return self._engine.merge_topk_packed(packed_all, parts, n_queries, k, threshold)
+
+
 class ShardedSearch:
-    def __init__(self, local_search, merge, local_rows, group=None):
-        """local_search(queries, k, threshold, index_offset) -> (scores[Q,k], idx[Q,k], counts[Q]);
-        merge(part_scores[P,Q,k], part_idx[P,Q,k], k, threshold) -> same triple."""
-        self.local_search = local_search
-        self.merge = merge
+    def __init__(self, backend, local_rows, group=None):
+        self.backend = backend
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -30,11 +70,7 @@ class ShardedSearch:
 
     @classmethod
     def from_gallery(cls, gallery, group=None):
-        from . import engine
-        return cls(
-            lambda q, k, thr, off: gallery.search(q, k, thr, index_offset=off),
-            lambda ps, pi, k, thr: engine.merge_topk(ps, pi, k, thr),
-            len(gallery), group)
+        return cls(GalleryBackend(gallery), len(gallery), group)
 
     def _device(self):
         if dist.is_initialized() and dist.get_backend(self.group) == "nccl":
@@ -58,7 +94,9 @@ class ShardedSearch:
     def _all_gather(self, out, inp):
         """all_gather_into_tensor; device tensors on a gloo group (a rehearsal of the N > 1 path on one GPU,
         or a CPU-only interconnect) are staged through host memory, RCCL takes them as they are."""
-        if inp.is_cuda and dist.get_backend(self.group) != "nccl":
+        if self.world == 1:
+            out.copy_(inp.reshape(out.shape))
+        elif inp.is_cuda and dist.get_backend(self.group) != "nccl":
             host = torch.empty(out.shape, dtype=out.dtype)
             dist.all_gather_into_tensor(host, inp.contiguous().cpu(), group=self.group)
             out.copy_(host)
@@ -74,15 +112,24 @@ class ShardedSearch:
         self._all_gather(out, local_queries)
         return out
 
+    def top_m(self, k):
+        """Scores published per query and rank: world * top_m >= ksel makes the bound the exact global ksel-th
+        best whenever no shard holds more than top_m of the global best ksel; at least 8 so that an uneven
+        spread of the best rows over the shards rarely loosens it."""
+        ksel = self.backend.ksel(k)
+        return min(ksel, max(8, -(-ksel // self.world)))
+
     def search(self, queries, k, threshold=None):
         """queries: identical [Q, D] on every rank.  Returns the global top-k triple on every rank."""
-        s, i, c = self.local_search(queries, k, None, self.offset)   # threshold applies after the merge
-        if self.world == 1:
-            return self.merge(s[None], i[None], k, threshold)
         Q = queries.shape[0]
-        # concatenated along dim 0 (the layout both RCCL and gloo accept), viewed as [world, Q, k]
-        ps = torch.empty((self.world * Q, k), dtype=s.dtype, device=s.device)
-        pi = torch.empty((self.world * Q, k), dtype=i.dtype, device=i.device)
-        self._all_gather(ps, s)
-        self._all_gather(pi, i)
-        return self.merge(ps.view(self.world, Q, k), pi.view(self.world, Q, k), k, threshold)
+        top_m = self.top_m(k)
+        mine = self.backend.candidates(queries, k, top_m)                        # [Q, top_m] int32
+        if self.world == 1:
+            packed = self.backend.finish(Q, k, None, self.offset)
+            return self.backend.merge(packed, 1, Q, k, threshold)
+        allb = torch.empty((self.world * Q, top_m), dtype=mine.dtype, device=mine.device)
+        self._all_gather(allb, mine)                                             # exchange 1: admission scores
+        packed = self.backend.finish(Q, k, allb.view(self.world, Q, top_m), self.offset)
+        allp = torch.empty((self.world * packed.numel(),), dtype=torch.uint8, device=packed.device)
+        self._all_gather(allp, packed)                                           # exchange 2: packed per-rank top-k
+        return self.backend.merge(allp, self.world, Q, k, threshold)

@@ -13,6 +13,7 @@ from .config import PEConfig
 
 def expected_shapes(cfg: PEConfig):
     W, M, D, P, S = cfg.width, cfg.mlp_dim, cfg.out_dim, cfg.patch_size, cfg.seq
+    PM = cfg.pool_mlp_dim          # the pool head's own MLP width (4 * W upstream), not the tower's
     sh = {
         "visual.conv1.weight": (W, 3, P, P),
         "visual.positional_embedding": (S, W),
@@ -24,8 +25,8 @@ def expected_shapes(cfg: PEConfig):
         "visual.attn_pool.attn.out_proj.weight": (W, W),
         "visual.attn_pool.attn.out_proj.bias": (W,),
         "visual.attn_pool.layernorm.weight": (W,), "visual.attn_pool.layernorm.bias": (W,),
-        "visual.attn_pool.mlp.c_fc.weight": (M, W), "visual.attn_pool.mlp.c_fc.bias": (M,),
-        "visual.attn_pool.mlp.c_proj.weight": (W, M), "visual.attn_pool.mlp.c_proj.bias": (W,),
+        "visual.attn_pool.mlp.c_fc.weight": (PM, W), "visual.attn_pool.mlp.c_fc.bias": (PM,),
+        "visual.attn_pool.mlp.c_proj.weight": (W, PM), "visual.attn_pool.mlp.c_proj.bias": (W,),
         "visual.proj": (W, D),
     }
     if cfg.use_cls:

@@ -1,5 +1,6 @@
 """Micro-benchmark + check of the body attention kernel through the C ABI."""
 import os, sys
+os.environ.setdefault("REVO_EXPERIMENTS", "1")   # timing switches live in librevo_exp.so (make -C revers-o_amd/csrc exp)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import reverso_amd

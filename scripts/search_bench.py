@@ -1,12 +1,14 @@
 """Search micro-benchmark (K12/K13): time of Gallery.search and of its kernels, with the
 MFMA / HBM roofline figures of SURVEY.md §8(d).   python scripts/search_bench.py [N] [Q ...]"""
 import os, sys, json
+os.environ.setdefault("REVO_EXPERIMENTS", "1")   # timing switches live in librevo_exp.so (make -C revers-o_amd/csrc exp)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, reverso_amd
 from reverso_amd import engine
 dev = torch.device("cuda", 0)
 from reverso_amd import _lib
-_lib.load().revo_op_set_gemm_debug(int(os.environ.get("SCAN_DBG", "0")) << 13)
+_dbg = int(os.environ.get("SCAN_DBG", "0"))     # 1 no selection, 2 counters, 4 no slow path, 8 no global traffic, 16 no refreshes
+_lib.load().revo_op_set_gemm_debug(((_dbg & 7) << 13) | ((_dbg >> 3) << 20))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 Qs = [int(a) for a in sys.argv[2:]] or [1, 64, 256, 10000]
 D, k = 1024, int(os.environ.get("TOPK", "10"))
@@ -33,7 +35,7 @@ for Q in Qs:
     if int(os.environ.get("SCAN_DBG", "0")) & 2:
         import ctypes
         st4 = (ctypes.c_int64 * 8)(); _lib.load().revo_debug_scan_stats(st4)
-        print("scan stats over", iters + 2, "searches: drains", st4[0], "queued", st4[1], "retry passes", st4[2], "slow fragments", st4[3], "bound improved/not/zero", st4[4], st4[5], st4[6])
+        print("scan stats over", iters + 2, "searches: drains", st4[0], "queued", st4[1], "retry passes", st4[2], "slow fragments", st4[3], "appended", st4[4], "refreshes", st4[5])
     print(json.dumps({"Q": Q, "N": N, "search_ms": round(ms, 4), "scan_ms": round(scan, 4),
                       "scan_TFLOPs": round(flops / scan / 1e9, 1), "scan_frac_mfma": round(flops / scan / 1e9 / 2500, 4),
                       "scan_GBs": round(byts / scan / 1e6, 1), "scan_frac_hbm": round(byts / scan / 1e6 / 8000, 4),

@@ -9,10 +9,13 @@ from reverso_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
+def _declared(experiments=False):
     text = open(os.path.join(ROOT, "include", "revo.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(revo_[a-z0-9_]+)\s*\(", text)))
+    exp = "".join(re.findall(r"#ifdef REVO_EXPERIMENTS(.*?)#endif", text, flags=re.S))
+    text = re.sub(r"#ifdef REVO_EXPERIMENTS.*?#endif", "", text, flags=re.S)
+    names = lambda t: sorted(set(re.findall(r"\b(revo_[a-z0-9_]+)\s*\(", t)))
+    return (names(exp), names(text))[0 if experiments else 1]
 
 
 def test_library_exports_every_declared_symbol():
@@ -25,6 +28,15 @@ def test_library_exports_every_declared_symbol():
 
 def test_binding_covers_header_exactly():
     assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_experiment_switches_are_not_in_the_product_library():
+    """The work-skipping timing switches (wrong results) exist only in librevo_exp.so (`make exp`)."""
+    lib = _lib.load()
+    exp = _declared(experiments=True)
+    assert "revo_op_set_gemm_debug" in exp and sorted(exp) == sorted(_lib.EXPERIMENT_SIGNATURES)
+    for n in exp:
+        assert not hasattr(lib, n), f"librevo.so exports the experiment switch {n}"
 
 
 def test_version_and_error_string():

@@ -193,3 +193,34 @@ def test_device_resize_ingest_equals_host_resize(system):
     names = [p["filename"] for p in r.vector_db.payloads]
     perm = [host_names.index(nm) for nm in names]
     assert torch.equal(r.vector_db.gallery.read().cpu(), host[perm])
+
+
+def test_resume_after_stop_in_storage_phase_builds_the_database(system, tmp_path):
+    """A stop (or crash) after the last embed batch but before the collection was written leaves a checkpoint
+    that marks every file processed and no meta.json.  Resuming must store the checkpointed vectors instead of
+    answering "already complete", and a later create_database for another name must not inherit those vectors."""
+    r, folder, paths, root = system
+    sub = tmp_path / "imgs"
+    sub.mkdir()
+    for p in paths[:6]:
+        (sub / os.path.basename(p)).write_bytes(open(p, "rb").read())
+
+    def stop_at_storage(msg, v=None):
+        if msg.startswith("📦 Recreated collection"):
+            r.request_stop()
+    out = r.create_database(str(sub), "stopped", use_direct_pe=True, progress_callback=stop_at_storage)
+    assert "Processing stopped" in out
+    assert not os.path.exists(os.path.join(r.db_root, "stopped", "meta.json"))
+    assert r._partial_embeddings == [] and r._partial_metadata == []
+    out = r.create_database(str(sub), "stopped", use_direct_pe=True, resume_from_checkpoint=True)
+    assert "All files already embedded" in out and "ready for searching" in out, out
+    assert os.path.exists(os.path.join(r.db_root, "stopped", "meta.json")) and len(r.vector_db) == 6
+    # complete now: a second resume has nothing to do
+    out = r.create_database(str(sub), "stopped", use_direct_pe=True, resume_from_checkpoint=True)
+    assert "ready for searching" in out or "already processed" in out
+    # no leak into the next collection
+    other = tmp_path / "other"
+    other.mkdir()
+    (other / "a.jpg").write_bytes(open(paths[10], "rb").read())
+    out = r.create_database(str(other), "fresh", use_direct_pe=True)
+    assert "Total embeddings stored: 1" in out and len(r.vector_db) == 1

@@ -261,7 +261,7 @@ def test_gemm_persistent_tile_loop(lib, dev, gemm_tile, M, N, K):
     res = {}
     try:
         for flag in (1 << 16, 0):
-            _lib.check(lib.revo_op_set_gemm_debug(flag))
+            _lib.check(lib.revo_op_set_variant(flag))
             c32 = torch.full((M, N), float("nan"), device=dev)
             _gemm(lib, EPI_F32, a, b, c32, bias)
             cb = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
@@ -272,7 +272,7 @@ def test_gemm_persistent_tile_loop(lib, dev, gemm_tile, M, N, K):
             _gemm(lib, EPI_RESID_F32, a, b, x, bias, gamma)
             res[flag] = (c32, cb, cg, x)
     finally:
-        _lib.check(lib.revo_op_set_gemm_debug(0))
+        _lib.check(lib.revo_op_set_variant(0))
     for u, v in zip(res[1 << 16], res[0]):
         assert torch.equal(u, v)
     c32, cb, cg, x = res[0]
@@ -299,12 +299,12 @@ def test_gemm_splitk_tail_residual(lib, dev, gemm_tile, M, N, K):
     outs = []
     try:
         for flag in (0, 0, 1 << 17):
-            _lib.check(lib.revo_op_set_gemm_debug(flag))
+            _lib.check(lib.revo_op_set_variant(flag))
             x = x0.clone()
             _gemm(lib, EPI_RESID_F32, a, b, x, bias, gamma)
             outs.append(x)
     finally:
-        _lib.check(lib.revo_op_set_gemm_debug(0))
+        _lib.check(lib.revo_op_set_variant(0))
     assert torch.equal(outs[0], outs[1])                                   # deterministic
     assert (outs[0] - outs[2]).abs().max().item() <= 1e-3                  # summation order only
     rows = torch.cat([torch.arange(0, 512, device=dev), torch.arange(M - 4200, M, device=dev)])

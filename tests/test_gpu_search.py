@@ -242,18 +242,39 @@ def test_properties_at_full_gallery_1m(dev):
         got = torch.cat([G.read(int(r), 1) for r in i[j]]).double()
         assert ((got @ qn[j]) - s[j].double()).abs().max().item() <= 2e-6
     # 8 shards searched apart (global row ids via index_offset) and merged == unsharded
-    parts_s, parts_i = [], []
+    shards = []
     for p in range(8):
         Gp = engine.Gallery(D, 125_000, device=0)
         Gp.add(G.read(p * 125_000, 125_000), normalize=False)
+        shards.append(Gp)
+    parts_s, parts_i = [], []
+    for p, Gp in enumerate(shards):
         ps, pi, _ = Gp.search(q, k, index_offset=p * 125_000)
         parts_s.append(ps); parts_i.append(pi)
-        Gp.close()
     ms, mi, mc = engine.merge_topk(torch.stack(parts_s), torch.stack(parts_i), k)
     assert torch.equal(mi, i) and torch.equal(ms, s) and torch.equal(mc, c)
-    # a large query batch takes the MFMA-bound regime of the same scan: same answers on the shared queries
+    # the two-phase protocol of the sharded search (sharded.py; BASELINE.json configs[3]) on the same 8 shards, with
+    # the 10 000-query batch: publish admission scores, "all-gather", bounded fp32 re-score, packed "all-gather",
+    # merge == the unsharded search, bit for bit
     big = torch.cat([q, torch.randn(10_000 - Q, D, generator=g, device=dev)])
     bs, bi, bc = G.search(big, k)
+    top_m = 8
+    assert engine.search_ksel(k) == 32
+    allb = torch.stack([Gp.search_candidates(big, k, top_m) for Gp in shards])          # [8, Q, top_m]
+    # (each shard's candidates stay in its handle between the two phases)
+    pb = engine.packed_bytes(big.shape[0], k)
+    packed = torch.empty((8 * pb,), dtype=torch.uint8, device=dev)
+    kept = 0
+    for p, Gp in enumerate(shards):
+        _, pi, _ = Gp.search_finish(big.shape[0], k, allb, None, p * 125_000, out_packed=packed[p * pb:(p + 1) * pb])
+        kept += int((pi >= 0).sum())
+    ts, ti, tc = engine.merge_topk_packed(packed, 8, big.shape[0], k)
+    assert torch.equal(ti, bi) and torch.equal(ts, bs) and torch.equal(tc, bc)
+    # the bound did its job: far fewer than 8 x k results per query survive the cut (about ksel = 32 per query in all)
+    assert kept <= big.shape[0] * 40, kept
+    for Gp in shards:
+        Gp.close()
+    # a large query batch takes the MFMA-bound regime of the same scan: same answers on the shared queries
     assert torch.equal(bi[:Q], i) and torch.equal(bs[:Q], s)
     assert (bc == k).all() and (bs[:, :-1] >= bs[:, 1:]).all()
     G.close()
@@ -312,3 +333,68 @@ def test_wide_k_adversarial_overflow_and_ties(dev):
     s, i, c = G.search(torch.from_numpy(np.stack([v, -v])).to(dev), k)
     assert i[0].cpu().tolist() == list(range(k)) and i[1].cpu().tolist() == list(range(k))
     G.close()
+
+
+@pytest.mark.parametrize("k", [10, 50])
+def test_scan_bound_histogram_edge_cases(dev, k):
+    """The scan's admission bound comes from per-query score histograms whose 64 buckets start at the
+    pre-pass bound and span one binade of the fp32 score.  Cases that leave that window must stay exact
+    (the bound only ever lags; full segments fall back to the sorted-merge path):
+    (a) clusters of near-copies of some queries far above the window (scores ~0.95 against a ~0.3 seed),
+        late in the gallery and longer than a segment;
+    (b) every score negative (bucket origin below zero);
+    (c) a seed slightly below zero with positive scores later on (the window straddles zero)."""
+    D, Q = 128, 300
+    rng = np.random.default_rng(100 + k)
+    # (a)
+    N = 90000
+    gal = rng.standard_normal((N, D), dtype=np.float32)
+    qr = rng.standard_normal((Q, D), dtype=np.float32)
+    for j in range(12):
+        rows = 20000 + j * 5000 + np.arange(150)            # 150 > 2 * 64: the row's segment overflows
+        # cosines spread from ~0.995 down to ~0.8 in steps of ~1.5e-3: further apart than the bf16 selection noise
+        lvl = np.sqrt(0.01 + 0.5 * np.arange(150, dtype=np.float32) / 150)[:, None]
+        gal[rows] = qr[j][None] + lvl * rng.standard_normal((150, D), dtype=np.float32)
+    G = engine.Gallery(D, N, device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    out = G.search(torch.from_numpy(qr).to(dev), k)
+    _check(out, osearch.search(gal, qr, k), atol=1e-5, near_tie=3e-7)
+    assert float(out[0][0, 0]) > 0.9 and float(out[0][20, 0]) < 0.6
+    G.close()
+    # (b)
+    N = 50000
+    base = rng.standard_normal(D).astype(np.float32)
+    qr = base[None] + 0.5 * rng.standard_normal((Q, D), dtype=np.float32)
+    gal = -(base[None] + 0.5 * rng.standard_normal((N, D), dtype=np.float32))
+    G = engine.Gallery(D, N, device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    out = G.search(torch.from_numpy(qr).to(dev), k)
+    _check(out, osearch.search(gal, qr, k), atol=1e-5, near_tie=3e-7)
+    assert float(out[0].max()) < 0.0
+    G.close()
+    # (c)
+    gal = np.concatenate([-(base[None] + 2.0 * rng.standard_normal((20000, D), dtype=np.float32)),
+                          rng.standard_normal((30000, D), dtype=np.float32)])
+    G = engine.Gallery(D, len(gal), device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    out = G.search(torch.from_numpy(qr).to(dev), k)
+    _check(out, osearch.search(gal, qr, k), atol=1e-5, near_tie=3e-7)
+    G.close()
+
+
+def test_scan_slice_balance_and_tails(dev):
+    """Gallery sizes that leave ragged last tiles and uneven slices (the tiles are dealt out as evenly as
+    possible, the first slices take one more), with the planted best row in the very last gallery row."""
+    D, k = 64, 10
+    for N, Q in [(16384 + 255, 600), (50001, 1500), (65536 + 256 * 7 + 1, 257)]:
+        rng = np.random.default_rng(N)
+        gal = rng.standard_normal((N, D), dtype=np.float32)
+        qr = rng.standard_normal((Q, D), dtype=np.float32)
+        gal[N - 1] = qr[Q - 1]
+        gal[0] = qr[0]
+        G = engine.Gallery(D, N, device=0)
+        G.add(torch.from_numpy(gal).to(dev))
+        out = G.search(torch.from_numpy(qr).to(dev), k)
+        _check(out, osearch.search(gal, qr, k), atol=1e-5)
+        assert int(out[1][Q - 1, 0]) == N - 1 and int(out[1][0, 0]) == 0
+        G.close()

@@ -120,15 +120,7 @@ def _shard_worker(rank, world, port, tmp, N, D, Q, k):
     lo = sum(sizes[:rank])
     mine = gal[lo:lo + sizes[rank]]
 
-    def local_search(q, kk, thr, off):
-        s, i, c = osearch.search(mine, q.numpy(), kk, thr, normalize=False)
-        return torch.from_numpy(s), torch.from_numpy(np.where(i >= 0, i + off, -1)), torch.from_numpy(c)
-
-    def merge(ps, pi, kk, thr):
-        s, i, c = osearch.merge_topk(ps.numpy(), pi.numpy(), kk, thr)
-        return torch.from_numpy(s), torch.from_numpy(i), torch.from_numpy(c)
-
-    ss = sharded.ShardedSearch(local_search, merge, sizes[rank])
+    ss = sharded.ShardedSearch(osearch.OracleShardBackend(mine), sizes[rank])
     assert ss.offset == lo and ss.total_rows == N
     # data-parallel queries: each rank contributes its slice, gather gives everyone all of them
     per = Q // world
