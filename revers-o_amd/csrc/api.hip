@@ -242,7 +242,8 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
     REVO_REQUIRE(c.out_dim % 4 == 0, "vit_create: out_dim must be a multiple of 4");
     REVO_REQUIRE(c.width / c.heads == 64 || c.width / c.heads == 96,
                  "vit_create: body head_dim must be 64 (PE-Core B16 / L14) or 96 (G14)");
-    REVO_ON_DEVICE(device);
+    REVO_REQUIRE(c.image_size > 0 && c.patch_size > 0 && c.layers >= 1 && c.heads >= 1 && c.pool_heads >= 1 && n_weights >= 0,
+                 "vit_create: sizes must be positive");
     std::unique_ptr<revo_vit> v(new revo_vit());
     v->cfg = c; v->device = device; v->max_batch = max_batch;
     const int W = c.width, M = c.mlp_dim, D = c.out_dim, P = c.patch_size, G = c.image_size / P;
@@ -256,8 +257,41 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
     v->Kp = (Kreal + 63) / 64 * 64;
     const int S = v->S;
 
+    // The checkpoint is validated as a whole before the device is touched: every tensor the architecture needs must
+    // be present with the right element count (a checkpoint of another variant fails here, by name, not half-way
+    // through the upload).
     WeightMap wm;
-    for (int i = 0; i < n_weights; ++i) wm.m[weights[i].name] = &weights[i];
+    for (int i = 0; i < n_weights; ++i) {
+        REVO_REQUIRE(weights[i].name && weights[i].data, "vit_create: weight entry with a null name or data pointer");
+        wm.m[weights[i].name] = &weights[i];
+    }
+    {
+        std::vector<std::pair<std::string, int64_t>> need = {
+            {"visual.conv1.weight", (int64_t)W * Kreal}, {"visual.positional_embedding", (int64_t)S * W},
+            {"visual.ln_pre.weight", W}, {"visual.ln_pre.bias", W}, {"visual.ln_post.weight", W}, {"visual.ln_post.bias", W},
+            {"visual.attn_pool.probe", W}, {"visual.attn_pool.attn.in_proj_weight", (int64_t)3 * W * W},
+            {"visual.attn_pool.attn.in_proj_bias", 3 * W}, {"visual.attn_pool.attn.out_proj.weight", (int64_t)W * W},
+            {"visual.attn_pool.attn.out_proj.bias", W}, {"visual.attn_pool.layernorm.weight", W},
+            {"visual.attn_pool.layernorm.bias", W}, {"visual.attn_pool.mlp.c_fc.weight", (int64_t)PM * W},
+            {"visual.attn_pool.mlp.c_fc.bias", PM}, {"visual.attn_pool.mlp.c_proj.weight", (int64_t)W * PM},
+            {"visual.attn_pool.mlp.c_proj.bias", W}, {"visual.proj", (int64_t)W * D}};
+        if (c.use_cls) need.push_back({"visual.class_embedding", W});
+        for (int i = 0; i < c.layers; ++i) {
+            const std::string p = "visual.transformer.resblocks." + std::to_string(i) + ".";
+            for (const char* n : {"ln_1.weight", "ln_1.bias", "ln_2.weight", "ln_2.bias", "attn.out_proj.bias", "mlp.c_proj.bias"})
+                need.push_back({p + n, W});
+            need.push_back({p + "attn.in_proj_weight", (int64_t)3 * W * W});
+            need.push_back({p + "attn.in_proj_bias", 3 * W});
+            need.push_back({p + "attn.out_proj.weight", (int64_t)W * W});
+            need.push_back({p + "mlp.c_fc.weight", (int64_t)M * W});
+            need.push_back({p + "mlp.c_fc.bias", M});
+            need.push_back({p + "mlp.c_proj.weight", (int64_t)W * M});
+            if (c.use_ls) { need.push_back({p + "ls_1.gamma", W}); need.push_back({p + "ls_2.gamma", W}); }
+        }
+        for (auto& kv : need)
+            if (!wm.get(kv.first, kv.second)) return -2;
+    }
+    REVO_ON_DEVICE(device);
 
     // staging buffer for fp32 -> bf16 conversion: the largest matrix
     size_t stage_elems = (size_t)std::max({(long)3 * W * W, (long)M * W, (long)PM * W, (long)W * Kreal, (long)W * D});

@@ -163,7 +163,7 @@ struct S256Lds {
 // [base + (b << SH), base + ((b + 1) << SH))  (the last bucket is open-ended).  If the buckets b.. hold at
 // least KSEL scores, KSEL distinct gallery rows score at least the lower edge of bucket b: a valid lower
 // bound of the query's final KSEL-th best.  Counts only ever lag (a store may not have landed yet): stale
-// reads give weaker bounds, never wrong ones.  One wave per row, rows strided by 8, eight rows of loads in flight.
+// reads give weaker bounds, never wrong ones.  One wave per row, rows strided by 8.
 template <int KSEL>
 __device__ __noinline__ void s256_refresh_hist(const S256Lds& L, const uint32_t* hist, const uint32_t* tau_g, int q0,
                                                int qvalid, int tid) {
@@ -172,34 +172,33 @@ __device__ __noinline__ void s256_refresh_hist(const S256Lds& L, const uint32_t*
     uint32_t tgv = 0u;
     if (lane < 32 && wave + 8 * lane < qvalid)
         tgv = __hip_atomic_load(tau_g + q0 + wave + 8 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i0 = 0; i0 < 32; i0 += 8) {
-        uint32_t h[8];
+    // all 32 rows' counters are requested before any is used: one L2 round trip per refresh, not one per batch
+    uint32_t h[32];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int r = wave + 8 * (i0 + u);
-            h[u] = r < qvalid ? __hip_atomic_load(hist + (long)(q0 + r) * S256_NB + lane, __ATOMIC_RELAXED, S256_HIST_SCOPE) : 0u;
+    for (int u = 0; u < 32; ++u) {
+        const int r = wave + 8 * u;
+        h[u] = r < qvalid ? __hip_atomic_load(hist + (long)(q0 + r) * S256_NB + lane, __ATOMIC_RELAXED, S256_HIST_SCOPE) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        const int r = wave + 8 * u;
+        if (r >= qvalid) break;                                   // wave-uniform
+        // suffix sums: s[lane] = h[lane] + h[lane + 1] + ... + h[63]
+        uint32_t sfx = h[u];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_down(sfx, o, 64);
+            sfx += (lane + o < 64) ? t : 0u;
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int r = wave + 8 * (i0 + u);
-            if (r >= qvalid) break;                                   // wave-uniform
-            // suffix sums: s[lane] = h[lane] + h[lane + 1] + ... + h[63]
-            uint32_t sfx = h[u];
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t t = __shfl_down(sfx, o, 64);
-                sfx += (lane + o < 64) ? t : 0u;
+        const unsigned long long m = __ballot(sfx >= (uint32_t)KSEL);
+        if (lane == 0) {
+            float t = orderable_f32((uint32_t)__builtin_amdgcn_readlane((int)tgv, u));
+            if (m) {
+                const int b = 63 - __builtin_clzll(m);
+                const float th = orderable_f32(L.base[r] + ((uint32_t)b << S256_SH));
+                t = th > t ? th : t;
             }
-            const unsigned long long m = __ballot(sfx >= (uint32_t)KSEL);
-            if (lane == 0) {
-                float t = orderable_f32((uint32_t)__builtin_amdgcn_readlane((int)tgv, i0 + u));
-                if (m) {
-                    const int b = 63 - __builtin_clzll(m);
-                    const float th = orderable_f32(L.base[r] + ((uint32_t)b << S256_SH));
-                    t = th > t ? th : t;
-                }
-                if (t > L.tau[r]) L.tau[r] = t;
-            }
+            if (t > L.tau[r]) L.tau[r] = t;
         }
     }
     __syncthreads();
@@ -377,6 +376,13 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     g256_operand_init(A, p.Qb, p.ldq, p.Q, q0, wave, lane);
     g256_operand_init(B, p.Gb + row_begin * p.ldg, p.ldg, p.N - row_begin, 0, wave, lane);
     g256_issue_prologue(A, B, smem, p.D, wave);
+    // Slices that start after others have run (later rounds of workgroups on this CU) begin with what those have
+    // learnt, not with the pre-pass bound: one refresh while the first operands are in flight.  (Without it every
+    // slice's first tile admitted about one score per row: at 24 tiles per slice a third of all slow fragments.)
+    if (!(p.dbg & 17)) {
+        if (p.stats && tid == 0) atomicAdd(p.stats + 5, 1ull);
+        s256_refresh_hist<KSEL>(L, p.hist, p.tau_g, q0, qvalid, tid);
+    }
 
     // Normal mode: one pass per tile (groups == 1).  If a pass pushes more entries to the overflow queue than
     // it holds (an adversarially ordered gallery), the tile is recomputed in 2, 4, ... 32 column groups, one

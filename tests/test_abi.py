@@ -61,3 +61,16 @@ def test_product_has_no_oracle_import():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f), encoding="utf-8").read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_host_paths_under_address_and_ub_sanitizers():
+    """api.hip's host code (argument validation, the checkpoint name / size map, error strings, handle lifetime,
+    graceful failure without a device) compiled with -fsanitize=address,undefined and driven through every entry
+    point by tests/native/abi_host_check.cpp.  (GPU sanitizers are not available on this pool: CPU build only.)"""
+    import subprocess
+    csrc = os.path.join(ROOT, "revers-o_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "-j", "4", "all", "asan"], check=True, capture_output=True, timeout=900)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(csrc, "build", "asan", "abi_host_check")], capture_output=True, text=True, env=env,
+                       timeout=120)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

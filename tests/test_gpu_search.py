@@ -398,3 +398,60 @@ def test_scan_slice_balance_and_tails(dev):
         _check(out, osearch.search(gal, qr, k), atol=1e-5)
         assert int(out[1][Q - 1, 0]) == N - 1 and int(out[1][0, 0]) == 0
         G.close()
+
+
+def test_config4_gallery_10m_x_1536(dev):
+    """BASELINE.json configs[4]'s gallery as written: 10 M x 1536 (bf16 scan copy 30.7 GB + fp32 master 61 GB of
+    the 288 GB), 256 queries, through the 256 x 256 scan.  The CPU oracle cannot hold this; what is checked:
+    planted near-copies at the first / last / pre-pass-boundary rows come back in the planted order, results are
+    sorted and complete, returned scores are the exact fp32 cosines of the returned rows, no row of four sampled
+    50 000-row ranges beats a query's 10th result without being in it (oracle on the sample), and an 8-way
+    row shard + merge equals the unsharded search bit for bit."""
+    N, D, Q, k = 10_000_000, 1536, 256, 10
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 130 << 30:
+        pytest.skip("needs ~110 GB of free HBM")
+    g = torch.Generator(device=dev).manual_seed(404)
+    q = torch.randn(Q, D, generator=g, device=dev)
+    plant_rows = [0, 1, 65535, 65536, 65537, N // 2, N - 2, N - 1]
+    G = engine.Gallery(D, N, device=0)
+    chunk = 500_000
+    for s0 in range(0, N, chunk):
+        G.add(torch.randn(chunk, D, generator=g, device=dev))
+    # the gallery is append-only: instead of planting copies of the queries, the first queries are made near-copies of
+    # gallery rows at the interesting positions (first / last rows, both sides of the 65 536-row pre-pass boundary)
+    ids = torch.tensor(plant_rows, device=dev)
+    qrows = torch.cat([G.read(int(r), 1) for r in plant_rows])   # the normalised fp32 rows themselves
+    q[: len(plant_rows)] = qrows + 0.01 * torch.randn(len(plant_rows), D, generator=g, device=dev)
+    s, i, c = G.search(q, k)
+    assert torch.equal(i[: len(plant_rows), 0], ids) and (c == k).all()
+    assert float(s[: len(plant_rows), 0].min()) > 0.9 and float(s[len(plant_rows):, 0].max()) < 0.3
+    assert (s[:, :-1] >= s[:, 1:]).all()
+    qn = torch.nn.functional.normalize(q.double(), dim=-1)
+    for j in (0, 7, 100, Q - 1):
+        got = torch.cat([G.read(int(r), 1) for r in i[j]]).double()
+        assert ((got @ qn[j]) - s[j].double()).abs().max().item() <= 2e-6
+    # oracle on a sample: rows of four ranges against 16 of the queries
+    qs = list(range(8)) + list(range(Q - 8, Q))
+    for start in (0, 40_000, N // 3, N - 50_000):
+        sub = G.read(start, 50_000).cpu().numpy()
+        sc = osearch.cosine_scores(sub, qn[qs].float().cpu().numpy())
+        for a, j in enumerate(qs):
+            better = np.where(sc[a] > float(s[j, k - 1]) + 1e-6)[0] + start
+            assert set(better.tolist()) <= set(i[j].cpu().tolist()), (start, j)
+    # 8 shards searched apart and merged == unsharded (global row ids through index_offset)
+    shard = N // 8
+    parts_s, parts_i = [], []
+    for p in range(8):
+        Gp = engine.Gallery(D, shard, device=0)
+        for s0 in range(0, shard, chunk):
+            Gp.add(G.read(p * shard + s0, min(chunk, shard - s0)), normalize=False)
+        ps, pi, _ = Gp.search(q, k, index_offset=p * shard)
+        parts_s.append(ps); parts_i.append(pi)
+        Gp.close()
+    ms, mi, mc = engine.merge_topk(torch.stack(parts_s), torch.stack(parts_i), k)
+    assert torch.equal(mi, i) and torch.equal(ms, s) and torch.equal(mc, c)
+    plan = G.search_plan(Q, k)
+    assert plan["scan256"] and plan["ksel"] == 32
+    G.close()
