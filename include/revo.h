@@ -151,6 +151,8 @@ int32_t revo_op_set_variant(int32_t flags);
  * bit 13 = skip the scan's selection, bit 15 = skip the scan's slow path (all four: WRONG RESULTS),
  * bit 14 = count scan events for revo_debug_scan_stats. */
 int32_t revo_op_set_gemm_debug(int32_t flags);
+/* copies bytes of the handle's search workspace to host_dst (host_dst NULL: returns the workspace size) */
+int64_t revo_debug_read_workspace(revo_gallery* g, int64_t offset, int64_t bytes, void* host_dst);
 /* counters of the fused scan when debug bit 14 is set */
 int32_t revo_debug_scan_stats(int64_t* out8);
 #endif

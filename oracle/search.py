@@ -161,6 +161,11 @@ class OracleShardBackend:
     def packed_bytes(self, n_queries, k):
         return packed_bytes(n_queries, k)
 
+    def search(self, queries, k, threshold):
+        t = self._torch
+        s, i, c = search(self.shard, np.asarray(queries, dtype=np.float32), k, threshold, normalize=False)
+        return t.from_numpy(s), t.from_numpy(i), t.from_numpy(c)
+
     def candidates(self, queries, k, top_m):
         q = np.asarray(queries, dtype=np.float32)
         ksel = self.ksel(k)

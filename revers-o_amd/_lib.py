@@ -76,9 +76,13 @@ SIGNATURES = {
 EXPERIMENT_SIGNATURES = {
     "revo_op_set_gemm_debug": (_i32, [_i32]),
     "revo_debug_scan_stats": (_i32, [C.POINTER(C.c_int64)]),
+    "revo_debug_read_workspace": (_i64, [_p, _i64, _i64, _p]),
 }
-if os.environ.get("REVO_EXPERIMENTS") == "1":
+if os.environ.get("REVO_LIBRARY_PATH"):            # bisecting / A-B runs of another build of the same ABI
+    LIB_PATH = os.environ["REVO_LIBRARY_PATH"]
+elif os.environ.get("REVO_EXPERIMENTS") == "1":
     LIB_PATH = os.path.join(_HERE, "librevo_exp.so")
+if os.environ.get("REVO_EXPERIMENTS") == "1":
     SIGNATURES = dict(SIGNATURES, **EXPERIMENT_SIGNATURES)
 
 _lib = None

@@ -715,21 +715,27 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
         // Pre-pass size: about one round of 256 x 256 GEMM tiles; with few queries (short gallery slices
         // per CU) up to 64 k rows, which seed the 0.05 % quantile.
         const long n_pre = search_prepass_rows(Q, N);
-        const int splits = topk_scan256_splits(Q, N - n_pre);
+        // the scan runs as one launch, or as a main launch of whole query tiles plus one for a ragged tail of queries
+        const int q_main = topk_scan256_main_queries(Q, N - n_pre);
+        struct Part { int q0, nq, splits; size_t seg_off, cnt_off; } parts[2] = {{0, q_main, 0, 0, 0}, {q_main, Q - q_main, 0, 0, 0}};
+        const int nparts = q_main < Q ? 2 : 1;
         const int NB = topk_scan256_hist_buckets();
-        // workspace: histograms (zeroed) | segment counts | segments | pre-pass lists | final lists | pre-pass scores
+        // workspace: histograms (zeroed) | per part: segment counts, segments | pre-pass lists | final lists | pre-pass scores
         auto up256 = [](size_t x) { return (x + 255) / 256 * 256; };
         const size_t hist_off = 0, hist_bytes = (size_t)Q * NB * 4;
-        const size_t cnt_off = up256(hist_off + hist_bytes), cnt_bytes = (size_t)Q * splits * 4;
-        const size_t seg_off = up256(cnt_off + cnt_bytes), seg_bytes = (size_t)Q * splits * (2 * ksel) * 8;
-        const size_t pre_off = up256(seg_off + seg_bytes), pre_bytes = (size_t)Q * ksel * 8;
+        size_t off = up256(hist_off + hist_bytes);
+        for (int i = 0; i < nparts; ++i) {
+            Part& pt = parts[i];
+            pt.splits = topk_scan256_splits(pt.nq, N - n_pre);
+            pt.cnt_off = off; off = up256(off + (size_t)pt.nq * pt.splits * 4);
+            pt.seg_off = off; off = up256(off + (size_t)pt.nq * pt.splits * (2 * ksel) * 8);
+        }
+        const size_t pre_off = off, pre_bytes = (size_t)Q * ksel * 8;
         const size_t fin_off = up256(pre_off + pre_bytes), fin_bytes = (size_t)Q * ksel * 8;
         const size_t sco_off = up256(fin_off + fin_bytes);
         CHECK_RC(need_part(sco_off + (size_t)Q * n_pre * 4));
         char* wsb = (char*)g->part;
         uint32_t* hist = (uint32_t*)(wsb + hist_off);
-        int* seg_cnt = (int*)(wsb + cnt_off);
-        uint64_t* seg = (uint64_t*)(wsb + seg_off);
         uint64_t* prelist = (uint64_t*)(wsb + pre_off);
         uint64_t* final_lists = (uint64_t*)(wsb + fin_off);
         float* pre_scores = (float*)(wsb + sco_off);
@@ -746,10 +752,19 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
             REVO_HIP_CHECK(hipMemcpyAsync(tau_live, tau_base, (size_t)Q * 4, hipMemcpyDeviceToDevice, st));
         }
         { ProfScope ps("topk_scan", st);
-          CHECK_RC(launch_topk_scan256(g->qb, D, g->gb, D, Q, N, D, n_pre, splits, seg, seg_cnt, tau_live, tau_base, hist,
-                                       ksel, st)); }
+          for (int i = 0; i < nparts; ++i) {
+              const Part& pt = parts[i];
+              CHECK_RC(launch_topk_scan256(g->qb + (size_t)pt.q0 * D, D, g->gb, D, pt.nq, N, D, n_pre, pt.splits,
+                                           (uint64_t*)(wsb + pt.seg_off), (int*)(wsb + pt.cnt_off), tau_live + pt.q0,
+                                           tau_base + pt.q0, hist + (size_t)pt.q0 * NB, ksel, st));
+          } }
         { ProfScope ps("topk_reduce", st);
-          CHECK_RC(launch_topk_reduce_segs(seg, seg_cnt, splits, prelist, final_lists, Q, ksel, st)); }
+          for (int i = 0; i < nparts; ++i) {
+              const Part& pt = parts[i];
+              CHECK_RC(launch_topk_reduce_segs((const uint64_t*)(wsb + pt.seg_off), (const int*)(wsb + pt.cnt_off), pt.splits,
+                                               prelist + (size_t)pt.q0 * ksel, final_lists + (size_t)pt.q0 * ksel, pt.nq, ksel,
+                                               st));
+          } }
         g->cand = final_lists; g->cand_stride = ksel;
     } else {
         // ---- small galleries: 128 x 128 scan with per-wave LDS lists
@@ -776,7 +791,8 @@ extern "C" int32_t revo_search_plan(const revo_gallery* g, int32_t Q, int32_t k,
     const long n_pre = big ? search_prepass_rows(Q, N) : 0;
     out4[0] = big ? 1 : 0;
     out4[1] = n_pre;
-    out4[2] = big ? revo::topk_scan256_splits(Q, N - n_pre) : revo::topk_scan_workspace_splits(Q, N);
+    out4[2] = big ? revo::topk_scan256_splits(revo::topk_scan256_main_queries(Q, N - n_pre), N - n_pre)
+                  : revo::topk_scan_workspace_splits(Q, N);
     out4[3] = search_ksel(k);
     return 0;
 }
@@ -919,6 +935,15 @@ extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
     revo::gemm_set_debug(flags & 3);
     revo::topk_scan256_set_debug(((flags >> 13) & 7) | (((flags >> 20) & 255) << 3));
     return revo_op_set_variant(flags);
+}
+// copy bytes [offset, offset + bytes) of the handle's search workspace to the host (debugging the scan's buffers)
+extern "C" int64_t revo_debug_read_workspace(revo_gallery* g, int64_t offset, int64_t bytes, void* host_dst) {
+    if (!g || !g->part) return -1;
+    if (!host_dst) return (int64_t)g->part_cap;
+    if (offset < 0 || bytes < 0 || (size_t)(offset + bytes) > g->part_cap) return -2;
+    if (hipDeviceSynchronize() != hipSuccess) return -3;
+    if (hipMemcpy(host_dst, (const char*)g->part + offset, (size_t)bytes, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    return bytes;
 }
 extern "C" int32_t revo_debug_scan_stats(int64_t* out4) {
     REVO_HIP_CHECK(hipDeviceSynchronize());

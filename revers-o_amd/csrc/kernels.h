@@ -98,6 +98,9 @@ int launch_topk_publish(const uint64_t* part, long part_stride, int Q, int top_m
 // 256 x 256 tile scan (topk256.hip): survivors are appended to per-(query, slice) segments of 2 * ksel keys and
 // counted in per-query score histograms; launch_topk_reduce_segs then picks each query's best ksel keys
 int topk_scan256_splits(int Q, long rows);
+// queries the main launch of a search takes; the rest (a ragged tail of <= 128 queries) runs as a second launch in the
+// small-query mode of the kernel when that is cheaper (Q = one launch)
+int topk_scan256_main_queries(int Q, long rows);
 int topk_scan256_hist_buckets();      // u32 counters per query in `hist`
 int topk_scan256_hist_shift();        // bucket width = 2^shift ulps of the fp32 score above the pre-pass bound
 #ifdef REVO_EXPERIMENTS

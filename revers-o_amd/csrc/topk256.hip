@@ -4,29 +4,34 @@
 // One workgroup = 256 queries x one contiguous slice of the gallery, walked in 256-row
 // tiles.  After each tile a lane compares its 128 scores with the admission score of its
 // 8 query rows (a lower bound of the query's final KSEL-th best score, so nothing that can
-// end up in the top KSEL is ever dropped).  Survivors are rare; a survivor is
-//   * appended to its row's SEGMENT of this slice in global memory ([Q][slices][2 KSEL] keys,
-//     slot from a per-row LDS counter, fire-and-forget store: no sorting in the scan), and
-//   * counted in the query's global score HISTOGRAM (64 buckets of 2^17 fp32 ulps above the
-//     pre-pass bound, shared by all slices of the query: one non-returning L2 atomic).
-// Every few tiles a workgroup re-reads the histograms of its 256 queries: the lower edge of
-// the highest bucket with KSEL or more scores at or above it is a valid admission bound that
-// reflects what ALL slices have seen so far -- close to the bound a sequential scan would
-// have (measured: ~4x fewer survivors than per-slice running bounds give, and no sorted
-// lists to maintain).  A separate kernel picks each query's best KSEL out of its segments.
-// Only when a row's segment is full do its survivors go to a 2048-entry LDS queue, which is
-// drained by sorting it and merging each row's entries with its segment (the slow, exact
-// path: adversarially ordered galleries, huge tie groups); if even the queue overflows, the
-// tile is recomputed by column groups.  The admission scores are seeded by a pre-pass over
-// the first rows of the gallery (topk.hip).  The next tile's first DMA is issued before the
-// selection runs, so its HBM latency is hidden behind the compares.
+// end up in the top KSEL is ever dropped).  Survivors are rare; a survivor is staged in LDS
+// (row | score | index), and after the workgroup's barrier thread i moves staged entry i
+//   * to its row's SEGMENT of this slice in global memory ([Q][slices][2 KSEL] keys, slot from
+//     a per-row LDS counter, fire-and-forget store: no sorting in the scan), and
+//   * into the query's global score HISTOGRAM (64 buckets of 2^17 fp32 ulps above the pre-pass
+//     bound, shared by all slices of the query: one non-returning L2 atomic)
+// -- at most one store and one atomic instruction per wave and tile, which the next main
+// loop's operand-DMA waits never have to wait for.  Every few tiles a workgroup re-reads the
+// histograms of its 256 queries: the lower edge of the highest bucket with KSEL or more
+// scores at or above it is a valid admission bound that reflects what ALL slices have seen so
+// far -- close to the bound a sequential scan would have (measured: ~4x fewer survivors than
+// per-slice running bounds give, and no sorted lists to maintain).  A separate kernel picks
+// each query's best KSEL out of its segments.  Only when a row's segment is full do its
+// survivors go to a 1024-entry LDS queue, which is drained by sorting it and merging each
+// row's entries with its segment (the slow, exact path: adversarially ordered galleries, huge
+// tie groups); if the queue or the staging buffer overflows, the tile is recomputed by column
+// groups.  The admission scores are seeded by a pre-pass over the first rows of the gallery
+// (topk.hip).  The next tile's first DMA is issued before the selection runs, so its HBM
+// latency is hidden behind the compares.
 #include "gemm256_core.h"
 #include "kernels.h"
 
 namespace revo {
 
-constexpr int S256_QCAP = 2048;          // overflow-queue entries
-constexpr int S256_DRAIN = 1792;         // drain once this many are queued (256 slots of slack for the next tile)
+constexpr int S256_QCAP = 1024;          // overflow-queue entries (survivors whose row segment is full)
+constexpr int S256_DRAIN = 512;          // drain once this many are queued
+constexpr int S256_STG = 1024;           // staging entries: the survivors of ONE pass over a tile
+constexpr int S256_MAXGROUPS = 64;       // retry ladder: 256 rows x 4 columns = 1024 survivors per pass at most
 constexpr int S256_NB = 64;              // histogram buckets per query
 constexpr int S256_SH = 17;              // bucket width: 2^17 ulps of the fp32 score (1.6 % of the value; 64 buckets = one binade)
 // Scope of the histogram traffic.  Workgroup scope makes the counters live in the L2 of the issuing XCD (atomics
@@ -38,15 +43,18 @@ constexpr int S256_SH = 17;              // bucket width: 2^17 ulps of the fp32 
 // query tile to one XCD whenever there are at least 8 query tiles (fewer query tiles: each XCD tightens on its
 // own eighth of the gallery, and the scan is HBM-bound there anyway).
 #define S256_HIST_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
-// main-loop image + queue + tau / base / start / end / cnt (256 x 4 B each) + ctrl + merge scratch + wkey
-constexpr int S256_LDS = G256_LDS + S256_QCAP * 8 + 256 * 4 * 5 + 64 + 8 * 128 * 8 + 256 * 8;
+// main-loop image + queue + staging + tau / base / start / end / cnt (256 x 4 B each) + ctrl + merge scratch + wkey
+constexpr int S256_LDS = G256_LDS + S256_QCAP * 8 + S256_STG * 8 + 256 * 4 * 5 + 64 + 8 * 128 * 8 + 256 * 8;
 static_assert(S256_LDS <= 163840, "the scan needs more LDS than a CU has");
 
 // LDS byte offsets of the selection state behind the main-loop image (the dynamic LDS block starts at 0: no
 // static LDS in these kernels; gemm256_core.h addresses its fragments the same way)
-constexpr uint32_t S256_TAU_OFF = G256_LDS + S256_QCAP * 8;
+constexpr uint32_t S256_STG_OFF = G256_LDS + S256_QCAP * 8;
+constexpr uint32_t S256_TAU_OFF = S256_STG_OFF + S256_STG * 8;
 constexpr uint32_t S256_CNT_OFF = S256_TAU_OFF + 256 * 4 * 4;
-constexpr uint32_t S256_CTRL_OFF = S256_CNT_OFF + 256 * 4;
+constexpr uint32_t S256_CTRL_OFF = S256_CNT_OFF + 256 * 4;      // [0] overflow-queue count, [1] running total of staged survivors
+constexpr uint32_t S256_BASE_OFF = S256_TAU_OFF + 256 * 4;
+constexpr uint32_t S256_WKEY_OFF = S256_CTRL_OFF + 64 + 8 * 128 * 8;
 // atomicAdd(&cnt, 1) on LDS as raw ISA.  Through the compiler every LDS atomic here is preceded by
 // s_waitcnt vmcnt(0): the next tile's operand DMA (buffer_load ... lds) is in flight and the waitcnt pass cannot
 // tell that it writes a different part of LDS -- so every survivor waited for that DMA AND for the global store and
@@ -56,6 +64,16 @@ __device__ __forceinline__ int s256_lds_inc(uint32_t lds_byte_addr) {
     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(lds_byte_addr), "v"(1) : "memory");
     return old;
 }
+// the same for an 8-byte LDS store (the compiler's own LDS stores wait for vmcnt(0) here for the same reason)
+__device__ __forceinline__ void s256_lds_store64(uint32_t lds_byte_addr, uint64_t v) {
+    asm volatile("ds_write_b64 %0, %1" :: "v"(lds_byte_addr), "v"(v) : "memory");
+}
+// Plain LDS reads at constant offsets (the dynamic LDS block starts at 0).  Going through the generic pointers of
+// S256Lds made the compiler keep them alive across the main loop, spill one, and reload it from scratch behind an
+// s_waitcnt vmcnt(0) in the middle of the selection.
+__device__ __forceinline__ uint32_t s256_lds_u32(uint32_t off) { return *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)off; }
+__device__ __forceinline__ uint64_t s256_lds_u64(uint32_t off) { return *(__attribute__((address_space(3))) const uint64_t*)(uintptr_t)off; }
+__device__ __forceinline__ float s256_lds_f32(uint32_t off) { return *(__attribute__((address_space(3))) const float*)(uintptr_t)off; }
 // workgroup barrier that orders LDS traffic only (__syncthreads() also drains vmcnt: the next tile's operand DMA and
 // the selection's fire-and-forget global stores would have to land first)
 __device__ __forceinline__ void s256_barrier_lds() {
@@ -106,6 +124,15 @@ __device__ __forceinline__ uint64_t s256_bitonic_merge_desc(uint64_t v, int lane
     return v;
 }
 
+// a 64-bit key that another wave of this workgroup (or an earlier drain) stored: two 4-byte agent-scope loads (the
+// stores are complete by the time this runs, so the halves cannot be torn)
+__device__ __forceinline__ uint64_t s256_load_key_coherent(const uint64_t* p) {
+    const uint32_t* q = (const uint32_t*)p;
+    const uint32_t lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // One step of "list := best KSEL distinct keys of (list u new keys)".
 //   KSEL = 32: cur = the list in lanes 0..31 (best first, 0 = empty), fresh = up to 32 new keys in lanes 32..63,
 //              WORST FIRST (lane 63 holds the best new key).
@@ -114,7 +141,12 @@ __device__ __forceinline__ uint64_t s256_bitonic_merge_desc(uint64_t v, int lane
 // are dropped after the merge and the survivors are compacted through the wave's LDS scratch `ws` (128 slots;
 // LDS operations of one wave complete in order).
 template <int KSEL>
-__device__ __forceinline__ uint64_t s256_merge_step(uint64_t cur, uint64_t fresh, uint64_t* ws, int lane) {
+__device__ __forceinline__ uint64_t s256_merge_step(uint64_t cur, uint64_t fresh, uint64_t* ws_, int lane) {
+    // The compaction passes values BETWEEN lanes through LDS: lane a stores to slot p, lane p loads slot p.  To the
+    // compiler that is one thread storing to ws[lane] and ws[p] and loading ws[lane] -- it may (and, depending on
+    // what this is inlined into, did) answer the load from the thread's own stores, i.e. "0 unless p == lane".
+    // volatile keeps the three LDS operations as written; the hardware runs one wave's LDS operations in order.
+    volatile uint64_t* ws = ws_;
     const unsigned long long below = (1ull << lane) - 1ull;
     if (KSEL == 32) {
         uint64_t v = lane < 32 ? cur : fresh;       // best-first then worst-first: bitonic
@@ -148,12 +180,13 @@ __device__ __forceinline__ uint64_t s256_merge_step(uint64_t cur, uint64_t fresh
 
 struct S256Lds {
     uint64_t* queue;     // [S256_QCAP] overflow queue
+    uint64_t* stage;     // [S256_STG] survivors of the current pass (row | score | index), flushed after the barrier
     float* tau;          // [256] admission score per query row of the tile
     uint32_t* base;      // [256] order-preserving u32 of the pre-pass bound: histogram origin of the row
     int* start;          // [256]
     int* end;            // [256]
     int* cnt;            // [256] entries appended to the row's segment so far (may run past the capacity: those went to the queue)
-    int* ctrl;           // [0] queue count (may exceed the capacity: overflow), [1..] spare
+    int* ctrl;           // [0] queue count (may exceed the capacity: overflow), [1] running total of staged survivors (never reset)
     uint64_t* scratch;   // [8][128] wave-private
     uint64_t* wkey;      // [256] key of the row's KSEL-th best entry as of its last drain (0 = never drained / fewer than KSEL)
 };
@@ -212,7 +245,12 @@ __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* seg0, long s
                                         uint32_t idx_base, int tid, uint32_t* tau_g) {
     constexpr int SEG = 2 * KSEL;
     const int wave = tid >> 6, lane = tid & 63;
+    // The segments were written by other waves of this workgroup since this CU last read them (appends by the
+    // flush, list heads by earlier drains).  __syncthreads() makes every wave wait for its own stores; the CU's
+    // vector L1 is NOT kept coherent with them (a line it holds from the previous read-back stays as it was), so
+    // it is invalidated here (acquire fence: buffer_inv) and the read-back uses 4-byte sc1 loads.
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     int n = L.ctrl[0];
     n = n < S256_QCAP ? n : S256_QCAP;
     int np2 = 64;
@@ -251,7 +289,7 @@ __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* seg0, long s
         // the segment as it stands (appended by any wave of this workgroup, unsorted): sort it, drop repeats
         uint64_t cur;
         if (KSEL == 32) {
-            uint64_t v = lane < c ? __hip_atomic_load(seg + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            uint64_t v = lane < c ? s256_load_key_coherent(seg + lane) : 0ull;
             v = s256_sort_desc(v, lane);
             // as a merge step with an empty list: keeps the best 32 distinct keys
             const uint64_t lo32 = s256_shfl_xor(v, 63);          // lanes 32..63 <- v[31..0]: the best 32, worst first
@@ -260,8 +298,8 @@ __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* seg0, long s
             const uint64_t rest = s256_shfl_xor(v, 31);          // lanes 32..63 <- v[63..32]
             if (s256_readlane(cur, 31) == 0ull) cur = s256_merge_step<32>(cur, lane >= 32 ? rest : 0ull, ws, lane);
         } else {
-            uint64_t v0 = lane < c ? __hip_atomic_load(seg + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            uint64_t v1 = lane + 64 < c ? __hip_atomic_load(seg + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            uint64_t v0 = lane < c ? s256_load_key_coherent(seg + lane) : 0ull;
+            uint64_t v1 = lane + 64 < c ? s256_load_key_coherent(seg + 64 + lane) : 0ull;
             v0 = s256_sort_desc(v0, lane);
             v1 = s256_sort_desc(v1, lane);
             cur = s256_merge_step<64>(0ull, s256_shfl_xor(v0, 63), ws, lane);
@@ -321,7 +359,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     extern __shared__ __attribute__((aligned(16))) char smem[];
     S256Lds L;
     L.queue = (uint64_t*)(smem + G256_LDS);
-    L.tau = (float*)(smem + G256_LDS + S256_QCAP * 8);
+    L.stage = (uint64_t*)(smem + S256_STG_OFF);
+    L.tau = (float*)(smem + S256_TAU_OFF);
     L.base = (uint32_t*)(L.tau + 256);
     L.start = (int*)(L.base + 256);
     L.end = L.start + 256;
@@ -329,7 +368,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     L.ctrl = L.cnt + 256;
     L.scratch = (uint64_t*)(L.ctrl + 16);
     L.wkey = L.scratch + 8 * 128;
-    static_assert(S256_CNT_OFF == G256_LDS + S256_QCAP * 8 + (256 + 256 + 256 + 256) * 4, "cnt follows tau, base, start, end");
+    static_assert(S256_CNT_OFF == S256_TAU_OFF + (256 + 256 + 256 + 256) * 4, "cnt follows tau, base, start, end");
+    static_assert(S256_WKEY_OFF + 256 * 8 == S256_LDS, "wkey is the last block");
 
 #ifndef REVO_EXPERIMENTS
     // the product build has no timing switches and no counters: these fold to constants
@@ -365,7 +405,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
         L.wkey[tid] = 0ull;
         L.cnt[tid] = 0;
     }
-    if (tid == 0) L.ctrl[0] = 0;
+    if (tid == 0) { L.ctrl[0] = 0; L.ctrl[1] = 0; }
     __syncthreads();
     if (t0 >= t1) {
         if (tid < qvalid) p.seg_cnt[(long)(q0 + tid) * p.splits + sp] = 0;
@@ -385,11 +425,12 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     }
 
     // Normal mode: one pass per tile (groups == 1).  If a pass pushes more entries to the overflow queue than
-    // it holds (an adversarially ordered gallery), the tile is recomputed in 2, 4, ... 32 column groups, one
-    // pass and one drain per group; at 32 groups a pass can admit at most 256 x 8 = 2048 entries, so the
-    // retry always terminates.  Entries found twice are dropped when lists are merged (drain, final reduce).
+    // it holds, or stages more survivors than the staging buffer holds (an adversarially ordered gallery), the tile
+    // is recomputed in 2, 4, ... 64 column groups, one pass and one drain per group; at 64 groups a pass can
+    // admit at most 256 x 4 = 1024 entries, so the retry always terminates.  Entries found twice are dropped when lists are merged (drain, final reduce).
     long t = t0;
     int groups = 1, grp = 0;
+    uint32_t staged_before = 0;            // survivors staged by earlier passes (the LDS total is never reset)
     while (t < t1) {
         const long n0 = p.n_begin + t * 256;
         {
@@ -432,7 +473,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
                 asm volatile("" :: "v"(acc[0][0]), "v"(acc[7][3]));
             } else {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) taum[m] = L.tau[rbase + m * 16];
+                for (int m = 0; m < 8; ++m) taum[m] = s256_lds_f32(S256_TAU_OFF + (rbase + m * 16) * 4);
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     float mx = -INFINITY;
@@ -450,11 +491,9 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
                     if (p.stats && lane == 0) atomicAdd(p.stats + 3, 1ull);
                     const int row = rbase + m * 16;
                     // the row's KSEL-th best as of its last drain, as (score, index); none yet admits everything
-                    const uint64_t wk = L.wkey[row];
+                    const uint64_t wk = s256_lds_u64(S256_WKEY_OFF + row * 8);
                     const float ws = wk ? key_score(wk) : -INFINITY;
                     const uint32_t widx = wk ? key_index(wk) : 0xffffffffu;
-                    const uint32_t bo = L.base[row];
-                    uint64_t* segrow = myseg + (long)row * seg_row_stride;
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -464,26 +503,14 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
                             // admission score (shared across slices) first, then the strict test against the
                             // row's own KSEL-th entry: an equal score enters only with a smaller index, so a
                             // huge tie group cannot keep the queue full forever.  Survivors are rare: each lane
-                            // places its own under a mostly empty exec mask.
+                            // stages its own (row | score | index) in LDS under a mostly empty exec mask; nothing
+                            // here touches global memory.
                             const bool pass = v >= taum[m];
                             if (__ballot(pass) == 0ull) continue;       // wave-uniform: most elements of a hit fragment fail too
                             if (pass && (col & (groups - 1)) == grp &&
                                 (v > ws || (v == ws && idx_base + rel0 + col < widx))) {
-                                const int slot = s256_lds_inc(S256_CNT_OFF + row * 4);
-                                if (slot < SEG) {
-                                    if (p.dbg & 8) continue;       // timing experiment: no global traffic from the selection
-                                    if (!(p.dbg & 32)) segrow[slot] = make_key(v, idx_base + rel0 + col);
-                                    if (groups == 1) {             // a recomputed tile must not be counted twice
-                                        uint32_t b = (f32_orderable(v) - bo) >> S256_SH;
-                                        b = b < (uint32_t)(S256_NB - 1) ? b : (uint32_t)(S256_NB - 1);
-                                        (void)__hip_atomic_fetch_add(myhist + (long)row * S256_NB + b, 1u, __ATOMIC_RELAXED,
-                                                                     S256_HIST_SCOPE);
-                                    }
-                                    if (p.stats) atomicAdd(p.stats + 4, 1ull);
-                                } else {
-                                    const int pos = s256_lds_inc(S256_CTRL_OFF);
-                                    if (pos < S256_QCAP) L.queue[pos] = s256_entry(row, v, rel0 + col);
-                                }
+                                const uint32_t pos = (uint32_t)s256_lds_inc(S256_CTRL_OFF + 4) - staged_before;
+                                if (pos < (uint32_t)S256_STG) s256_lds_store64(S256_STG_OFF + pos * 8, s256_entry(row, v, rel0 + col));
                             }
                         }
                 }
@@ -491,8 +518,40 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
         }
         // the accumulators are dead from here on (refresh and drain are real calls)
         s256_barrier_lds();
-        const int qc = L.ctrl[0];
-        const bool overflow = qc > S256_QCAP;
+        // Flush.  The pass's survivors sit in the staging buffer; thread i moves entry i to its row's segment in
+        // global memory (slot from the row's LDS counter) and counts it in the query's histogram.  A tile has a few
+        // dozen survivors, so a wave issues at most ONE store and ONE atomic instruction per tile, and those fit
+        // inside the four vector-memory operations the next main loop's first wait leaves outstanding anyway.
+        // (Placed by the lane that found them, 2 x 7 operations per wave and tile were in flight at that wait, and it
+        //  -- and then the whole workgroup at the barrier behind it -- sat there until they had been acknowledged.)
+        const uint32_t staged_total = s256_lds_u32(S256_CTRL_OFF + 4);
+        const uint32_t staged = staged_total - staged_before;
+        staged_before = staged_total;
+        {
+            const uint32_t nst = staged < (uint32_t)S256_STG ? staged : (uint32_t)S256_STG;
+            for (uint32_t i = tid; i < nst; i += 512) {
+                const uint64_t e = s256_lds_u64(S256_STG_OFF + i * 8);
+                const int row = (int)(e >> 56);
+                const int slot = s256_lds_inc(S256_CNT_OFF + row * 4);
+                if (slot < SEG) {
+                    if (!(p.dbg & 8)) {
+                        myseg[(long)row * seg_row_stride + slot] = s256_entry_to_key(e, idx_base);
+                        if (groups == 1) {                     // a recomputed tile must not be counted twice
+                            uint32_t b = ((uint32_t)(e >> 24) - s256_lds_u32(S256_BASE_OFF + row * 4)) >> S256_SH;
+                            b = b < (uint32_t)(S256_NB - 1) ? b : (uint32_t)(S256_NB - 1);
+                            (void)__hip_atomic_fetch_add(myhist + (long)row * S256_NB + b, 1u, __ATOMIC_RELAXED, S256_HIST_SCOPE);
+                        }
+                    }
+                    if (p.stats) atomicAdd(p.stats + 4, 1ull);
+                } else {
+                    const int pos = s256_lds_inc(S256_CTRL_OFF);
+                    if (pos < S256_QCAP) s256_lds_store64(G256_LDS + pos * 8, e);
+                }
+            }
+        }
+        s256_barrier_lds();
+        const int qc = (int)s256_lds_u32(S256_CTRL_OFF);
+        const bool overflow = qc > S256_QCAP || staged > (uint32_t)S256_STG;
         if (p.stats && tid == 0) {
             if (overflow || groups > 1) atomicAdd(p.stats + 2, 1ull);
             if (overflow || groups > 1 || qc >= S256_DRAIN || (t + 1 >= t1 && qc > 0)) { atomicAdd(p.stats + 0, 1ull); atomicAdd(p.stats + 1, (unsigned long long)qc); }
@@ -514,7 +573,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
         // retry mode (or entering it): merge what was queued, then recompute this tile / its next column group
         s256_drain<KSEL>(L, myseg, seg_row_stride, q0, qvalid, idx_base, tid, p.tau_g);
         if (overflow) {
-            groups = groups < 32 ? groups * 2 : 32;
+            groups = groups < S256_MAXGROUPS ? groups * 2 : S256_MAXGROUPS;
             grp = 0;
         } else if (++grp == groups) {
             groups = 1;
@@ -666,25 +725,44 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
     return 0;
 }
 
-// Slices per query tile.  Workgroups run one per CU in rounds of 256; a slice costs its tiles plus about one
-// tile time of fixed work (pipeline fill, refreshes, the tail), and the slices of a launch are dealt out evenly,
-// so the scan takes about  rounds x (ceil(tiles / s) + 1)  tile times.  Fewer, longer slices on a tie.
-int topk_scan256_splits(int Q, long rows) {
-    const int qtiles = (Q + 255) / 256;
-    const long tiles = (rows + 255) / 256;
-    if (tiles <= 0) return 1;
+// Slices per query tile.  Workgroups run one per CU in rounds; a slice costs its tiles plus about one tile time of
+// fixed work (pipeline fill, refreshes, the tail), and the slices of a launch are dealt out evenly, so the scan
+// takes about  rounds x (ceil(tiles / s) + 1)  tile times.  Fewer, longer slices on a tie.
+static int scan256_best_splits(int qtiles, long tiles, double* cost_out) {
     int best = 1;
     double best_cost = 1e300;
     for (int s = 1; s <= 512; ++s) {
         if (s > tiles) break;
         const long per = (tiles + s - 1) / s;
         if (s > 1 && per < 3) break;
-        const long wgs = (long)qtiles * s;
-        const long rounds = (wgs + 255) / 256;
+        // with >= 8 query tiles the launcher pins every query tile to one XCD (shared histograms): the busiest XCD has
+        // ceil(qtiles / 8) of them and runs their slices on its 32 CUs; with fewer, the slices spread over all 256 CUs
+        const long rounds = qtiles >= 8 ? ((long)((qtiles + 7) / 8) * s + 31) / 32 : ((long)qtiles * s + 255) / 256;
         const double cost = (double)rounds * ((double)per + 1.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
     }
+    if (cost_out) *cost_out = best_cost;
     return best;
+}
+int topk_scan256_splits(int Q, long rows) {
+    const long tiles = (rows + 255) / 256;
+    if (tiles <= 0) return 1;
+    return scan256_best_splits((Q + 255) / 256, tiles, nullptr);
+}
+// A query count that leaves a mostly empty last query tile (10 000 = 39 x 256 + 16) pays a whole tile row of MFMA work
+// for those few queries, and one more query tile can halve the slices the busiest XCD has room for (2064 queries =
+// 9 query tiles: one XCD holds two of them; 2048 + a tail of 16: one each).  The ragged
+// tail (<= 128 queries) then goes to its own launch in the 64- / 128-row mode of the kernel, which runs at the HBM
+// rate: about 0.006 tile times per gallery tile.  Returns the number of queries of the main launch (Q = no split).
+int topk_scan256_main_queries(int Q, long rows) {
+    const long tiles = (rows + 255) / 256;
+    const int rem = Q % 256;
+    if (tiles <= 0 || Q <= 256 || rem == 0 || rem > 128) return Q;
+    double whole = 0.0, main = 0.0;
+    scan256_best_splits((Q + 255) / 256, tiles, &whole);
+    scan256_best_splits(Q / 256, tiles, &main);
+    const double tail = 0.006 * (double)tiles + 0.5;
+    return main + tail < whole ? Q - rem : Q;
 }
 
 }  // namespace revo

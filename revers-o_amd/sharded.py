@@ -23,6 +23,7 @@ can be exercised on CPU with the gloo backend by the tests; the product wiring (
 the HIP kernels and nothing else.  Backend interface:
 
     ksel(k) -> int
+    search(queries, k, threshold) -> (scores, indices, counts)        the whole search on one shard (world size 1)
     candidates(queries, k, top_m) -> int32 [Q, top_m]
     finish(n_queries, k, all_bounds [P, Q, top_m], index_offset) -> uint8 [packed_bytes(Q, k)]
     packed_bytes(n_queries, k) -> int
@@ -45,6 +46,9 @@ class GalleryBackend:
 
     def packed_bytes(self, n_queries, k):
         return self._engine.packed_bytes(n_queries, k)
+
+    def search(self, queries, k, threshold):
+        return self.gallery.search(queries, k, threshold)
 
     def candidates(self, queries, k, top_m):
         return self.gallery.search_candidates(queries, k, top_m)
@@ -123,10 +127,9 @@ class ShardedSearch:
         """queries: identical [Q, D] on every rank.  Returns the global top-k triple on every rank."""
         Q = queries.shape[0]
         top_m = self.top_m(k)
-        mine = self.backend.candidates(queries, k, top_m)                        # [Q, top_m] int32
         if self.world == 1:
-            packed = self.backend.finish(Q, k, None, self.offset)
-            return self.backend.merge(packed, 1, Q, k, threshold)
+            return self.backend.search(queries, k, threshold)                    # one shard: the plain single-GPU search
+        mine = self.backend.candidates(queries, k, top_m)                        # [Q, top_m] int32
         allb = torch.empty((self.world * Q, top_m), dtype=mine.dtype, device=mine.device)
         self._all_gather(allb, mine)                                             # exchange 1: admission scores
         packed = self.backend.finish(Q, k, allb.view(self.world, Q, top_m), self.offset)

@@ -1,0 +1,66 @@
+"""Per-stage times of the two-phase sharded search (sharded.py) rehearsed on ONE GPU: the 1 M x 1024 gallery as 8 shards
+of 125 k rows, 10 000 replicated queries (BASELINE.json configs[3]).  Every shard's phases are timed with the library's
+per-class events; the two all-gathers cannot be measured here (one GPU) and are entered as an assumption.
+    python scripts/sharded_stage_bench.py [N] [Q] [P]"""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, reverso_amd
+from reverso_amd import engine
+dev = torch.device("cuda", 0)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+Q = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
+P = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+D, k = 1024, 10
+g = torch.Generator(device=dev).manual_seed(42)
+full = engine.Gallery(D, N, device=0)
+for s in range(0, N, 125_000):
+    full.add(torch.randn(min(125_000, N - s), D, generator=g, device=dev))
+shard = N // P
+shards = []
+for p in range(P):
+    Gp = engine.Gallery(D, shard, device=0)
+    Gp.add(full.read(p * shard, shard), normalize=False)
+    shards.append(Gp)
+q = torch.randn(Q, D, generator=g, device=dev)
+ksel = engine.search_ksel(k)
+top_m = min(ksel, max(8, -(-ksel // P)))
+pb = engine.packed_bytes(Q, k)
+
+def timed(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    engine.prof_reset(); engine.prof_enable(True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize(); engine.prof_enable(False)
+    prof = engine.prof_report()
+    return e0.elapsed_time(e1) / reps, {c: v["ms"] / reps for c, v in prof.items()}
+
+t1, st1 = timed(lambda: full.search(q, k))
+# phase 1 on shard 0 (all shards are statistically alike), then the gathered bounds of all 8, phase 2 on shard 0, merge of 8
+allb = torch.stack([Gp.search_candidates(q, k, top_m) for Gp in shards])
+tc, stc = timed(lambda: shards[0].search_candidates(q, k, top_m))
+packed = torch.empty((P * pb,), dtype=torch.uint8, device=dev)
+for p, Gp in enumerate(shards):
+    Gp.search_candidates(q, k, top_m)
+    Gp.search_finish(Q, k, allb, None, p * shard, out_packed=packed[p * pb:(p + 1) * pb])
+shards[0].search_candidates(q, k, top_m)
+tf, stf = timed(lambda: shards[0].search_finish(Q, k, allb, None, 0, out_packed=packed[:pb]))
+tfu, _ = timed(lambda: shards[0].search_finish(Q, k, None, None, 0, out_packed=packed[:pb]))
+tm, stm = timed(lambda: engine.merge_topk_packed(packed, P, Q, k))
+s_ref, i_ref, c_ref = full.search(q, k)
+for p, Gp in enumerate(shards):
+    Gp.search_candidates(q, k, top_m)
+    Gp.search_finish(Q, k, allb, None, p * shard, out_packed=packed[p * pb:(p + 1) * pb])
+s2, i2, c2 = engine.merge_topk_packed(packed, P, Q, k)
+kept = int((packed.view(P, pb)[:, : Q * k * 8].contiguous().view(torch.int64) >= 0).sum())
+comm_ms = 2 * 0.06     # assumption: two latency-bound RCCL all-gathers (0.3 MB and 1.2 MB per rank) at ~60 us each on xGMI
+t8 = tc + tf + tm + comm_ms
+print(json.dumps({
+    "N": N, "Q": Q, "shards": P, "top_m": top_m,
+    "one_gpu_ms": round(t1, 4), "one_gpu_stage_ms": {c: round(v, 4) for c, v in sorted(st1.items())},
+    "per_rank_phase1_ms": round(tc, 4), "phase1_stage_ms": {c: round(v, 4) for c, v in sorted(stc.items())},
+    "per_rank_finish_bounded_ms": round(tf, 4), "finish_unbounded_ms": round(tfu, 4), "merge_ms": round(tm, 4),
+    "assumed_comm_ms": comm_ms, "projected_8gpu_ms": round(t8, 4), "projected_speedup": round(t1 / t8, 3),
+    "results_equal_unsharded": bool(torch.equal(i2, i_ref) and torch.equal(s2, s_ref) and torch.equal(c2, c_ref)),
+    "results_kept_per_query_all_ranks": round(kept / Q, 2)}), flush=True)
