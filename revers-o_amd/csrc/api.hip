@@ -2,6 +2,7 @@
 // schedule, the search pipeline, error plumbing and the per-kernel-class profiler.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -670,6 +671,11 @@ extern "C" int32_t revo_gallery_read(revo_gallery* g, int64_t start, int64_t n, 
 
 // Rows of the pre-pass of the 256 x 256 scan: about one round of GEMM tiles, at most a quarter of the gallery
 static long search_prepass_rows(int Q, long N) {
+#ifdef REVO_EXPERIMENTS
+    // (sweep of the pre-pass size, scripts/: 2048 / 4096 / 8192 / 16384 rows at 10 000 queries -> 4.22 / 3.43 / 3.36 /
+    //  3.50 ms per search of a 125 k-row shard: 8192 it is)
+    if (const char* e = getenv("REVO_NPRE")) { const long v = atol(e) / 256 * 256; if (v >= 1024 && v <= N / 4) return v; }
+#endif
     const long qtiles = (Q + 255) / 256;
     long n_pre = (65536 / qtiles) / 256 * 256;
     n_pre = n_pre > 65536 ? 65536 : (n_pre < 8192 ? 8192 : n_pre);

@@ -110,14 +110,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int m_base, int
 // the wave's LDS slab, then whole 256-byte row segments to/from global memory.  For the residual
 // epilogue the old values of the quarter arrive in `res` (loaded by gemm256_load_resid one quarter
 // ahead, so that only the first of the four HBM round trips of a tile is exposed).
+// Branch-free: rows / columns past the matrix edge re-read the last valid row / column chunk (the values are never
+// stored).  With the loads inside per-lane branches the waitcnt pass lost track of which load a register came from
+// and put s_waitcnt vmcnt(0) in front of every one of the 16 store steps of the second half of a tile -- each of
+// them then waited for the previous step's store to be acknowledged by L2.
 template <int QT>
 __device__ __forceinline__ void gemm256_load_resid(const GemmArgs& p, int m_base, int n_base, int lane, f32x4 (&res)[8]) {
-    const int gcol = n_base + (lane & 15) * 4;
+    int gcol = n_base + (lane & 15) * 4;
+    gcol = gcol < p.N ? gcol : p.N - 4;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-        const int grow = m_base + QT * 32 + it * 4 + (lane >> 4);
-        res[it] = (grow < p.M && gcol < p.N) ? *(const f32x4*)((const float*)p.C + (long)grow * p.ldc + gcol)
-                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
+        int grow = m_base + QT * 32 + it * 4 + (lane >> 4);
+        grow = grow < p.M ? grow : p.M - 1;
+        res[it] = *(const f32x4*)((const float*)p.C + (long)grow * p.ldc + gcol);
     }
 }
 template <int EPI, int QT>
@@ -230,12 +235,16 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
             asm volatile("" ::: "memory");
         }
     } else {
+        // Old values of two quarters at a time.  Loads and stores share one in-order-per-type counter (vmcnt), so a
+        // load result that is needed while stores are in flight costs a full drain of both: prefetching a quarter
+        // "one ahead" between the stores of the previous ones made every use such a drain.  Two batches of loads,
+        // each issued when no load result is outstanding, leave two drains per tile.
         f32x4 ra[8], rb[8];
         if (EPI == EPI_RESID_F32) gemm256_load_resid<0>(p, m_base, n_base, lane, ra);
         if (EPI == EPI_RESID_F32) gemm256_load_resid<1>(p, m_base, n_base, lane, rb);
         gemm256_epilogue_f32_quarter<EPI, 0>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, ra);
-        if (EPI == EPI_RESID_F32) gemm256_load_resid<2>(p, m_base, n_base, lane, ra);
         gemm256_epilogue_f32_quarter<EPI, 1>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, rb);
+        if (EPI == EPI_RESID_F32) gemm256_load_resid<2>(p, m_base, n_base, lane, ra);
         if (EPI == EPI_RESID_F32) gemm256_load_resid<3>(p, m_base, n_base, lane, rb);
         gemm256_epilogue_f32_quarter<EPI, 2>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, ra);
         gemm256_epilogue_f32_quarter<EPI, 3>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, rb);
