@@ -15,10 +15,47 @@
 
 namespace revo {
 
-__device__ __forceinline__ bf16x8 tr_pair(const char* lo, const char* hi) {
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lo);
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)hi);
-    const s16x8 c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+// V^T fragments by inline asm.  Through the builtin, the compiler cannot tell these reads from the LDS-DMA that is
+// filling the NEXT ring slots and puts s_waitcnt vmcnt(0) in front of the first of them in every iteration: the K/V
+// tiles requested a few hundred cycles earlier are drained and their latency is paid once per key tile.  The asm reads
+// are invisible to that bookkeeping; their own wait is att_v_wait (operands tied so that no consumer moves above it).
+template <int OFF>
+__device__ __forceinline__ uint64_t att_tr_read(uint32_t lds_addr) {
+    uint64_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+    return v;
+}
+// the 2 k-steps x DB d-blocks of key block KB of a tile: v[s2][d][lo/hi]
+template <int ROWB, int DB, int KB>
+__device__ __forceinline__ void att_v_issue(uint64_t (&v)[2][DB][2], const uint32_t (&va)[DB]) {
+#define ATT_V1(S2, D)                                                          \
+    v[S2][D][0] = att_tr_read<(KB * 32 + 16 * S2) * ROWB>(va[D]);              \
+    v[S2][D][1] = att_tr_read<(KB * 32 + 16 * S2 + 8) * ROWB>(va[D]);
+    ATT_V1(0, 0) ATT_V1(0, 1)
+    if constexpr (DB == 3) { ATT_V1(0, 2) }
+    ATT_V1(1, 0) ATT_V1(1, 1)
+    if constexpr (DB == 3) { ATT_V1(1, 2) }
+#undef ATT_V1
+}
+// LEFT: LDS reads issued after v's that may stay in flight
+template <int DB, int LEFT = 0>
+__device__ __forceinline__ void att_v_wait(uint64_t (&v)[2][DB][2]) {
+    if constexpr (DB == 2) {
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(v[0][0][0]), "+v"(v[0][0][1]), "+v"(v[0][1][0]), "+v"(v[0][1][1]), "+v"(v[1][0][0]),
+                       "+v"(v[1][0][1]), "+v"(v[1][1][0]), "+v"(v[1][1][1])
+                     : "n"(LEFT));
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(%12)"
+                     : "+v"(v[0][0][0]), "+v"(v[0][0][1]), "+v"(v[0][1][0]), "+v"(v[0][1][1]), "+v"(v[0][2][0]),
+                       "+v"(v[0][2][1]), "+v"(v[1][0][0]), "+v"(v[1][0][1]), "+v"(v[1][1][0]), "+v"(v[1][1][1]),
+                       "+v"(v[1][2][0]), "+v"(v[1][2][1])
+                     : "n"(LEFT));
+    }
+}
+__device__ __forceinline__ bf16x8 att_v_frag(uint64_t lo, uint64_t hi) {
+    typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 c = {lo, hi};
     return __builtin_bit_cast(bf16x8, c);
 }
 
@@ -40,8 +77,9 @@ __device__ __forceinline__ void att_dma_issue(const AttDmaSrc& src, char* dst, u
 // Query rows are then taken in rotated order (1, 2, ..., S-1, 0): the patch rows tile the
 // waves exactly and the class-token query lands in a wave of the last workgroup that would
 // otherwise idle (q_rot).
+// (second launch bound: 4 waves per SIMD = two 8-wave workgroups per CU at head_dim 64, i.e. at most 128 VGPRs)
 template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld,
+__global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                           bf16_t* __restrict__ out, long ldo, int S, int H, float c,
                                                           int q_rot, int k_lo) {
     static_assert(HD == 64 || HD == 96, "body attention kernel is built for head_dim 64 (B16, L14) and 96 (G14)");
@@ -197,6 +235,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
             }
     }
 
+    // The query fragments were requested before the first K/V tiles.  Use them here once: the compiler then places its
+    // wait for them in front of the loop.  Left pending, its bookkeeping carries them around the back edge and puts
+    // vmcnt(3..0) in front of the score MFMAs of EVERY iteration, which drains the K/V tiles just requested.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     for (int t = 0; t < nt; ++t) {
         ATT_WAIT_TILE(t);
         __builtin_amdgcn_s_barrier();           // tile t is in LDS for every wave; every wave is done with tile t-1
@@ -232,6 +275,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
             // does the wave take the maximum, move the reference, rescale and redo the exponentials.
             uint32_t pw[2][8];
             f32x2 ps2;
+            // V^T fragments of key block 0 are requested ahead of the exponentials, block 1's before block 0's MFMAs
+            uint64_t vt0[2][DB][2], vt1[2][DB][2];
+            uint32_t vbase[DB];
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+                vbase[d] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(base + vaddr[d]);
+            att_v_issue<ROWB, DB, 0>(vt0, vbase);
 #define ATT_EXPS()                                                                               \
     do {                                                                                         \
         const f32x2 c2_ = {c, c}, m2_ = {m_run, m_run};                                          \
@@ -270,25 +320,24 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
 #undef ATT_EXPS
 #undef ATT_SCORES
             l_run += ps;
-#pragma unroll
-            for (int kblk = 0; kblk < 2; ++kblk) {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    uint4 pk;
-                    pk.x = pw[kblk][4 * s2 + 0];
-                    pk.y = pw[kblk][4 * s2 + 1];
-                    pk.z = pw[kblk][4 * s2 + 2];
-                    pk.w = pw[kblk][4 * s2 + 3];
-                    const bf16x8 pb = __builtin_bit_cast(bf16x8, pk);
-                    // k index (h, j) of this step is key 16*s2 + 8*(j>>2) + 4*h + (j&3) of the block
-#pragma unroll
-                    for (int d = 0; d < DB; ++d) {
-                        const char* alo = base + vaddr[d] + (kblk * 32 + 16 * s2) * ROWB;
-                        const bf16x8 a = tr_pair(alo, alo + 8 * ROWB);
-                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, oacc[d], 0, 0, 0);
-                    }
-                }
-            }
+            att_v_wait<DB>(vt0);
+            att_v_issue<ROWB, DB, 1>(vt1, vbase);
+#define ATT_PV(KB, VT)                                                                                  \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                  \
+        uint4 pk;                                                                                       \
+        pk.x = pw[KB][4 * s2 + 0];                                                                      \
+        pk.y = pw[KB][4 * s2 + 1];                                                                      \
+        pk.z = pw[KB][4 * s2 + 2];                                                                      \
+        pk.w = pw[KB][4 * s2 + 3];                                                                      \
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, pk);                                               \
+        /* k index (h, j) of this step is key 16*s2 + 8*(j>>2) + 4*h + (j&3) of the block */            \
+        _Pragma("unroll") for (int d = 0; d < DB; ++d)                                                  \
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_v_frag(VT[s2][d][0], VT[s2][d][1]), pb, oacc[d], 0, 0, 0); \
+    }
+            ATT_PV(0, vt0);
+            att_v_wait<DB>(vt1);
+            ATT_PV(1, vt1);
+#undef ATT_PV
         }
     }
 
