@@ -12,6 +12,7 @@
 // LDS round trip.  V^T fragments come from ds_read_b64_tr_b16 (hardware
 // transpose) of the row-major V tile.
 #include "kernels.h"
+#include <type_traits>
 
 namespace revo {
 
@@ -25,12 +26,12 @@ __device__ __forceinline__ uint64_t att_tr_read(uint32_t lds_addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
     return v;
 }
-// the 2 k-steps x DB d-blocks of key block KB of a tile: v[s2][d][lo/hi]
-template <int ROWB, int DB, int KB>
+// the 2 k-steps x DB d-blocks of one key block of a tile: v[s2][d][lo/hi]; OFF0 = ring slot + key block (bytes)
+template <int ROWB, int DB, int OFF0>
 __device__ __forceinline__ void att_v_issue(uint64_t (&v)[2][DB][2], const uint32_t (&va)[DB]) {
 #define ATT_V1(S2, D)                                                          \
-    v[S2][D][0] = att_tr_read<(KB * 32 + 16 * S2) * ROWB>(va[D]);              \
-    v[S2][D][1] = att_tr_read<(KB * 32 + 16 * S2 + 8) * ROWB>(va[D]);
+    v[S2][D][0] = att_tr_read<OFF0 + (16 * S2) * ROWB>(va[D]);                 \
+    v[S2][D][1] = att_tr_read<OFF0 + (16 * S2 + 8) * ROWB>(va[D]);
     ATT_V1(0, 0) ATT_V1(0, 1)
     if constexpr (DB == 3) { ATT_V1(0, 2) }
     ATT_V1(1, 0) ATT_V1(1, 1)
@@ -52,6 +53,20 @@ __device__ __forceinline__ void att_v_wait(uint64_t (&v)[2][DB][2]) {
                        "+v"(v[1][2][0]), "+v"(v[1][2][1])
                      : "n"(LEFT));
     }
+}
+// K fragments the same way (ds_read_b128), four reads deep: a fragment's registers are refilled right behind the MFMA
+// that consumed them and the MFMAs wait with counts.  Left to the compiler under the 128-VGPR budget, each read was
+// issued into the same four registers right before the MFMA that consumes it: eight exposed LDS latencies per tile.
+typedef uint32_t att_u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ att_u32x4 att_read_b128(uint32_t lds_addr) {
+    att_u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+    return v;
+}
+template <int LEFT>
+__device__ __forceinline__ void att_k_wait(att_u32x4& k) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(k) : "n"(LEFT));
 }
 __device__ __forceinline__ bf16x8 att_v_frag(uint64_t lo, uint64_t hi) {
     typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
@@ -164,9 +179,9 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
         dma_voff[i] = (ch < CH && j < NI) ? (uint32_t)(((long)key * ld + (isv ? W : 0)) * 2 + ch * 16) : 0x80000000u;
     }
     const uint32_t tile_bytes = (uint32_t)(64 * ld * 2);
-#define ATT_ISSUE_TILE(t)                                                                       \
+#define ATT_ISSUE_TILE(slot, t)                                                                 \
     do {                                                                                        \
-        char* dst_ = lds + ((t) % NBUF) * BUF + wave * 1024;                                    \
+        char* dst_ = lds + (slot) * BUF + wave * 1024;                                          \
         _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                       \
             char* d_ = (NDUMMY == 0 || wave + NW * i < NI) ? dst_ + i * NW * 1024               \
                                                            : lds + NBUF * BUF + (wave + NW * i - NI) * 1024; \
@@ -182,18 +197,19 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
     } while (0)
 
     // ---- per-lane LDS fragment addresses (buffer 0), swizzles resolved once
-    int kaddr[KS], vaddr[DB];
+    uint32_t kaddr[KS], vaddr[DB];
     {
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
         const int sw = HD == 64 ? ((r >> 1) & 7) : (r & 15);      // same for key r and key r + 32
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kaddr[ks] = r * ROWB + (((2 * ks + hh) ^ sw) << 4);
+        for (int ks = 0; ks < KS; ++ks) kaddr[ks] = lds0 + r * ROWB + (((2 * ks + hh) ^ sw) << 4);
         const int g16 = lane >> 4, li = lane & 15;
         const int tq = li >> 2, tp = li & 3;
         // V swizzle of keys 4*hh + tq (+ multiples of 8): moves whole 64-byte d-blocks
         const int sv = HD == 64 ? ((tq >> 1) & 1) : tq;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
-            vaddr[d] = TILE + (4 * hh + tq) * ROWB + ((((d ^ sv) * 4 + (g16 & 1) * 2 + (tp >> 1))) << 4) + (tp & 1) * 8;
+            vaddr[d] = lds0 + TILE + (4 * hh + tq) * ROWB + ((((d ^ sv) * 4 + (g16 & 1) * 2 + (tp >> 1))) << 4) + (tp & 1) * 8;
     }
 
     f32x16 oacc[DB];
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
     // tile t + NBUF - 1 behind its barrier, i.e. once every wave is done with tile t-1 (same buffer)
 #pragma unroll
     for (int u = 0; u < NBUF - 1; ++u)
-        if (u < nt) ATT_ISSUE_TILE(u);
+        if (u < nt) ATT_ISSUE_TILE(u, u);
 
     if (k_lo == 1 && wave_active) {
         // rank-1 prelude with key row 0: this lane holds q[d] for d = 16*ks + 8*hh + j
@@ -240,88 +256,103 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
     // vmcnt(3..0) in front of the score MFMAs of EVERY iteration, which drains the K/V tiles just requested.
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
-    for (int t = 0; t < nt; ++t) {
+    // One key tile.  The ring slot is a compile-time constant (the loop below is unrolled NBUF times), so every LDS
+    // address is a per-lane register fixed at kernel entry plus an immediate.
+    auto tile_step = [&](auto slot_c, const int t) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int SB = SLOT * BUF;
         ATT_WAIT_TILE(t);
         __builtin_amdgcn_s_barrier();           // tile t is in LDS for every wave; every wave is done with tile t-1
-        if (t + NBUF - 1 < nt) ATT_ISSUE_TILE(t + NBUF - 1);
-        if (wave_active) {
-            const char* base = lds + (t % NBUF) * BUF;
-            f32x16 sacc[2];
-            // S^T = K . Q^T for the 64 keys of the tile, masked past the last key
-#define ATT_SCORES()                                                                                 \
-    do {                                                                                             \
-        _Pragma("unroll") for (int kblk = 0; kblk < 2; ++kblk) {                                     \
-            _Pragma("unroll") for (int i = 0; i < 16; ++i) sacc[kblk][i] = 0.f;                      \
-            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                      \
-                const bf16x8 a_ = *(const bf16x8*)(base + kaddr[ks] + kblk * 32 * ROWB);             \
-                sacc[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, qf[ks], sacc[kblk], 0, 0, 0); \
-            }                                                                                        \
-        }                                                                                            \
-        if (t == nt - 1 && (nkeys & 63)) {                                                           \
-            asm volatile("" ::: "memory"); /* a real branch: if-converted, this is 32 selects per key tile */ \
-            _Pragma("unroll") for (int kblk = 0; kblk < 2; ++kblk)                                   \
-                _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                     \
-                    const int key_ = t * 64 + kblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;           \
-                    if (key_ >= nkeys) sacc[kblk][i] = -INFINITY;                                    \
-                }                                                                                    \
-        }                                                                                            \
-    } while (0)
-            ATT_SCORES();
-            // Optimistic softmax.  p = 2^(s c - m) is computed against the running reference m on
-            // register pairs (v_pk_fma_f32 / v_pk_add_f32 / v_cvt_pk_bf16_f32) WITHOUT first taking the
-            // tile maximum: the softmax VALU work, not the MFMAs, bounds this kernel at head_dim 64.
-            // fp32 and bf16 share the exponent range, so a reference that lags the true maximum by up
-            // to 2^80 loses no precision; only when a row sum leaves that range (or m is still -inf)
-            // does the wave take the maximum, move the reference, rescale and redo the exponentials.
-            uint32_t pw[2][8];
-            f32x2 ps2;
-            // V^T fragments of key block 0 are requested ahead of the exponentials, block 1's before block 0's MFMAs
-            uint64_t vt0[2][DB][2], vt1[2][DB][2];
-            uint32_t vbase[DB];
+        if (t + NBUF - 1 < nt) ATT_ISSUE_TILE((SLOT + NBUF - 1) % NBUF, t + NBUF - 1);
+        if (!wave_active) return;
+        f32x16 sacc[2];
+        att_u32x4 kf[4];
+        // S^T = K . Q^T for the 64 keys of the tile, masked past the last key
+        auto scores = [&]() __attribute__((always_inline)) {
+            constexpr int NR = 2 * KS;          // fragment i: key block i / KS, k-step i % KS
+#define ATT_KOFF(i) (SB + ((i) / KS) * 32 * ROWB)
+            kf[0] = att_read_b128<ATT_KOFF(0)>(kaddr[0]);
+            kf[1] = att_read_b128<ATT_KOFF(1)>(kaddr[1]);
+            kf[2] = att_read_b128<ATT_KOFF(2)>(kaddr[2]);
+            kf[3] = att_read_b128<ATT_KOFF(3)>(kaddr[3]);
 #pragma unroll
-            for (int d = 0; d < DB; ++d)
-                vbase[d] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(base + vaddr[d]);
-            att_v_issue<ROWB, DB, 0>(vt0, vbase);
-#define ATT_EXPS()                                                                               \
-    do {                                                                                         \
-        const f32x2 c2_ = {c, c}, m2_ = {m_run, m_run};                                          \
-        ps2 = (f32x2){0.f, 0.f};                                                                 \
-        _Pragma("unroll") for (int kblk = 0; kblk < 2; ++kblk)                                   \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                      \
-                const f32x2 sv_ = {sacc[kblk][2 * j], sacc[kblk][2 * j + 1]};                    \
-                const f32x2 e_ = sv_ * c2_ - m2_;                                                \
-                const f32x2 pv_ = {__builtin_amdgcn_exp2f(e_.x), __builtin_amdgcn_exp2f(e_.y)};  \
-                ps2 += pv_;                                                                      \
-                pw[kblk][j] = pack_bf16x2(pv_.x, pv_.y);                                         \
-            }                                                                                    \
-    } while (0)
-            ATT_EXPS();
-            float ps = ps2.x + ps2.y;
-            if (!__all(ps < 0x1p80f)) {
-                asm volatile("" ::: "memory");
-                ATT_SCORES();       // rare path: the scores were consumed in place, compute them again
-                float mx = -INFINITY;
+            for (int kblk = 0; kblk < 2; ++kblk)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sacc[kblk][i] = 0.f;
+#define ATT_KSTEP(i)                                                                                              \
+    if constexpr ((i) < NR) {                                                                                     \
+        if constexpr ((i) + 4 <= NR) att_k_wait<3>(kf[(i) % 4]);                                                  \
+        else att_k_wait<NR - 1 - (i)>(kf[(i) % 4]);                                                               \
+        sacc[(i) / KS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[(i) % 4]), qf[(i) % KS], \
+                                                                 sacc[(i) / KS], 0, 0, 0);                          \
+        if constexpr ((i) + 4 < NR) kf[(i) % 4] = att_read_b128<ATT_KOFF((i) + 4)>(kaddr[((i) + 4) % KS]);        \
+    }
+            ATT_KSTEP(0) ATT_KSTEP(1) ATT_KSTEP(2) ATT_KSTEP(3) ATT_KSTEP(4) ATT_KSTEP(5)
+            ATT_KSTEP(6) ATT_KSTEP(7) ATT_KSTEP(8) ATT_KSTEP(9) ATT_KSTEP(10) ATT_KSTEP(11)
+#undef ATT_KSTEP
+#undef ATT_KOFF
+            if (t == nt - 1 && (nkeys & 63)) {
+                asm volatile("" ::: "memory"); /* a real branch: if-converted, this is 32 selects per key tile */
 #pragma unroll
                 for (int kblk = 0; kblk < 2; ++kblk)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kblk][i]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 when m_run was -inf
-                m_run = m_new;
-                l_run *= alpha;
-#pragma unroll
-                for (int d = 0; d < DB; ++d)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
-                ATT_EXPS();
-                ps = ps2.x + ps2.y;
+                    for (int i = 0; i < 16; ++i) {
+                        const int key_ = t * 64 + kblk * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                        if (key_ >= nkeys) sacc[kblk][i] = -INFINITY;
+                    }
             }
-#undef ATT_EXPS
-#undef ATT_SCORES
-            l_run += ps;
-            att_v_wait<DB>(vt0);
-            att_v_issue<ROWB, DB, 1>(vt1, vbase);
+        };
+        scores();
+        // V^T fragments of key block 0 are requested ahead of the exponentials, block 1's before block 0's MFMAs
+        uint64_t vt0[2][DB][2], vt1[2][DB][2];
+        att_v_issue<ROWB, DB, SB>(vt0, vaddr);
+        // Optimistic softmax.  p = 2^(s c - m) is computed against the running reference m on
+        // register pairs (v_pk_fma_f32 / v_pk_add_f32 / v_cvt_pk_bf16_f32) WITHOUT first taking the
+        // tile maximum: the softmax VALU work, not the MFMAs, bounds this kernel at head_dim 64.
+        // fp32 and bf16 share the exponent range, so a reference that lags the true maximum by up
+        // to 2^80 loses no precision; only when a row sum leaves that range (or m is still -inf)
+        // does the wave take the maximum, move the reference, rescale and redo the exponentials.
+        uint32_t pw[2][8];
+        f32x2 ps2;
+        auto exps = [&]() __attribute__((always_inline)) {
+            const f32x2 c2_ = {c, c}, m2_ = {m_run, m_run};
+            ps2 = (f32x2){0.f, 0.f};
+#pragma unroll
+            for (int kblk = 0; kblk < 2; ++kblk)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f32x2 sv_ = {sacc[kblk][2 * j], sacc[kblk][2 * j + 1]};
+                    const f32x2 e_ = sv_ * c2_ - m2_;
+                    const f32x2 pv_ = {__builtin_amdgcn_exp2f(e_.x), __builtin_amdgcn_exp2f(e_.y)};
+                    ps2 += pv_;
+                    pw[kblk][j] = pack_bf16x2(pv_.x, pv_.y);
+                }
+        };
+        exps();
+        float ps = ps2.x + ps2.y;
+        if (!__all(ps < 0x1p80f)) {
+            asm volatile("" ::: "memory");
+            scores();           // rare path: the scores were consumed in place, compute them again
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kblk = 0; kblk < 2; ++kblk)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kblk][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 when m_run was -inf
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+            exps();
+            ps = ps2.x + ps2.y;
+        }
+        l_run += ps;
+        att_v_wait<DB>(vt0);
+        att_v_issue<ROWB, DB, SB + 32 * ROWB>(vt1, vaddr);
 #define ATT_PV(KB, VT)                                                                                  \
     _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                  \
         uint4 pk;                                                                                       \
@@ -334,11 +365,15 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
         _Pragma("unroll") for (int d = 0; d < DB; ++d)                                                  \
             oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_v_frag(VT[s2][d][0], VT[s2][d][1]), pb, oacc[d], 0, 0, 0); \
     }
-            ATT_PV(0, vt0);
-            att_v_wait<DB>(vt1);
-            ATT_PV(1, vt1);
+        ATT_PV(0, vt0);
+        att_v_wait<DB>(vt1);
+        ATT_PV(1, vt1);
 #undef ATT_PV
-        }
+    };
+    for (int t = 0; t < nt; t += NBUF) {
+        tile_step(std::integral_constant<int, 0>{}, t);
+        if (NBUF > 1 && t + 1 < nt) tile_step(std::integral_constant<int, 1 % NBUF>{}, t + 1);
+        if (NBUF > 2 && t + 2 < nt) tile_step(std::integral_constant<int, 2 % NBUF>{}, t + 2);
     }
 
     if constexpr (HD == 64) {

@@ -16,11 +16,14 @@ def go(): _lib.check(lib.revo_op_attention(_lib.ptr(qkv), 3 * W, _lib.ptr(out), 
 nw = int(os.environ.get("ATTN_NW", "0")); lib.revo_op_set_gemm_debug(nw << 8)
 for _ in range(3): go()
 torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(20): go()
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 20
+times = []
+for _ in range(5):          # median of 5 rounds of 100 launches: single rounds move by +-5 % with the clock
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100): go()
+    e1.record(); torch.cuda.synchronize()
+    times.append(e0.elapsed_time(e1) / 100)
+ms = sorted(times)[2]
 fl = 4.0 * B * H * S * S * hd
 print(f"attention B={B} S={S} H={H}: {ms:.4f} ms  {fl/ms/1e9:.1f} TF")
 x = qkv[: 2 * S].float().reshape(2, S, 3, H, hd)
