@@ -335,6 +335,45 @@ def test_wide_k_adversarial_overflow_and_ties(dev):
     G.close()
 
 
+@pytest.mark.parametrize("k,csize", [(10, 22), (50, 14)])
+def test_near_duplicate_frame_clusters(dev, k, csize):
+    """Near-duplicate video frames (the reference stores one vector per frame region, core_system.py:406-408): clusters
+    of rows 1e-3 apart per element whose scores against a query lie within ~6e-5 of each other, i.e. inside the scan's
+    bf16 input rounding (~1e-4): the scan's ranking INSIDE a cluster is noise.  The guarantee ("Why
+    bit-exact indices with a bf16 scan") is that nothing is lost while a cluster that straddles the k-th place has at
+    most ksel - k members more than the result holds: 22 at k = 10 (32 candidates kept), 14 at k = 50 (64 kept).
+    Every query's whole result comes out of one cluster of k + csize members and the fp32 re-score has to order them.
+    Neighbouring scores are ~2e-6 apart, so a few queries have an fp32-level tie (< 3e-7) at the k-th place:
+    checked is that every returned row scores (fp64) at least the oracle's k-th score minus that, and that the score
+    lists agree to 1e-6."""
+    N, D, Q = 150000, 256, 96
+    rng = np.random.default_rng(100 + k)
+    gal = rng.standard_normal((N, D), dtype=np.float32)
+    centres = rng.standard_normal((Q, D), dtype=np.float32)
+    members = csize + k
+    pos = rng.permutation(N)[: Q * members].reshape(Q, members)
+    for q in range(Q):
+        gal[pos[q]] = centres[q][None] + 1e-3 * rng.standard_normal((members, D), dtype=np.float32)
+    qr = centres + 0.3 * rng.standard_normal((Q, D), dtype=np.float32)
+    G = engine.Gallery(D, N, device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    s, i, c = (t.cpu().numpy() for t in G.search(torch.from_numpy(qr).to(dev), k, None))
+    G.close()
+    rs, ri, rc = osearch.search(gal, qr, k)
+    assert np.array_equal(c, rc)
+    assert np.abs(s - rs).max() <= 1e-6
+    assert np.median(np.abs(np.diff(rs, axis=1))) > 5e-7        # the planted gaps are well above fp32 resolution
+    g64, q64 = gal.astype(np.float64), qr.astype(np.float64)
+    exact_ties = 0
+    for q in range(Q):
+        assert set(i[q].tolist()) <= set(pos[q].tolist()), q
+        rows = g64[i[q]]
+        true = (rows @ q64[q]) / (np.linalg.norm(rows, axis=1) * np.linalg.norm(q64[q]))
+        assert true.min() >= rs[q, k - 1] - 3e-7, (q, true.min(), rs[q, k - 1])
+        exact_ties += sorted(i[q].tolist()) != sorted(ri[q].tolist())
+    assert exact_ties <= Q // 8     # only the occasional tie at the k-th place
+
+
 @pytest.mark.parametrize("k", [10, 50])
 def test_scan_bound_histogram_edge_cases(dev, k):
     """The scan's admission bound comes from per-query score histograms whose 64 buckets start at the
