@@ -939,6 +939,7 @@ extern "C" int32_t revo_op_set_variant(int32_t flags) {
 // timing experiments (librevo_exp.so only): the variant bits plus the switches that skip work
 extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
     revo::gemm_set_debug(flags & 3);
+    revo::gemm_set_stagger(((flags >> 28) & 15) * 200, 2 + ((flags >> 2) & 3));   // bits 28-31: stagger in 2 us steps (100 MHz clock), bits 2-3: groups - 2
     revo::topk_scan256_set_debug(((flags >> 13) & 7) | (((flags >> 20) & 255) << 3));
     return revo_op_set_variant(flags);
 }

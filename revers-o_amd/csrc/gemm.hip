@@ -370,6 +370,15 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     char* slab = smem + (wave < 3 ? 32768 + wave * 9216 : 98304 + (wave - 3) * 9216);
+#ifdef REVO_EXPERIMENTS
+    if (p.stagger_cycles > 0) {
+        // timing experiment: phase groups.  Workgroup (slot % groups) starts (that / groups) of a tile time late.
+        const int grp = (blockIdx.x >> 3) % p.stagger_groups;
+        const long t0 = (long)__builtin_amdgcn_s_memrealtime();     // constant 100 MHz clock
+        const long wait = (long)p.stagger_cycles * grp / p.stagger_groups;
+        while ((long)__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
 
     int m0 = (m_lo + slot / n_cnt) * 256, n0 = (n_lo + slot % n_cnt) * 256;
     G256Operand A, B;
@@ -497,12 +506,19 @@ static int launch_256d(const GemmArgs& a, hipStream_t st) {
     return 0;
 }
 
+#ifdef REVO_EXPERIMENTS
+static int g_stagger_cycles = 0, g_stagger_groups = 2;
+void gemm_set_stagger(int cycles, int groups) { g_stagger_cycles = cycles; g_stagger_groups = groups < 1 ? 1 : groups; }
+#endif
 static int g_persistent = 1;   // timing experiments only: 0 = one workgroup per tile
 void gemm_set_persistent(int on) { g_persistent = on; }
 template <int EPI>
 static int launch_256p(const GemmArgs& a, hipStream_t st) {
     REVO_FUNC_LDS(gemm256p_kernel<EPI>, G256P_LDS);
     GemmArgs b = a;
+#ifdef REVO_EXPERIMENTS
+    b.stagger_cycles = g_stagger_cycles; b.stagger_groups = g_stagger_groups;
+#endif
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
     int gy = tiles_n >= 12 ? 4 : (tiles_n >= 8 ? 2 : 1);
     if (g_force_gy) gy = g_force_gy;

@@ -29,12 +29,16 @@ struct GemmArgs {
     int prefer256;               // caller's hint: few rows but very many columns (search pre-pass) -> 256 x 256 tiles
     float* ws; long ws_elems;    // optional scratch for the split-K tail of EPI_RESID_F32 (null = never split K)
     int ksplit; long c_split_stride;   // set by the launcher: K ranges per tile, fp32 elements between partial outputs
+#ifdef REVO_EXPERIMENTS
+    int stagger_cycles, stagger_groups;   // timing experiment (persistent kernel): phase groups, see gemm256p_kernel
+#endif
 };
 // true when launch_gemm would run the 256 x 256 kernel with the row-coalesced epilogue for these sizes
 bool gemm_uses_wide_epilogue(int M, int N, long lda, long ldb, long ldc);
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
 #ifdef REVO_EXPERIMENTS
 void gemm_set_debug(int d);           // timing experiments (results are wrong): librevo_exp.so only
+void gemm_set_stagger(int cycles, int groups);
 #endif
 void gemm_force_gy(int gy);
 void gemm_set_tail_split(int on);
