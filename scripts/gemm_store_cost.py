@@ -22,11 +22,11 @@ def bench(M, N, K, flags, iters=50):
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / iters)
     _lib.check(lib.revo_op_set_gemm_debug(0))
     return sorted(ts)[2]
-for (M, N, K) in [(36864, 4096, 1024), (36864, 3072, 1024)]:
+for (M, N, K) in [(36864, 4096, 1024), (36864, 3072, 1024), (32768, 1024, 4096), (32768, 1024, 1024)]:
     fl = 2.0 * M * N * K
     r = {}
     variants = [("persistent", 0), ("per-tile", 1 << 16), ("per-tile no stores", (1 << 16) | 1), ("per-tile no main loop", (1 << 16) | 2)]
-    for groups in (2, 4):
+    for groups in ():
         for us in (6, 12, 18, 24):
             variants.append((f"persistent {groups} phase groups, last starts {us * (groups - 1) // groups} us late", ((us // 2) << 28) | ((groups - 2) << 2)))
     for name, flags in variants:
