@@ -1,0 +1,58 @@
+"""GPU: bench.py's output contract at N = 1 and, rehearsed with two ranks on this one GPU (gloo, host staging: RCCL
+wants one device per rank), at N = 2 -- the launch line is the driver's (`python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N`).  A small tower and gallery: this checks the JSON
+line, the sharded leg and the rank-0-only fields, not speed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--variant", "PE-Tiny-T14-56", "--batch", "8", "--gallery", "60000", "--steps", "2", "--warmup", "1",
+         "--search-queries", "600", "--no-cpu-baseline"]
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_contract(d, n):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1
+    assert d["unit"] == "images/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "bf16"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 8 * n / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]      # whole-job images / max-over-ranks time
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9
+    sq = d["search_query_batch"]
+    assert sq["queries"] == 600 and sq["gallery_rows"] == 60000 and sq["shard_rows"] == 60000 // n
+    assert sq["sharded_ms"] > 0
+
+
+def test_bench_contract_one_gpu(dev):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    _check_contract(_json_line(p.stdout), 1)
+
+
+def test_bench_contract_two_ranks_on_one_gpu(dev):
+    port = 29700 + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-gpu", "--backend", "gloo"] + SMALL
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _json_line(p.stdout)
+    _check_contract(d, 2)
+    sq = d["search_query_batch"]
+    assert sq["one_gpu_ms_same_process"] > 0 and sq["speedup_vs_1gpu_model"] > 0      # rank 0's 1-GPU run of the same search
+    assert "cpu_baseline" not in d                                                       # N = 1 only
