@@ -230,6 +230,14 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
                         v = make_uint4(w[0], w[1], w[2], w[3]);
                     }
                 }
+                // qkv and the MLP hidden activations (226 / 302 MB at PE-L14, batch 64) are written once and read once by the
+                // next kernel: stored non-temporally they leave more of L2 / Infinity Cache to the operands and to the
+                // fp32 residual stream (measured in the step: fc1 -1.4 %, fc2 -1.3 %, qkv -1 %)
+                typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+                if (EPI == EPI_BF16_ROPE || EPI == EPI_BF16_GELU) {
+                    if (grow < p.M && gcol < p.N)
+                        __builtin_nontemporal_store(__builtin_bit_cast(nt_u32x4, v), (nt_u32x4*)((bf16_t*)p.C + (long)grow * p.ldc + gcol));
+                } else
                 if (grow < p.M && gcol < p.N) *(uint4*)((bf16_t*)p.C + (long)grow * p.ldc + gcol) = v;
             }
             asm volatile("" ::: "memory");
