@@ -184,7 +184,7 @@ struct revo_vit {
     bf16_t *patches = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr, *pool_att = nullptr,
            *pool_h = nullptr, *pool_m = nullptr, *pool_ob = nullptr;
     float *x = nullptr, *pool_o = nullptr, *feat = nullptr;
-    float* splitk_ws = nullptr;        // fp32 partial planes of the split-K residual GEMMs, one region per stream
+    float* splitk_ws = nullptr;        // fp32 partial planes of the split-K residual GEMMs
 
     template <class T> int dalloc(T** out, size_t count) {
         void* p = nullptr;
