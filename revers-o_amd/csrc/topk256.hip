@@ -599,6 +599,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
 // segments of all slices.  Wave w packs the segments of slices w, w + RW, ... into 64-key chunks (whole
 // segments, so that a repeated key always sits in one chunk or in consecutive ones), sorts each chunk
 // and merges it into its running list; the RW partial lists meet in LDS and wave 0 merges them.
+// With few slices (up to 32; a shard of a row-sharded gallery: 6) one wave per query does all of it, four queries per workgroup:
+// their segments pack into one or two chunks, against one sort per slice and RW - 1 merges in the 8-wave form.
 constexpr int S256_RW = 8;
 template <int KSEL>
 __device__ __forceinline__ uint64_t s256_fold_chunk(uint64_t run, uint64_t chunk, uint64_t* ws, int lane) {
@@ -614,31 +616,34 @@ __device__ __forceinline__ uint64_t s256_fold_chunk(uint64_t run, uint64_t chunk
         return s256_merge_step<64>(run, s256_shfl_xor(chunk, 63), ws, lane);
     }
 }
-template <int KSEL>
-__global__ __launch_bounds__(S256_RW * 64) void topk_reduce_segs_kernel(const uint64_t* __restrict__ seg,
-                                                                       const int* __restrict__ seg_cnt, int splits,
-                                                                       const uint64_t* __restrict__ prelist,
-                                                                       uint64_t* __restrict__ out) {
+template <int KSEL, int RW>
+__global__ __launch_bounds__((RW == 1 ? 4 : RW) * 64) void topk_reduce_segs_kernel(const uint64_t* __restrict__ seg,
+                                                                                  const int* __restrict__ seg_cnt, int splits,
+                                                                                  const uint64_t* __restrict__ prelist,
+                                                                                  uint64_t* __restrict__ out, int Q) {
     constexpr int SEG = 2 * KSEL;
-    __shared__ uint64_t partial[S256_RW][64];
-    __shared__ uint64_t wsb[S256_RW][128];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long q = blockIdx.x;
-    uint64_t* ws = wsb[w];
+    constexpr int NWV = RW == 1 ? 4 : RW;               // waves per workgroup
+    __shared__ uint64_t partial[RW == 1 ? 1 : RW][64];
+    __shared__ uint64_t wsb[NWV][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int w = RW == 1 ? 0 : wv;                     // this wave's share of the query's slices: w, w + RW, ...
+    const long q = RW == 1 ? (long)blockIdx.x * 4 + wv : (long)blockIdx.x;
+    if (RW == 1 && q >= Q) return;
+    uint64_t* ws = wsb[wv];
     uint64_t run = (w == 0 && lane < KSEL) ? prelist[q * KSEL + lane] : 0ull;
     uint64_t chunk = 0ull;
     int fill = 0;                                      // wave-uniform
     const int* cq = seg_cnt + q * splits;
     const uint64_t* sq = seg + q * (long)splits * SEG;
     // this wave's counts, one slice per lane (slices w + RW * lane), 64 slices at a time
-    for (int sb = w; sb < splits; sb += S256_RW * 64) {
-        const int my = sb + S256_RW * lane;
+    for (int sb = w; sb < splits; sb += RW * 64) {
+        const int my = sb + RW * lane;
         const int cl = my < splits ? cq[my] : 0;
-        const int nlan = (splits - sb + S256_RW - 1) / S256_RW;
+        const int nlan = (splits - sb + RW - 1) / RW;
         for (int i = 0; i < (nlan < 64 ? nlan : 64); ++i) {
             int c = __builtin_amdgcn_readlane(cl, i);
             if (c <= 0) continue;
-            const uint64_t* sp = sq + (long)(sb + S256_RW * i) * SEG;
+            const uint64_t* sp = sq + (long)(sb + RW * i) * SEG;
             int done = 0;
             while (done < c) {
                 int take = c - done;
@@ -653,11 +658,15 @@ __global__ __launch_bounds__(S256_RW * 64) void topk_reduce_segs_kernel(const ui
         }
     }
     if (fill > 0) run = s256_fold_chunk<KSEL>(run, chunk, ws, lane);
+    if constexpr (RW == 1) {
+        if (lane < KSEL) out[q * KSEL + lane] = run;
+        return;
+    }
     partial[w][lane] = run;
     __syncthreads();
     if (w == 0) {
 #pragma unroll 1
-        for (int o = 1; o < S256_RW; ++o) {
+        for (int o = 1; o < RW; ++o) {
             const uint64_t other = partial[o][63 - lane];              // worst first; KSEL = 32: lanes 32..63 <- entries 31..0
             run = s256_merge_step<KSEL>(run, other, ws, lane);
         }
@@ -667,8 +676,15 @@ __global__ __launch_bounds__(S256_RW * 64) void topk_reduce_segs_kernel(const ui
 int launch_topk_reduce_segs(const uint64_t* seg, const int* seg_cnt, int splits, const uint64_t* prelist, uint64_t* out,
                             int Q, int ksel, hipStream_t st) {
     if (Q <= 0) return 0;
-    if (ksel == 32) hipLaunchKernelGGL((topk_reduce_segs_kernel<32>), dim3(Q), dim3(S256_RW * 64), 0, st, seg, seg_cnt, splits, prelist, out);
-    else hipLaunchKernelGGL((topk_reduce_segs_kernel<64>), dim3(Q), dim3(S256_RW * 64), 0, st, seg, seg_cnt, splits, prelist, out);
+    if (splits <= 32) {
+        const dim3 grid((unsigned)((Q + 3) / 4)), block(4 * 64);
+        if (ksel == 32) hipLaunchKernelGGL((topk_reduce_segs_kernel<32, 1>), grid, block, 0, st, seg, seg_cnt, splits, prelist, out, Q);
+        else hipLaunchKernelGGL((topk_reduce_segs_kernel<64, 1>), grid, block, 0, st, seg, seg_cnt, splits, prelist, out, Q);
+    } else {
+        const dim3 grid((unsigned)Q), block(S256_RW * 64);
+        if (ksel == 32) hipLaunchKernelGGL((topk_reduce_segs_kernel<32, S256_RW>), grid, block, 0, st, seg, seg_cnt, splits, prelist, out, Q);
+        else hipLaunchKernelGGL((topk_reduce_segs_kernel<64, S256_RW>), grid, block, 0, st, seg, seg_cnt, splits, prelist, out, Q);
+    }
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
