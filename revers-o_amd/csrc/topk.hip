@@ -443,6 +443,33 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
     float tau = orderable_f32((uint32_t)__builtin_amdgcn_readlane((int)o, KSEL - 1));
     uint64_t run = 0ull;
     int cnt = 0;                           // wave-uniform
+    // Pass 2.  Usually at most 64 scores of the strip reach T: every lane counts its own, one prefix sum over the
+    // lanes gives each its place in the compacted list, and the list is sorted once.  (A ballot per element -- 128 of
+    // them, each with a branch -- is what this kernel's time used to go into.)  More than 64 (ties, duplicates): the
+    // chunked walk below.
+    int mine = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mine += (v[i][e] >= tau && v[i][e] > -INFINITY) ? 1 : 0;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total <= 64) {
+        int pos = incl - mine;
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sv = v[i][e];
+                if (sv >= tau && sv > -INFINITY) cand[w][pos++] = make_key(sv, (uint32_t)(c0 + (i * 64 + lane) * 4 + e));
+            }
+        cnt = total;
+    } else {
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
 #pragma unroll
@@ -457,6 +484,7 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
             cnt += add;
             if (cnt == 64) sel_flush<KSEL>(run, tau, cnt, cand[w], lane);
         }
+    }
     }
     if (cnt > 0) sel_flush<KSEL>(run, tau, cnt, cand[w], lane);
     partial[w][lane] = run;
