@@ -381,10 +381,11 @@ int launch_topk_publish(const uint64_t* part, long part_stride, int Q, int top_m
 // the KSEL best (score, column) keys of every row, best first, written to
 // part[q][slot][KSEL], and tau0[q] = the KSEL-th score (-inf if fewer than KSEL columns).
 //
-// One workgroup per query, one wave per strip of 8192 columns, the strip held in registers (32 x 16-byte
-// loads per lane, all in flight at once).  Pass 1: every lane takes the maximum of its 128 scores; those 64
+// One workgroup per query, one wave per strip of 4096 columns, the strip held in registers (16 x 16-byte
+// loads per lane, all in flight at once; 8192-column strips took 174 VGPRs, two waves per SIMD, and were
+// 10 % slower).  Pass 1: every lane takes the maximum of its 64 scores; those 64
 // maxima belong to 64 different columns, so their KSEL-th largest is a lower bound T of the strip's KSEL-th
-// best score -- one 64-value sort instead of a running list.  Pass 2: the few scores >= T (about 45 of 8192 for
+// best score -- one 64-value sort instead of a running list.  Pass 2: the few scores >= T (about 45 of 4096 for
 // KSEL = 32) are compacted into LDS and sorted once.  (The previous form walked 64-column chunks against a
 // running bound and sorted whenever 64 survivors had gathered, 16 waves per query with a serial 15-step
 // merge at the end: 0.59 ms for 10 000 x 8192 scores; this one is bound by reading the scores.)
@@ -403,8 +404,9 @@ __device__ __noinline__ void sel_flush(uint64_t& run, float& tau, int& cnt, cons
     run = r;
     cnt = 0;
 }
-constexpr int SEL_STRIP = 8192;     // columns per wave
-constexpr int SEL_MAXW = 8;         // waves per query: n <= 65536
+constexpr int SEL_STRIP = 4096;     // columns per wave
+constexpr int SEL_MAXW = 16;        // waves per query: n <= 65536
+constexpr int SEL_NV = SEL_STRIP / 256;   // 16-byte loads per lane
 template <int KSEL>
 __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const float* __restrict__ scores, long lds_, int n,
                                                                         int Q, uint64_t* __restrict__ part,
@@ -419,16 +421,16 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
     const int c0 = w * SEL_STRIP;
     const float* row = scores + (long)q * lds_ + c0;
     const int left = n - c0;                                   // columns of this strip (may be <= 0 or > SEL_STRIP)
-    f32x4 v[32];
+    f32x4 v[SEL_NV];
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
+    for (int i = 0; i < SEL_NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         // n and the row stride are multiples of 4 (checked by the launcher): a 16-byte chunk is all in or all out
         v[i] = c < left ? *(const f32x4*)(row + c) : (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     }
 #pragma unroll
-    for (int i = 0; i < 32; ++i) mx = fmaxf(fmaxf(mx, fmaxf(v[i][0], v[i][1])), fmaxf(v[i][2], v[i][3]));
+    for (int i = 0; i < SEL_NV; ++i) mx = fmaxf(fmaxf(mx, fmaxf(v[i][0], v[i][1])), fmaxf(v[i][2], v[i][3]));
     // T = KSEL-th largest of the 64 lane maxima (order-preserving u32; NaN scores cannot occur: unit rows)
     uint32_t o = f32_orderable(mx);
 #pragma unroll
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
     // chunked walk below.
     int mine = 0;
 #pragma unroll
-    for (int i = 0; i < 32; ++i)
+    for (int i = 0; i < SEL_NV; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) mine += (v[i][e] >= tau && v[i][e] > -INFINITY) ? 1 : 0;
     int incl = mine;
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
     if (total <= 64) {
         int pos = incl - mine;
 #pragma unroll
-        for (int i = 0; i < 32; ++i)
+        for (int i = 0; i < SEL_NV; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float sv = v[i][e];
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
         cnt = total;
     } else {
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
+    for (int i = 0; i < SEL_NV; ++i) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float sv = v[i][e];
