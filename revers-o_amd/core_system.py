@@ -21,6 +21,7 @@ import os
 import shutil
 import threading
 import time
+import random
 import uuid
 from concurrent.futures import ThreadPoolExecutor
 
@@ -37,6 +38,14 @@ from .weights import load_state_dict, synth_weights
 DB_ROOT = "./simple_reverso_db"
 IMAGE_EXTENSIONS = ['.jpg', '.jpeg', '.png', '.bmp', '.tiff', '.webp']
 
+
+
+_uuid_rng = random.Random()   # ids only have to be unique (uuid4 format as upstream), not unpredictable
+
+
+def _uuid4():
+    """uuid.uuid4() without the os.urandom system call (35 us each, three per stored region)"""
+    return str(uuid.UUID(int=_uuid_rng.getrandbits(128), version=4))
 
 class Regions:
     """Minimal stand-in for ``supervision.Detections`` (xyxy, mask, confidence, class_id)."""
@@ -202,7 +211,7 @@ class SimpleReverso:
             cid = int(regions.class_id[i]) if i < len(regions.class_id) else -1
             mask = regions.mask[i] if getattr(regions, "mask", None) is not None and i < len(regions.mask) else None
             if mask is None:
-                metas.append({"region_id": str(uuid.uuid4()), "bbox": [0, 0, pil.width, pil.height], "area_ratio": 1.0,
+                metas.append({"region_id": _uuid4(), "bbox": [0, 0, pil.width, pil.height], "area_ratio": 1.0,
                               "detection_index": i, "confidence": conf,
                               "detected_class": names[cid] if 0 <= cid < len(names) else "unknown",
                               "mask_status": "missing_or_unavailable"})
@@ -214,7 +223,7 @@ class SimpleReverso:
                 print(f"⚠️ Empty mask for region {i}, skipping")
                 continue
             ys, xs = np.where(m)
-            metas.append({"region_id": str(uuid.uuid4()),
+            metas.append({"region_id": _uuid4(),
                           "bbox": [int(xs.min()), int(ys.min()), int(xs.max()), int(ys.max())],
                           "area_ratio": float(m.sum() / m.size), "detection_index": i, "confidence": conf,
                           "detected_class": names[cid] if 0 <= cid < len(names) else "object",
@@ -237,11 +246,12 @@ class SimpleReverso:
             emb = self.pe_model.embed(u8.to(self.device, non_blocking=True))
         return emb.cpu()
 
-    def _embed_regions_batch(self, items):
+    def _embed_regions_batch(self, items, to_host=True):
         """items: [(pil, metas)].  One vector per region of every image: the frames go to the device once,
         every region's bbox is cropped + squash-resized there in one launch (bit-identical to PIL
         crop().resize()), then forwards of max_batch crops.  Mask-derived boxes are inclusive
-        (core_system.py:411).  Returns fp32 CPU tensor [n_regions, D] in item order."""
+        (core_system.py:411).  Returns fp32 [n_regions, D] in item order: a CPU tensor, or with
+        to_host=False the device tensor (the launches are asynchronous)."""
         frames, boxes = [], []
         for pil, metas in items:
             if not metas:
@@ -254,11 +264,11 @@ class SimpleReverso:
                     x1, y1 = x1 + 1, y1 + 1
                 boxes.append((fi,) + pp.clamp_box((x0, y0, x1, y1), pil.width, pil.height))
         if not boxes:
-            return torch.empty((0, self.pe_model.cfg.out_dim))
+            return torch.empty((0, self.pe_model.cfg.out_dim), device=None if to_host else self.device)
         with self._lock:
             u8 = pp.crop_resize_device(frames, boxes, self.pe_model.cfg.image_size)
             emb = self.pe_model.embed(u8)
-        return emb.cpu()
+        return emb.cpu() if to_host else emb
 
     def _embed_regions(self, pil, metas):
         """One vector per region of one image (see _embed_regions_batch)."""
@@ -289,7 +299,7 @@ class SimpleReverso:
         if e.dim() != 1:
             raise ValueError(f"Unexpected feature shape: {tuple(e.shape)}")
         self.region_embeddings = [e]
-        meta = {"region_id": str(uuid.uuid4()), "bbox": [0, 0, pil.width, pil.height], "area_ratio": 1.0,
+        meta = {"region_id": _uuid4(), "bbox": [0, 0, pil.width, pil.height], "area_ratio": 1.0,
                 "detection_index": 0, "confidence": 1.0, "detected_class": "full_image"}
         return [e.clone()], [meta]
 
@@ -383,64 +393,71 @@ class SimpleReverso:
         host_resize = not self.device_resize and not (self.region_mode == "crop" and not use_direct_pe)
         model_size = self.pe_model.cfg.image_size
 
-        def open_rgb(path):
-            """pool task: decode (and, on the host-resize path, squash-resize) one file"""
+        def open_rgb(path, slot=None):
+            """pool task: decode (and, on the host-resize path, squash-resize) one file; with `slot` (a row of the
+            pinned staging batch) the resized image is written there instead of being returned"""
             try:
                 im = Image.open(path).convert("RGB")
-                return im, (pp.resize_u8(im, model_size) if host_resize else None)
+                if not host_resize:
+                    return im, None
+                u8 = pp.resize_u8(im, model_size)
+                if slot is None:
+                    return im, u8
+                slot.copy_(u8)
+                return im, True
             except Exception as e:           # per-image failure: logged and skipped (core_system.py:585-591)
                 return e, None
 
         B = self.max_batch
 
         def submit(s0):
+            if stage is not None:            # batch s0 // B fills staging buffer (s0 // B) & 1, one row per file
+                buf = stage[(s0 // B) & 1]
+                return [self._decode_pool.submit(open_rgb, p, buf[j]) for j, p in enumerate(image_files[s0:s0 + B])]
             return [self._decode_pool.submit(open_rgb, p) for p in image_files[s0:s0 + B]]
 
-        # the next batch is decoded by the pool while the device embeds the current one
-        pending = submit(0)
+        # Three things overlap: the pool decodes batch i+1, the device embeds batch i (its vectors come back through a
+        # pinned buffer behind an event), and this thread does the per-image bookkeeping of batch i-1.
         last_ckpt = time.monotonic()
-        for s in range(0, len(image_files), B):
-            if self._stop_requested:
-                log_status("🛑 Stop requested. Saving progress...")
-                checkpoint()
-                return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
-            paths = image_files[s:s + B]
-            futures, pending = pending, (submit(s + B) if s + B < len(image_files) else [])
-            results = [f.result() for f in futures]
-            pils = [r[0] for r in results]
-            crop_mode = self.region_mode == "crop" and not use_direct_pe
-            good = [r for r in results if not isinstance(r[0], Exception)]
-            # global vectors of the whole batch in one forward (not needed when every region is cropped)
-            embs = None
-            if good and not crop_mode:
-                if host_resize:
-                    with self._lock:
-                        embs = self.pe_model.embed(torch.stack([u8 for _, u8 in good]).to(self.device, non_blocking=True)).cpu()
-                else:
-                    embs = self._embed_pils([im for im, _ in good])
+        crop_mode = self.region_mode == "crop" and not use_direct_pe
+        pipelined = host_resize and not crop_mode
+        stage = host_out = None
+        if not crop_mode:
+            host_out = [torch.empty((B, self.pe_model.cfg.out_dim), dtype=torch.float32).pin_memory() for _ in range(2)]
+        if pipelined:
+            stage = [torch.zeros((B, 3, model_size, model_size), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        pending = submit(0)
+
+        def finalize(item):
+            """bookkeeping of one embedded batch: metadata, region embeddings in crop mode, partial lists, checkpoint"""
+            nonlocal failed
+            s, paths, pils, embs, event, by_file, last = item
+            if event is not None:
+                event.synchronize()
             gi = 0
-            batch_items = []                       # (path, filename, pil, metas, global vector or None)
+            batch_items = []                       # (path, pil, metas, global vector or None)
             for j, (path, im) in enumerate(zip(paths, pils)):
                 i = s + j
                 filename = os.path.basename(path)
                 log_status(f"🔄 Processing {i + 1}/{len(image_files)}: {filename}", 0.1 + 0.7 * (i / len(image_files)))
-                processed_files.add(path)
                 if isinstance(im, Exception):
                     log_status(f"❌ Error processing {filename}: {str(im)}")
+                    processed_files.add(path)
                     failed += 1
                     continue
                 e = None
                 if embs is not None:
-                    e = embs[gi]
+                    e = embs[j] if by_file else embs[gi]      # staged batches have one row per file, the others one per decoded file
                     gi += 1
                 if use_direct_pe:
-                    metas = [{"region_id": str(uuid.uuid4()), "bbox": [0, 0, im.width, im.height], "area_ratio": 1.0,
+                    metas = [{"region_id": _uuid4(), "bbox": [0, 0, im.width, im.height], "area_ratio": 1.0,
                               "detection_index": 0, "confidence": 1.0, "detected_class": "full_image"}]
                     log_status(f"✅ Extracted global embedding for {filename}")
                 else:
                     n_reg = self.detect_regions(im, text_prompt)
                     if n_reg == 0:
                         log_status(f"⚠️ No regions found in {filename}, skipping")
+                        processed_files.add(path)
                         failed += 1
                         continue
                     _, metas = self._region_metadata(im, self.detected_regions)
@@ -448,26 +465,109 @@ class SimpleReverso:
                 for m in metas:
                     m["image_source"] = path
                     m["filename"] = filename
-                    m["original_region_id"] = m.get("region_id", str(uuid.uuid4()))
-                    m["region_id"] = str(uuid.uuid4())
+                    m["original_region_id"] = m.get("region_id", _uuid4())
+                    m["region_id"] = _uuid4()
                 batch_items.append((path, im, metas, e))
-            # region crops of the whole batch: frames go to the device once, one crop + resize launch,
-            # forwards of max_batch crops
-            region_vecs = self._embed_regions_batch([(im, metas) for _, im, metas, _ in batch_items]) if crop_mode else None
+            if crop_mode:
+                # region crops of the whole batch: frames go to the device once, one crop + resize launch, forwards of
+                # max_batch crops -- all asynchronous; the vectors are stored when the NEXT batch has been launched
+                flush_regions()
+                with torch.cuda.device(self.device):
+                    dev = self._embed_regions_batch([(im, metas) for _, im, metas, _ in batch_items], to_host=False)
+                    n = dev.shape[0]
+                    slot = region_host[0] & 1
+                    if region_bufs[slot] is None or region_bufs[slot].shape[0] < n:
+                        region_bufs[slot] = torch.empty((max(n, 256), dev.shape[1]), dtype=torch.float32).pin_memory()
+                    host = region_bufs[slot][:n]
+                    host.copy_(dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                region_host[0] += 1
+                region_pending.append((batch_items, host, ev, last))
+                if last:
+                    flush_regions()
+                return
+            store(batch_items, None, last)
+
+        def store(batch_items, region_vecs, last):
+            """the embedded batch enters the partial lists (and only now counts as processed: a checkpoint never names a
+            file whose vectors it does not hold)"""
+            nonlocal processed, last_ckpt
             ri = 0
             for path, im, metas, e in batch_items:
-                if crop_mode:
+                if region_vecs is not None:
                     self._partial_embeddings.extend(region_vecs[ri + t].clone() for t in range(len(metas)))
                     ri += len(metas)
                 else:
                     self._partial_embeddings.extend(e.clone() for _ in metas)
                 self._partial_metadata.extend(metas)
+                processed_files.add(path)
                 processed += 1
                 self._last_processed_file = path
             # checkpoints rewrite everything collected so far: at most one per interval, and one at the end
-            if time.monotonic() - last_ckpt >= self.checkpoint_interval_s or s + B >= len(image_files):
+            if time.monotonic() - last_ckpt >= self.checkpoint_interval_s or last:
                 checkpoint()
                 last_ckpt = time.monotonic()
+
+        region_pending, region_bufs, region_host = [], [None, None], [0]
+
+        def flush_regions():
+            while region_pending:
+                batch_items, host, ev, last = region_pending.pop(0)
+                ev.synchronize()
+                store(batch_items, host, last)
+
+        inflight = None
+        h2d_done = [None, None]
+        for it, s in enumerate(range(0, len(image_files), B)):
+            if self._stop_requested:
+                if inflight is not None:
+                    finalize(inflight)
+                    inflight = None
+                flush_regions()
+                log_status("🛑 Stop requested. Saving progress...")
+                checkpoint()
+                return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
+            paths = image_files[s:s + B]
+            if h2d_done[(it + 1) & 1] is not None:
+                h2d_done[(it + 1) & 1].synchronize()      # the staging buffer the next batch's decode fills has left the host
+            futures, pending = pending, (submit(s + B) if s + B < len(image_files) else [])
+            results = [f.result() for f in futures]
+            pils = [r[0] for r in results]
+            good = [r for r in results if not isinstance(r[0], Exception)]
+            # global vectors of the whole batch in one forward (not needed when every region is cropped)
+            embs = event = None
+            if good and not crop_mode:
+                if pipelined:
+                    # every file of the batch has its row in the staging buffer (a failed file's row keeps whatever it
+                    # held: embedded and never looked at)
+                    buf = stage[it & 1][:len(paths)]
+                    with self._lock, torch.cuda.device(self.device):
+                        dev_in = buf.to(self.device, non_blocking=True)
+                        h2d_done[it & 1] = torch.cuda.Event()
+                        h2d_done[it & 1].record()
+                        dev_emb = self.pe_model.embed(dev_in)
+                        embs = host_out[it & 1][:len(paths)]
+                        embs.copy_(dev_emb, non_blocking=True)
+                        event = torch.cuda.Event()
+                        event.record()
+                else:
+                    # device resize: the decoded frames go up as they are, one crop + resize launch, one forward
+                    with self._lock, torch.cuda.device(self.device):
+                        frames = [torch.from_numpy(np.array(pp.to_pil(im), dtype=np.uint8)).to(self.device, non_blocking=True)
+                                  for im, _ in good]
+                        dev_emb = self.pe_model.embed(pp.crop_resize_device(frames, None, model_size))
+                        embs = host_out[it & 1][:len(good)]
+                        embs.copy_(dev_emb, non_blocking=True)
+                        event = torch.cuda.Event()
+                        event.record()
+            cur = (s, paths, pils, embs, event, pipelined, s + B >= len(image_files))
+            if inflight is not None:
+                finalize(inflight)
+            inflight = cur
+        if inflight is not None:
+            finalize(inflight)
+        flush_regions()
 
         if not self._partial_embeddings:
             return str(log_status("❌ No embeddings extracted from any images"))
