@@ -178,6 +178,34 @@ def test_region_crop_mode_embeds_each_box(tmp_path, dev):
     assert items[0]["bbox"] == metas[0]["bbox"]
 
 
+def test_pipelined_ingest_equals_one_batch(tmp_path, dev):
+    """create_database overlaps decode, embed and bookkeeping across three batches (staging and result buffers used
+    alternately, region vectors stored one batch late).  Many small batches must store exactly what one big batch
+    stores, in the same order, in every mode -- a broken file in the middle included."""
+    from reverso_amd.core_system import Regions
+    folder = str(tmp_path / "images")
+    _make_jpegs(folder, n=21, seed=9)
+    (tmp_path / "images" / "img_010a_broken.jpg").write_bytes(b"not a jpeg")
+
+    def detector(pil, prompt):
+        w, h = pil.size
+        return Regions([[0, 0, w // 2, h // 2], [w // 4, h // 4, w - 1, h - 1], [w // 3, 0, w - 1, h // 2]],
+                       confidence=[0.9, 0.8, 0.7], class_id=[0, 1, 0], class_names=["person", "car"])
+
+    for kw, direct in (({}, True), ({"device_resize": True}, True), ({"detector": detector, "region_mode": "crop"}, False),
+                       ({"detector": detector}, False)):
+        got = []
+        for mb in (4, 64):
+            r = SimpleReverso(model_name="PE-Tiny-T14-56", db_root=str(tmp_path / f"db{len(got)}_{mb}_{len(kw)}_{direct}"),
+                              max_batch=mb, **kw)
+            msg = r.create_database(folder, "p", use_direct_pe=direct)
+            assert "✅" in msg and "❌ Error processing img_010a_broken.jpg" in msg
+            got.append((r.vector_db.gallery.read().cpu(), [(p["filename"], p["bbox"]) for p in r.vector_db.payloads]))
+        assert got[0][1] == got[1][1]
+        assert len(got[0][1]) == (21 if direct else 63)
+        assert torch.equal(got[0][0], got[1][0])
+
+
 def test_device_resize_ingest_equals_host_resize(system):
     """device_resize=True builds the same gallery, bit for bit."""
     r, folder, paths, root = system
