@@ -131,6 +131,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if args.one_gpu:
         local_rank = 0
+    ndev = torch.cuda.device_count()
+    if ndev > 0 and local_rank >= ndev:
+        local_rank %= ndev              # a launcher that narrows each rank's visible devices (one device per process)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
