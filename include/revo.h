@@ -91,7 +91,17 @@ int32_t revo_gallery_read(revo_gallery* g, int64_t start, int64_t n, float* dst,
  * queries: [n_queries, dim] fp32 on the device (normalised internally, cosine semantics).
  * Results, best first under (score desc, index asc): scores [n_queries, k] fp32, indices
  * [n_queries, k] int64 (row index + index_offset), counts [n_queries] int32; entries past
- * counts[q] are -inf / -1.  has_threshold != 0 keeps only score >= threshold. */
+ * counts[q] are -inf / -1.  has_threshold != 0 keeps only score >= threshold.
+ *
+ * EXACTNESS.  The reference's search is an exhaustive one (qdrant local mode: scores = G @ q over every row, then the
+ * ranking).  This search returns exactly what an exhaustive scoring of the gallery's fp32 rows would -- the same rows
+ * in the same order, every score an fp32 dot product in one fixed summation order -- although its scan selects on bf16
+ * scores: each query carries a certificate (the k-th re-scored score must exceed the best bf16 score of any row that
+ * was not re-scored by more than a rigorous bound of |bf16 score - fp32 score|, computed from the rounding norms of
+ * the query and of the gallery's rows), and a query that fails it is re-done by a collecting pass over the gallery
+ * (every row within that bound of what is needed, re-scored in fp32) and, if that list overflows, by a brute-force
+ * fp32 pass.  All of it is enqueued on `stream`; revo_search_stats reports how often it happened.  (A gallery created
+ * with keep_f32 = 0 has no fp32 rows: it returns the scan's own scores and certifies nothing.) */
 int32_t revo_search_topk(revo_gallery* g, const float* queries, int32_t n_queries, int32_t k, int32_t has_threshold,
                          float threshold, int64_t index_offset, float* scores, int64_t* indices, int32_t* counts,
                          void* stream);
@@ -115,18 +125,43 @@ int32_t revo_search_candidates(revo_gallery* g, const float* queries, int32_t n_
                                uint32_t* bounds, void* stream);
 int32_t revo_search_finish(revo_gallery* g, int32_t n_queries, int32_t k, int32_t has_threshold, float threshold,
                            int64_t index_offset, const uint32_t* all_bounds, int32_t parts, int32_t top_m, float* scores,
-                           int64_t* indices, int32_t* counts, void* stream);
+                           int64_t* indices, int32_t* counts, float* cert, void* stream);
+/* cert (optional, [n_queries] fp32): this shard's share of the exactness certificate -- the best fp32 score any of its
+ * rows that was NOT re-scored can have (scan score of the best such row + the error bound; -inf if every row was
+ * re-scored).  All-gathered with the results (it is the third block of the packed layout below) and checked by
+ * revo_topk_merge_packed against the merged k-th score.
+ *   5. revo_search_exact: second round for the queries that check failed for (none on ordinary data): entry j is query
+ *      q_idx[j] of the last revo_search_candidates call, need[j] the fp32 score a row must reach to change its merged
+ *      result (both device arrays, identical on every rank: the merge step's unc_q / unc_need, sorted by query).  The
+ *      shard collects every row whose scan score is within the error bound of need[j], re-scores it in fp32 and returns
+ *      its exact local top-k in row j of scores / indices / counts ([n, k], [n, k], [n]); all-gathered and merged like
+ *      step 4, these replace the queries' first-round results. */
+int32_t revo_search_exact(revo_gallery* g, int32_t n, const int32_t* q_idx, const float* need, int32_t k,
+                          int32_t has_threshold, float threshold, int64_t index_offset, float* scores, int64_t* indices,
+                          int32_t* counts, void* stream);
+/* how the certificate treats the handle's searches: 0 = certificate + fallback (default), 1 = every query takes the
+ * collecting pass, 2 = every query takes the brute-force pass (1 and 2: parity tests of the fallback against the fast
+ * path), 3 = certificate evaluated and counted but no fallback (what the search did before it had one; timing only) */
+int32_t revo_search_set_mode(revo_gallery* g, int32_t mode);
+/* counters of the handle's last search, read after `stream` has drained (host array): out4 = { queries the certificate
+ * failed for (-1: the gallery has no fp32 rows), of those: brute-forced, queries the certificate was evaluated for,
+ * rows the collecting passes re-scored } */
+int32_t revo_search_stats(revo_gallery* g, int32_t* out4, void* stream);
 /* merge `parts` result sets laid out [parts, n_queries, k] (the all-gathered per-shard
  * results of a row-sharded gallery) into one [n_queries, k] set, same ordering rule. */
 int32_t revo_topk_merge(const float* scores, const int64_t* indices, int32_t parts, int32_t n_queries, int32_t k,
                         int32_t has_threshold, float threshold, float* out_scores, int64_t* out_indices,
                         int32_t* out_counts, void* stream);
 
-/* One result set packed for a single all-gather: [n_queries, k] int64 indices followed by [n_queries, k] fp32 scores,
- * padded to revo_topk_packed_bytes(n_queries, k) bytes; `packed` holds `parts` such blocks back to back. */
+/* One result set packed for a single all-gather: [n_queries, k] int64 indices, [n_queries, k] fp32 scores, then
+ * [n_queries] fp32 certificate bounds (revo_search_finish's cert), padded to revo_topk_packed_bytes(n_queries, k) bytes;
+ * `packed` holds `parts` such blocks back to back.  unc_count / unc_q / unc_need (optional, device: [1], [n_queries],
+ * [n_queries]): the merge checks every query's certificate over all shards and lists the queries that fail it (in no
+ * particular order) with the score a row needs to enter their result -- the input of revo_search_exact. */
 int64_t revo_topk_packed_bytes(int32_t n_queries, int32_t k);
 int32_t revo_topk_merge_packed(const void* packed, int32_t parts, int32_t n_queries, int32_t k, int32_t has_threshold,
-                               float threshold, float* out_scores, int64_t* out_indices, int32_t* out_counts, void* stream);
+                               float threshold, float* out_scores, int64_t* out_indices, int32_t* out_counts,
+                               int32_t* unc_count, int32_t* unc_q, float* unc_need, void* stream);
 
 /* ---- single kernels, exposed for parity tests and micro-benchmarks (device pointers) */
 int32_t revo_op_gemm(int32_t epilogue, const void* a_bf16, int64_t lda, const void* b_bf16, int64_t ldb, int32_t m,

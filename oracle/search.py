@@ -143,17 +143,35 @@ def f32_orderable(x):
 
 
 def packed_bytes(n_queries, k):
-    return (n_queries * k * 12 + 15) // 16 * 16
+    return (n_queries * k * 12 + n_queries * 4 + 15) // 16 * 16
 
 
 class OracleShardBackend:
-    """The backend interface of revers-o_amd/sharded.py on numpy (rows already normalised)."""
+    """The backend interface of revers-o_amd/sharded.py on numpy (rows already normalised).
 
-    def __init__(self, shard_rows):
+    ``scan_noise`` > 0 imitates the HIP path's bf16 scan: candidates are selected on scores perturbed by a
+    deterministic pseudo-noise of at most that size (a function of query and global row only), results are re-scored
+    exactly, and every shard publishes its certificate bound (best noisy score of a row it did not re-score +
+    ``scan_noise``), so that the protocol's certificate check and second, exact round run on CPU too."""
+
+    def __init__(self, shard_rows, scan_noise=0.0, row_offset=0):
         import torch
         self._torch = torch
         self.shard = np.asarray(shard_rows, dtype=np.float32)
+        self.scan_noise = float(scan_noise)
+        self.row_offset = int(row_offset)
         self._cand = None
+        self.exact_calls = 0
+
+    def _noisy(self, q):
+        """[Q, n] scan scores: exact scores + bounded deterministic noise."""
+        sc = cosine_scores(self.shard, q)
+        if self.scan_noise > 0.0:
+            rows = (np.arange(self.shard.shape[0], dtype=np.int64) + self.row_offset)[None, :]
+            qi = np.arange(q.shape[0], dtype=np.int64)[:, None]
+            h = ((rows * 2654435761 + qi * 40503 + 12345) % 1000003).astype(np.float64) / 1000003.0
+            sc = (sc.astype(np.float64) + (2.0 * h - 1.0) * self.scan_noise).astype(np.float32)
+        return sc
 
     def ksel(self, k):
         return 32 if k <= 16 else 64
@@ -169,7 +187,18 @@ class OracleShardBackend:
     def candidates(self, queries, k, top_m):
         q = np.asarray(queries, dtype=np.float32)
         ksel = self.ksel(k)
-        s, i, c = search(self.shard, q, ksel, None, normalize=False)
+        if self.scan_noise > 0.0:
+            noisy = self._noisy(q)
+            Q, n = noisy.shape
+            kk = min(ksel, n)
+            s = np.full((Q, ksel), -np.inf, dtype=np.float32)
+            i = np.full((Q, ksel), -1, dtype=np.int64)
+            c = np.full((Q,), kk, dtype=np.int32)
+            for r in range(Q):
+                o = np.lexsort((np.arange(n), -noisy[r].astype(np.float64)))[:kk]
+                s[r, :kk], i[r, :kk] = noisy[r][o], o
+        else:
+            s, i, c = search(self.shard, q, ksel, None, normalize=False)
         self._cand = (q, s, i, c)
         pub = np.zeros((q.shape[0], top_m), dtype=np.uint32)
         for r in range(q.shape[0]):
@@ -183,20 +212,46 @@ class OracleShardBackend:
         out = np.zeros((packed_bytes(n_queries, k),), dtype=np.uint8)
         idx = np.full((n_queries, k), -1, dtype=np.int64)
         sc = np.full((n_queries, k), -np.inf, dtype=np.float32)
+        cert = np.full((n_queries,), -np.inf, dtype=np.float32)
         for r in range(n_queries):
             bound = np.uint32(0)
             if all_bounds is not None:
                 pub = np.sort(all_bounds[:, r, :].numpy().view(np.uint32).reshape(-1))[::-1]
                 if pub.shape[0] >= ksel:
                     bound = pub[ksel - 1]
-            keep = [j for j in range(int(c[r])) if f32_orderable(s[r, j]) >= bound][:k]
-            idx[r, :len(keep)] = i[r, keep] + index_offset
-            sc[r, :len(keep)] = s[r, keep]
-        out[: n_queries * k * 8] = idx.view(np.uint8).reshape(-1)
-        out[n_queries * k * 8: n_queries * k * 12] = sc.view(np.uint8).reshape(-1)
+            nc = int(c[r])
+            keep = [j for j in range(nc) if f32_orderable(s[r, j]) >= bound]
+            # certificate bound: the first candidate the shard bound dropped, else the worst kept one of a full list
+            if len(keep) < nc:
+                cert[r] = s[r, len(keep)] + np.float32(self.scan_noise)
+            elif nc == ksel and self.shard.shape[0] > ksel:
+                cert[r] = s[r, ksel - 1] + np.float32(self.scan_noise)
+            rows = i[r, keep]
+            exact = cosine_scores(self.shard[rows], q[r:r + 1])[0] if len(keep) else np.zeros((0,), np.float32)
+            o = np.lexsort((rows, -exact.astype(np.float64)))[:k]
+            idx[r, :len(o)] = rows[o] + index_offset
+            sc[r, :len(o)] = exact[o]
+        self._pack(out, n_queries, k, idx, sc, cert)
         return self._torch.from_numpy(out)
 
-    def merge(self, packed_all, parts, n_queries, k, threshold):
+    @staticmethod
+    def _pack(out, n, k, idx, sc, cert):
+        out[: n * k * 8] = idx.view(np.uint8).reshape(-1)
+        out[n * k * 8: n * k * 12] = sc.view(np.uint8).reshape(-1)
+        out[n * k * 12: n * k * 12 + n * 4] = cert.view(np.uint8).reshape(-1)
+
+    def exact(self, q_idx, need, k, index_offset):
+        """Second round: the exact local top-k of the listed queries (brute force on this shard)."""
+        self.exact_calls += 1
+        q = self._cand[0][np.asarray(q_idx, dtype=np.int64)]
+        n = q.shape[0]
+        s, i, c = search(self.shard, q, k, None, normalize=False)
+        i = np.where(i >= 0, i + index_offset, i)
+        out = np.zeros((packed_bytes(n, k),), dtype=np.uint8)
+        self._pack(out, n, k, i.astype(np.int64), s, np.full((n,), -np.inf, dtype=np.float32))
+        return self._torch.from_numpy(out)
+
+    def merge(self, packed_all, parts, n_queries, k, threshold, certify=False):
         pb = packed_bytes(n_queries, k)
         buf = packed_all.numpy().reshape(parts, pb)
         pi = np.stack([buf[p, : n_queries * k * 8].copy().view(np.int64).reshape(n_queries, k) for p in range(parts)])
@@ -204,4 +259,17 @@ class OracleShardBackend:
                        for p in range(parts)])
         s, i, c = merge_topk(ps, pi, k, threshold)
         t = self._torch
-        return t.from_numpy(s), t.from_numpy(i), t.from_numpy(c)
+        if not certify:
+            return t.from_numpy(s), t.from_numpy(i), t.from_numpy(c)
+        cert = np.stack([buf[p, n_queries * k * 12: n_queries * k * 12 + n_queries * 4].copy().view(np.float32)
+                         for p in range(parts)]).max(0)
+        full = merge_topk(ps, pi, k, None)                       # the k-th merged score before the threshold cut
+        sk = np.where(full[2] >= k, full[0][:, k - 1], -np.inf).astype(np.float32)
+        need = np.maximum(sk, np.float32(threshold)) if threshold is not None else sk
+        unc = np.nonzero(~((cert == -np.inf) | (need > cert)))[0].astype(np.int32)
+        uq = np.zeros((max(n_queries, 1),), dtype=np.int32)
+        un = np.zeros((max(n_queries, 1),), dtype=np.float32)
+        uq[: unc.shape[0]] = unc[::-1]                           # "in no particular order": the caller must sort
+        un[: unc.shape[0]] = need[unc[::-1]]
+        return (t.from_numpy(s), t.from_numpy(i), t.from_numpy(c),
+                (t.tensor([unc.shape[0]], dtype=t.int32), t.from_numpy(uq), t.from_numpy(un)))

@@ -54,10 +54,13 @@ SIGNATURES = {
     "revo_search_ksel": (_i32, [_i32]),
     "revo_search_plan": (_i32, [_p, _i32, _i32, C.POINTER(C.c_int64)]),
     "revo_search_candidates": (_i32, [_p, _p, _i32, _i32, _i32, _p, _p]),
-    "revo_search_finish": (_i32, [_p, _i32, _i32, _i32, _f32, _i64, _p, _i32, _i32, _p, _p, _p, _p]),
+    "revo_search_finish": (_i32, [_p, _i32, _i32, _i32, _f32, _i64, _p, _i32, _i32, _p, _p, _p, _p, _p]),
+    "revo_search_exact": (_i32, [_p, _i32, _p, _p, _i32, _i32, _f32, _i64, _p, _p, _p, _p]),
+    "revo_search_set_mode": (_i32, [_p, _i32]),
+    "revo_search_stats": (_i32, [_p, C.POINTER(C.c_int32), _p]),
     "revo_topk_merge": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p]),
     "revo_topk_packed_bytes": (_i64, [_i32, _i32]),
-    "revo_topk_merge_packed": (_i32, [_p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p]),
+    "revo_topk_merge_packed": (_i32, [_p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p, _p, _p, _p]),
     "revo_op_gemm": (_i32, [_i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p]),
     "revo_op_gemm_rope": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
     "revo_op_set_gemm_tile": (_i32, [_i32]),

@@ -581,10 +581,21 @@ struct revo_gallery {
     float* stage = nullptr; size_t stage_cap = 0;
     // candidates of the last scan (inside `part`), consumed by the finish step
     const uint64_t* cand = nullptr; long cand_stride = 0; int cand_Q = 0, cand_ksel = 0;
+    // exactness certificate (kernels.h): per-query rounding norms of the last search's queries, running maxima over the
+    // gallery's rows, the fallback workspace (sized with q_cap) and the handle's mode
+    float* qstat = nullptr; uint32_t* gstat = nullptr;
+    char* xbuf = nullptr; revo::ExactWs xw{};
+    int mode = 0;
     ~revo_gallery() {
         (void)hipFree(gb); (void)hipFree(gf); (void)hipFree(qf); (void)hipFree(qb); (void)hipFree(part);
         (void)hipFree(tau0);
         (void)hipFree(stage);
+        (void)hipFree(qstat); (void)hipFree(gstat); (void)hipFree(xbuf);
+    }
+    revo::CertArgs cert_args(float* cert_out) const {
+        revo::CertArgs c{};
+        c.qstat = qstat; c.gstat = gstat; c.mode = mode; c.ws = xw; c.Qb = qb; c.ldq = D; c.cert_out = cert_out;
+        return c;
     }
 };
 
@@ -599,6 +610,8 @@ extern "C" int32_t revo_gallery_create(int32_t dim, int64_t capacity, int32_t de
     g->D = dim; g->device = device; g->capacity = capacity; g->keep_f32 = keep_f32 != 0;
     REVO_HIP_CHECK(hipMalloc((void**)&g->gb, (size_t)capacity * dim * 2));
     if (g->keep_f32) REVO_HIP_CHECK(hipMalloc((void**)&g->gf, (size_t)capacity * dim * 4));
+    REVO_HIP_CHECK(hipMalloc((void**)&g->gstat, 8));
+    REVO_HIP_CHECK(hipMemset(g->gstat, 0, 8));
     *out = g.release();
     return 0;
     API_END
@@ -612,6 +625,8 @@ extern "C" int32_t revo_gallery_destroy(revo_gallery* g) {
 extern "C" int64_t revo_gallery_size(const revo_gallery* g) { return g ? g->size : -1; }
 extern "C" int32_t revo_gallery_clear(revo_gallery* g) {
     REVO_REQUIRE(g, "null handle");
+    REVO_ON_DEVICE(g->device);
+    REVO_HIP_CHECK(hipMemset(g->gstat, 0, 8));        // the row maxima of the certificate start over with the rows
     g->size = 0;
     return 0;
 }
@@ -643,12 +658,9 @@ extern "C" int32_t revo_gallery_append(revo_gallery* g, const float* vecs, int64
         bf16_t* db = g->gb + row0 * D;
         float* df = g->keep_f32 ? g->gf + row0 * D : nullptr;
         ProfScope ps("gallery_append", st);
-        if (normalize) {
-            CHECK_RC(revo::launch_l2norm_rows(src, D, df, D, db, D, m, D, st));
-        } else {
-            if (df) REVO_HIP_CHECK(hipMemcpyAsync(df, src, (size_t)m * D * 4, hipMemcpyDeviceToDevice, st));
-            CHECK_RC(revo::launch_f32_to_bf16(src, D, db, D, m, D, st));
-        }
+        // one kernel either way: fp32 master row, bf16 scan row, and the row's share of the certificate's maxima
+        // (max ||g||, max ||bf16(g) - g||; with normalize = 0 the rows are stored as given, whatever their length)
+        CHECK_RC(revo::launch_l2norm_rows(src, D, df, D, db, D, m, D, st, normalize ? 1 : 0, nullptr, g->gstat));
         if (!src_on_device) REVO_HIP_CHECK(hipStreamSynchronize(st));   // staging buffer is reused
     }
     g->size += n;
@@ -695,11 +707,25 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
     const long N = g->size;
     if (g->q_cap < Q) {
         REVO_HIP_CHECK(hipStreamSynchronize(st));
-        (void)hipFree(g->qf); (void)hipFree(g->qb); (void)hipFree(g->tau0);
-        g->qf = nullptr; g->qb = nullptr; g->tau0 = nullptr; g->q_cap = 0;
+        (void)hipFree(g->qf); (void)hipFree(g->qb); (void)hipFree(g->tau0); (void)hipFree(g->qstat); (void)hipFree(g->xbuf);
+        g->qf = nullptr; g->qb = nullptr; g->tau0 = nullptr; g->qstat = nullptr; g->xbuf = nullptr; g->q_cap = 0;
+        g->xw = ExactWs{};
         REVO_HIP_CHECK(hipMalloc((void**)&g->qf, (size_t)Q * D * 4));
         REVO_HIP_CHECK(hipMalloc((void**)&g->qb, (size_t)Q * D * 2));
         REVO_HIP_CHECK(hipMalloc((void**)&g->tau0, (size_t)Q * 4 * 2));   // pre-pass bounds | live bounds
+        REVO_HIP_CHECK(hipMalloc((void**)&g->qstat, (size_t)Q * 8));
+        if (g->keep_f32) {
+            // fallback workspace of the exactness certificate: counters | unc_q | unc_lb | col_cnt | over_j | qb_u | col
+            auto up256 = [](size_t x) { return (x + 255) / 256 * 256; };
+            const size_t o_q = 256, o_lb = o_q + up256((size_t)Q * 4), o_cnt = o_lb + up256((size_t)Q * 4),
+                         o_over = o_cnt + up256((size_t)Q * 4), o_qb = o_over + up256((size_t)Q * 4),
+                         o_col = o_qb + up256((size_t)Q * D * 2), total = o_col + (size_t)Q * EXACT_COL_CAP * 8;
+            REVO_HIP_CHECK(hipMalloc((void**)&g->xbuf, total));
+            REVO_HIP_CHECK(hipMemsetAsync(g->xbuf, 0, 256, st));
+            g->xw.ctr = (int*)g->xbuf; g->xw.unc_q = (int*)(g->xbuf + o_q); g->xw.unc_lb = (float*)(g->xbuf + o_lb);
+            g->xw.col_cnt = (int*)(g->xbuf + o_cnt); g->xw.over_j = (int*)(g->xbuf + o_over);
+            g->xw.qb_u = (bf16_t*)(g->xbuf + o_qb); g->xw.ldqb = D; g->xw.col = (uint64_t*)(g->xbuf + o_col);
+        }
         g->q_cap = Q;
     }
     auto need_part = [&](size_t bytes) -> int {
@@ -713,7 +739,8 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
     };
     g->cand = nullptr; g->cand_Q = 0;
     { ProfScope ps("search_prep", st);
-      CHECK_RC(launch_l2norm_rows(queries, D, g->qf, D, g->qb, D, Q, D, st)); }
+      CHECK_RC(launch_l2norm_rows(queries, D, g->qf, D, g->qb, D, Q, D, st, 1, g->qstat, nullptr));
+      if (g->xbuf) REVO_HIP_CHECK(hipMemsetAsync(g->xw.ctr, 0, 32, st)); }
 
     if (N >= SEARCH_SMALL_ROWS) {
         // ---- 256 x 256 scan.  Pre-pass: a plain GEMM of the queries against the first n_pre rows and a
@@ -787,6 +814,25 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
     return 0;
 }
 
+// The fallback of the exactness certificate for the entries in the handle's workspace (count on the device): collect
+// pass, exact re-score of what it collected, brute force for the entries whose lists overflowed.  Idle passes cost a
+// few microseconds each.
+static int search_fallback(revo_gallery* g, int max_entries, int k, int has_thr, float thr, long index_offset, int out_compact,
+                           float* scores, long long* indices, int* counts, hipStream_t st) {
+    using namespace revo;
+    ProfScope ps("topk_exact", st);
+    if (g->mode != 2) {
+        Collect256Args ca{};
+        ca.Qb = g->xw.qb_u; ca.ldq = g->xw.ldqb; ca.Gb = g->gb; ca.ldg = g->D; ca.N = g->size; ca.D = g->D;
+        ca.n_q = g->xw.ctr; ca.lb = g->xw.unc_lb; ca.cnt = g->xw.col_cnt; ca.col = g->xw.col; ca.cap = EXACT_COL_CAP;
+        CHECK_RC(launch_topk_collect256(ca, max_entries, st));
+    }
+    CHECK_RC(launch_topk_exact_finish(g->xw, max_entries, g->qf, g->D, g->gf, g->D, g->D, k, has_thr, thr, index_offset,
+                                      g->mode == 2, out_compact, scores, indices, counts, st));
+    return launch_topk_exact_bruteforce(g->xw, max_entries, g->qf, g->D, g->gf, g->D, g->size, g->D, k, has_thr, thr,
+                                        index_offset, out_compact, scores, indices, counts, st);
+}
+
 // over-selection: the bf16 scan keeps ksel >= k + margin candidates, the fp32 re-score decides
 static int search_ksel(int k) { return (k <= 16) ? 32 : 64; }
 extern "C" int32_t revo_search_ksel(int32_t k) { return (k >= 1 && k <= 50) ? search_ksel(k) : -1; }
@@ -817,9 +863,14 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
     if (g->size == 0) return launch_topk_fill_empty(scores, (long long*)indices, counts, Q, k, st);
     const int ksel = search_ksel(k);
     CHECK_RC(search_candidates(g, queries, Q, ksel, st));
-    ProfScope ps("topk_finish", st);
-    return launch_topk_finish(g->cand, g->cand_stride, ksel, g->qf, g->D, g->keep_f32 ? g->gf : nullptr, g->D, g->D, Q, k,
-                              has_thr, thr, index_offset, nullptr, 0, 0, scores, (long long*)indices, counts, st);
+    const CertArgs ca = g->cert_args(nullptr);
+    { ProfScope ps("topk_finish", st);
+      CHECK_RC(launch_topk_finish(g->cand, g->cand_stride, ksel, g->qf, g->D, g->keep_f32 ? g->gf : nullptr, g->D, g->D, Q, k,
+                                  has_thr, thr, index_offset, nullptr, 0, 0, scores, (long long*)indices, counts,
+                                  g->keep_f32 ? &ca : nullptr, st)); }
+    if (g->keep_f32 && g->mode != 3)
+        CHECK_RC(search_fallback(g, Q, k, has_thr, thr, index_offset, 0, scores, (long long*)indices, counts, st));
+    return 0;
     API_END
 }
 
@@ -847,7 +898,7 @@ extern "C" int32_t revo_search_candidates(revo_gallery* g, const float* queries,
 }
 extern "C" int32_t revo_search_finish(revo_gallery* g, int32_t Q, int32_t k, int32_t has_thr, float thr,
                                       int64_t index_offset, const uint32_t* all_bounds, int32_t parts, int32_t top_m,
-                                      float* scores, int64_t* indices, int32_t* counts, void* stream) {
+                                      float* scores, int64_t* indices, int32_t* counts, float* cert, void* stream) {
     API_BEGIN
     REVO_REQUIRE(g && scores && indices && counts, "search_finish: null argument");
     REVO_REQUIRE(k >= 1 && k <= 50 && Q >= 0, "search_finish: bad k or query count");
@@ -858,11 +909,55 @@ extern "C" int32_t revo_search_finish(revo_gallery* g, int32_t Q, int32_t k, int
     REVO_ON_DEVICE(g->device);
     hipStream_t st = (hipStream_t)stream;
     using namespace revo;
-    if (g->size == 0 || !g->cand) return launch_topk_fill_empty(scores, (long long*)indices, counts, Q, k, st);
+    if (g->size == 0 || !g->cand) {
+        // an empty shard holds no row that could change a result: its certificate bound is -inf
+        if (cert) REVO_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)cert, (int)0xff800000u, (size_t)Q, st));
+        return launch_topk_fill_empty(scores, (long long*)indices, counts, Q, k, st);
+    }
     ProfScope ps("topk_finish", st);
+    const CertArgs ca = g->cert_args(cert);
     return launch_topk_finish(g->cand, g->cand_stride, g->cand_ksel, g->qf, g->D, g->keep_f32 ? g->gf : nullptr, g->D, g->D,
                               Q, k, has_thr, thr, index_offset, all_bounds, parts, top_m, scores, (long long*)indices,
-                              counts, st);
+                              counts, cert ? &ca : nullptr, st);
+    API_END
+}
+
+// Second round of a row-sharded search: exact local results for the queries the merge step could not certify.
+extern "C" int32_t revo_search_exact(revo_gallery* g, int32_t n, const int32_t* q_idx, const float* need, int32_t k,
+                                     int32_t has_thr, float thr, int64_t index_offset, float* scores, int64_t* indices,
+                                     int32_t* counts, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(g && scores && indices && counts && (n == 0 || (q_idx && need)), "search_exact: null argument");
+    REVO_REQUIRE(k >= 1 && k <= 50 && n >= 0, "search_exact: bad k or entry count");
+    REVO_REQUIRE(n <= g->cand_Q, "search_exact: more entries than queries in the last revo_search_candidates call");
+    if (n == 0) return 0;
+    REVO_ON_DEVICE(g->device);
+    hipStream_t st = (hipStream_t)stream;
+    using namespace revo;
+    if (g->size == 0) return launch_topk_fill_empty(scores, (long long*)indices, counts, n, k, st);
+    REVO_REQUIRE(g->keep_f32 && g->xbuf, "search_exact: the gallery was created without the fp32 master copy");
+    const CertArgs ca = g->cert_args(nullptr);
+    CHECK_RC(launch_topk_exact_prepare(g->xw, q_idx, need, n, ca, g->D, st));
+    return search_fallback(g, n, k, has_thr, thr, index_offset, 1, scores, (long long*)indices, counts, st);
+    API_END
+}
+
+extern "C" int32_t revo_search_set_mode(revo_gallery* g, int32_t mode) {
+    REVO_REQUIRE(g && mode >= 0 && mode <= 3, "search_set_mode: mode must be 0..3");
+    g->mode = mode;
+    return 0;
+}
+extern "C" int32_t revo_search_stats(revo_gallery* g, int32_t* out4, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(g && out4, "search_stats: null argument");
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    if (!g->xbuf) { out4[0] = -1; return 0; }       // no fp32 master rows (or no search yet): nothing was certified
+    REVO_ON_DEVICE(g->device);
+    int c[8];
+    REVO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    REVO_HIP_CHECK(hipMemcpy(c, g->xw.ctr, sizeof(c), hipMemcpyDeviceToHost));
+    out4[0] = c[0] + c[4]; out4[1] = c[1]; out4[2] = c[2]; out4[3] = c[3];
+    return 0;
     API_END
 }
 
@@ -878,19 +973,27 @@ extern "C" int32_t revo_topk_merge(const float* scores, const int64_t* indices, 
 }
 
 extern "C" int64_t revo_topk_packed_bytes(int32_t Q, int32_t k) {
-    return Q < 0 || k < 1 ? -1 : (((int64_t)Q * k * 12 + 15) / 16) * 16;
+    return Q < 0 || k < 1 ? -1 : (((int64_t)Q * k * 12 + (int64_t)Q * 4 + 15) / 16) * 16;
 }
 extern "C" int32_t revo_topk_merge_packed(const void* packed, int32_t parts, int32_t Q, int32_t k, int32_t has_thr, float thr,
-                                          float* out_scores, int64_t* out_indices, int32_t* out_counts, void* stream) {
+                                          float* out_scores, int64_t* out_indices, int32_t* out_counts,
+                                          int32_t* unc_count, int32_t* unc_q, float* unc_need, void* stream) {
     API_BEGIN
     REVO_REQUIRE(packed && out_scores && out_indices && out_counts, "merge: null argument");
     REVO_REQUIRE(Q >= 0 && k >= 1, "merge: bad sizes");
+    REVO_REQUIRE(!unc_count || (unc_q && unc_need), "merge: the certificate needs all three of unc_count, unc_q, unc_need");
     const int64_t pb = revo_topk_packed_bytes(Q, k);
     ProfScope ps("topk_merge", (hipStream_t)stream);
-    // part p: [Q][k] int64 indices, then [Q][k] fp32 scores
+    // part p: [Q][k] int64 indices, then [Q][k] fp32 scores, then [Q] fp32 certificate bounds
+    revo::MergeCert mc{};
+    if (unc_count) {
+        REVO_HIP_CHECK(hipMemsetAsync(unc_count, 0, 4, (hipStream_t)stream));
+        mc.cert = (const float*)((const char*)packed + (size_t)Q * k * 12); mc.cert_part_stride = pb / 4;
+        mc.unc_count = unc_count; mc.unc_q = unc_q; mc.unc_need = unc_need;
+    }
     return revo::launch_topk_merge_strided((const float*)((const char*)packed + (size_t)Q * k * 8), pb / 4,
                                            (const long long*)packed, pb / 8, parts, Q, k, has_thr, thr, out_scores,
-                                           (long long*)out_indices, out_counts, (hipStream_t)stream);
+                                           (long long*)out_indices, out_counts, (hipStream_t)stream, unc_count ? &mc : nullptr);
     API_END
 }
 

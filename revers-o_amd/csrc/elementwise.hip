@@ -328,29 +328,51 @@ int launch_transpose_f32_to_bf16(const float* src, int rows, int cols, bf16_t* d
 // --------------------------------------------------------- L2 normalise ----
 // e / ||e||_2 with no epsilon (core_system.py:447); an all-zero row stays zero
 // (qdrant local mode guards the division the same way).
+// row_stats (optional) [rows][2]: ( ||bf16(y) - y||_2 , ||bf16(y)||_2 ) of every output row y; max_stats (optional) [2]:
+// running maxima, as fp32 bit patterns (non-negative floats order like unsigned integers), of ||y||_2 and of
+// ||bf16(y) - y||_2 over all rows ever passed -- the quantities the search's exactness certificate is built from
+// (rigorous bound of |bf16-scan score - fp32 score|).  normalize == 0 copies the rows unscaled.
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ src, long ld_src,
                                                           float* __restrict__ dst_f32, long ld_f32,
                                                           bf16_t* __restrict__ dst_bf16, long ld_bf16, long rows,
-                                                          int D) {
+                                                          int D, int normalize, float* __restrict__ row_stats,
+                                                          uint32_t* __restrict__ max_stats) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* s = src + row * ld_src;
-    float q = 0.f;
-    for (int c = lane; c < D; c += 64) q = fmaf(s[c], s[c], q);
-    q = wave_sum(q);
-    const float inv = q > 0.f ? 1.0f / sqrtf(q) : 1.0f;
+    float inv = 1.0f;
+    if (normalize) {
+        float q = 0.f;
+        for (int c = lane; c < D; c += 64) q = fmaf(s[c], s[c], q);
+        q = wave_sum(q);
+        inv = q > 0.f ? 1.0f / sqrtf(q) : 1.0f;
+    }
+    float ny = 0.f, nb = 0.f, ne = 0.f;
     for (int c = lane; c < D; c += 64) {
         const float y = s[c] * inv;
+        const bf16_t yb = f32_to_bf16(y);
         if (dst_f32) dst_f32[row * ld_f32 + c] = y;
-        if (dst_bf16) dst_bf16[row * ld_bf16 + c] = f32_to_bf16(y);
+        if (dst_bf16) dst_bf16[row * ld_bf16 + c] = yb;
+        const float fb = bf16_to_f32(yb), d = fb - y;         // the difference of two neighbouring floats is exact
+        ny = fmaf(y, y, ny); nb = fmaf(fb, fb, nb); ne = fmaf(d, d, ne);
+    }
+    if (!row_stats && !max_stats) return;
+    ny = sqrtf(wave_sum(ny)); nb = sqrtf(wave_sum(nb)); ne = sqrtf(wave_sum(ne));
+    if (lane == 0) {
+        if (row_stats) { row_stats[row * 2] = ne; row_stats[row * 2 + 1] = nb; }
+        if (max_stats) {
+            // NaN / inf rows (never produced by the embed path) would poison the maxima: they are left out
+            if (ny == ny && ny < INFINITY) atomicMax(max_stats, __float_as_uint(ny));
+            if (ne == ne && ne < INFINITY) atomicMax(max_stats + 1, __float_as_uint(ne));
+        }
     }
 }
 int launch_l2norm_rows(const float* src, long ld_src, float* dst_f32, long ld_f32, bf16_t* dst_bf16, long ld_bf16,
-                       long rows, int D, hipStream_t st) {
+                       long rows, int D, hipStream_t st, int normalize, float* row_stats, uint32_t* max_stats) {
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, src, ld_src, dst_f32,
-                       ld_f32, dst_bf16, ld_bf16, rows, D);
+                       ld_f32, dst_bf16, ld_bf16, rows, D, normalize, row_stats, max_stats);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

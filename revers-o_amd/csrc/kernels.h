@@ -58,8 +58,12 @@ int launch_rope(bf16_t* qkv, long ld, const float2* cs, int rows, int S, int W, 
 // dst[r][0..cols) = bf16(src[r][0..cols)), dst[r][cols..ld_dst) = 0
 int launch_f32_to_bf16(const float* src, long ld_src, bf16_t* dst, long ld_dst, long rows, int cols, hipStream_t st);
 // row-wise L2 normalise; writes fp32 and/or bf16 copies (either may be null)
+// normalize = 0: rows copied unscaled.  row_stats [rows][2] (optional): (||bf16(y) - y||, ||bf16(y)||) per output row;
+// max_stats [2] (optional): running maxima (fp32 bit patterns) of ||y|| and ||bf16(y) - y||  -- inputs of the search's
+// exactness certificate
 int launch_l2norm_rows(const float* src, long ld_src, float* dst_f32, long ld_f32, bf16_t* dst_bf16, long ld_bf16,
-                       long rows, int D, hipStream_t st);
+                       long rows, int D, hipStream_t st, int normalize = 1, float* row_stats = nullptr,
+                       uint32_t* max_stats = nullptr);
 // dst[n][k] = src[k][n]   (fp32 -> bf16 transposed copy; visual.proj is stored [W][D])
 int launch_transpose_f32_to_bf16(const float* src, int rows, int cols, bf16_t* dst, long ld_dst, hipStream_t st);
 
@@ -90,13 +94,79 @@ int topk_scan_workspace_splits(int Q, long N);
 int launch_topk_scan(const ScanArgs& a, hipStream_t st);
 // merge `splits` sorted candidate lists per query into one list of ksel keys (in place into part[q][0])
 int launch_topk_reduce(uint64_t* part, int Q, int splits, int ksel, hipStream_t st);
+// ---- exactness certificate and its fallback (topk.hip: finish; topk256.hip: collect; topk_exact.hip: the rest) ----
+// The scan selects on bf16-input scores; the finish step re-scores its ksel candidates in fp32.  A query is CERTIFIED
+// when the score a row needs to enter the result exceeds the best bf16 score any un-re-scored row can have by more
+// than eps, a rigorous bound of |bf16-scan score - fp32 score|.  Uncertified queries are handed
+// to the collect pass (every row whose bf16 score is within eps of what is needed, re-scored exactly), and queries
+// whose collect list overflows to a brute-force fp32 pass over the whole gallery.  All of it is enqueued on the
+// stream with device-side counts: no host round trip.
+constexpr int EXACT_COL_CAP = 2048;     // collected keys per uncertified query
+constexpr int EXACT_L3_SLICES = 32;     // gallery slices of the brute-force pass (their 64-key lists reuse the query's collect buffer)
+static_assert(EXACT_L3_SLICES * 64 == EXACT_COL_CAP, "the brute-force partial lists live in the collect buffer");
+struct ExactWs {
+    int* ctr;            // [0] uncertified queries of this search, [1] of those: collect list overflowed -> brute force,
+                         // [2] queries the certificate was evaluated for, [3] rows collected (all lists), [4..7] spare
+    int* unc_q;          // [cap] query index of uncertified entry j (or the output row, see out_compact)
+    float* unc_lb;       // [cap] bf16-score bound of entry j's collect pass
+    bf16_t* qb_u;        // [cap][ldqb] its bf16 query row (compacted: the collect pass reads whole query tiles)
+    long ldqb;
+    int* col_cnt;        // [cap] rows appended to entry j's list (may exceed EXACT_COL_CAP: overflow)
+    uint64_t* col;       // [cap][EXACT_COL_CAP] keys (bf16 score, row)
+    int* over_j;         // [cap] entries that overflowed
+};
+struct CertArgs {
+    const float* qstat;      // [Q][2] (||qb - qf||, ||qb||) from the query normalisation
+    const uint32_t* gstat;   // [2] fp32 bit patterns: max ||g||, max ||gb - g|| over the gallery's rows
+    int mode;                // 0 = certificate + fallback, 1 = every query takes the collect path, 2 = every query takes the
+                             // brute-force path, 3 = certificate only (counted, no fallback: the pre-certificate behaviour)
+    ExactWs ws;
+    const bf16_t* Qb; long ldq;   // the search's bf16 query rows (source of qb_u)
+    float* cert_out;         // row-sharded search: [Q] this shard's bound U + eps for the merge step's certificate (then no
+                             // local decision is taken); null otherwise
+};
 // exact fp32 re-score of the ksel candidates of each query, final order (score desc, index asc),
-// threshold cut, write k results.  Gf may be null: then the bf16-scan scores are returned.
+// threshold cut, write k results.  Gf may be null: then the bf16-scan scores are returned (and nothing is certified).
 // all_bounds (optional): [parts][Q][top_m] order-preserving u32 scores published by every shard of a row-sharded
 // gallery; only candidates at or above their ksel-th largest (a lower bound of the global ksel-th best) are re-scored.
+// cert (optional): evaluate the exactness certificate and hand uncertified queries to the fallback workspace.
 int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const float* Qf, long ldqf, const float* Gf,
                        long ldgf, int D, int Q, int k, int has_thr, float thr, long idx_offset, const uint32_t* all_bounds,
-                       int parts, int top_m, float* out_scores, long long* out_idx, int* out_counts, hipStream_t st);
+                       int parts, int top_m, float* out_scores, long long* out_idx, int* out_counts, const CertArgs* cert,
+                       hipStream_t st);
+// rigorous bound of |bf16-scan score - fp32 re-score| for a query with (e_q, n_qb) against rows with (G, Eg); see DESIGN.md
+__host__ __device__ inline float cert_eps(float e_q, float n_qb, float G, float Eg, int D) {
+    const float gam1 = (float)D * 1.1920929e-7f;      // D * 2^-23: fp32 accumulation of the MFMA chain (truncation allowed)
+    const float gam2 = (float)D * 5.9604645e-8f;      // D * 2^-24: the fp32 fma chain of the re-score
+    const float eps = e_q * G + n_qb * Eg + gam1 * n_qb * (G + Eg) + gam2 * (n_qb + e_q) * G;
+    return eps * 1.001f + 1e-30f;
+}
+struct Collect256Args {
+    const bf16_t* Qb; long ldq;   // compacted bf16 query rows of the uncertified entries
+    const bf16_t* Gb; long ldg;
+    long N; int D;
+    int splits;                   // set by the launcher
+    const int* n_q;               // device: number of entries (query tiles past it exit)
+    const float* lb;              // [entries] bf16-score bound
+    int* cnt;                     // [entries] rows appended
+    uint64_t* col;                // [entries][cap]
+    int cap;
+};
+int launch_topk_collect256(const Collect256Args& a, int max_queries, hipStream_t st);
+// Fallback passes over the entries ws.ctr[0] (device count; launches are sized for max_entries).
+// exact_finish: fp32 re-score of every collected row, exact top-k; entries whose list overflowed go to ws.over_j.
+// bruteforce: for those, the fp32 score of EVERY gallery row (same fma chain as the re-score), exact top-k.
+// out_compact = 0: results go to row unc_q[j] of the outputs; 1: to row j (unc_q then only names the query row in Qf).
+int launch_topk_exact_finish(const ExactWs& ws, int max_entries, const float* Qf, long ldqf, const float* Gf, long ldgf,
+                             int D, int k, int has_thr, float thr, long idx_offset, int force_bruteforce, int out_compact,
+                             float* out_scores, long long* out_idx, int* out_counts, hipStream_t st);
+int launch_topk_exact_bruteforce(const ExactWs& ws, int max_entries, const float* Qf, long ldqf, const float* Gf, long ldgf,
+                                 long N, int D, int k, int has_thr, float thr, long idx_offset, int out_compact,
+                                 float* out_scores, long long* out_idx, int* out_counts, hipStream_t st);
+// entries from an explicit list (the row-sharded search's second round): entry j = query q_idx[j], collect bound
+// need[j] - eps(query, this gallery); sets ws.ctr[0] = n
+int launch_topk_exact_prepare(const ExactWs& ws, const int* q_idx, const float* need, int n, const CertArgs& cert, int D,
+                              hipStream_t st);
 // bounds[q][0..top_m) = order-preserving u32 scores of the query's best top_m candidates (0 = none)
 int launch_topk_publish(const uint64_t* part, long part_stride, int Q, int top_m, uint32_t* bounds, hipStream_t st);
 // 256 x 256 tile scan (topk256.hip): survivors are appended to per-(query, slice) segments of 2 * ksel keys and
@@ -128,9 +198,15 @@ int launch_topk_fill_empty(float* s, long long* i, int* c, int Q, int k, hipStre
 // merge P per-shard result lists [P][Q][k] -> [Q][k]
 int launch_topk_merge(const float* scores, const long long* idx, int P, int Q, int k, int has_thr, float thr,
                       float* out_scores, long long* out_idx, int* out_counts, hipStream_t st);
+// the merge's share of the exactness certificate of a row-sharded search (all optional: cert == null switches it off)
+struct MergeCert {
+    const float* cert; long cert_part_stride;   // [P][Q] per-shard bounds U_p + eps_p written by the shards' finish steps
+    int* unc_count;                             // device counter (zeroed by the caller): uncertified queries
+    int* unc_q; float* unc_need;                // [Q] their indices (in no particular order) and the score a row needs to enter
+};
 // the same with explicit distances (in elements) between the parts of the two arrays
 int launch_topk_merge_strided(const float* scores, long score_part_stride, const long long* idx, long idx_part_stride, int P,
                               int Q, int k, int has_thr, float thr, float* out_scores, long long* out_idx, int* out_counts,
-                              hipStream_t st);
+                              hipStream_t st, const MergeCert* mc = nullptr);
 
 }  // namespace revo

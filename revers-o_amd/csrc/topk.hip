@@ -14,49 +14,9 @@
 //   merge   combines per-shard results (multi-GPU, after the RCCL all-gather).
 #include "gemm_core.h"
 #include "kernels.h"
+#include "topk_util.h"
 
 namespace revo {
-
-// --------------------------------------------------- wave-level sorting ----
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, m, 64), hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t shfl_up1_u64(uint64_t v) {
-    const uint32_t lo = __shfl_up((uint32_t)v, 1, 64), hi = __shfl_up((uint32_t)(v >> 32), 1, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
-    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ float readlane_f32(float v, int l) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-// sort the 64 lane values, best (largest key) in lane 0
-__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t v, int lane) {
-#pragma unroll
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            const uint64_t o = shfl_xor_u64(v, j);
-            const bool desc = (lane & k2) == 0;
-            const bool lower = (lane & j) == 0;
-            const bool take_max = (lower == desc);
-            v = take_max ? (v > o ? v : o) : (v < o ? v : o);
-        }
-    }
-    return v;
-}
-// v is bitonic across the wave -> sorted, best in lane 0
-__device__ __forceinline__ uint64_t wave_bitonic_merge_desc(uint64_t v, int lane) {
-#pragma unroll
-    for (int j = 32; j > 0; j >>= 1) {
-        const uint64_t o = shfl_xor_u64(v, j);
-        v = ((lane & j) == 0) ? (v > o ? v : o) : (v < o ? v : o);
-    }
-    return v;
-}
 
 // ------------------------------------------------------------- the scan ----
 // Insert cand into the sorted (best-first) list of one row; returns the row's
@@ -249,26 +209,14 @@ int launch_topk_reduce(uint64_t* part, int Q, int splits, int ksel, hipStream_t 
 }
 
 // ----------------------------------------------------------- the finish ----
-// the 64 lane values sorted, largest in lane 0 (32-bit)
-__device__ __forceinline__ uint32_t wave_sort_desc_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            const uint32_t o = __shfl_xor(v, j, 64);
-            const bool take_max = (((lane & j) == 0) == ((lane & k2) == 0));
-            v = take_max ? (v > o ? v : o) : (v < o ? v : o);
-        }
-    }
-    return v;
-}
 __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __restrict__ part, long part_stride, int ksel,
                                                           const float* __restrict__ Qf, long ldqf,
                                                           const float* __restrict__ Gf, long ldgf, int D, int Q, int k,
                                                           int has_thr, float thr, long idx_offset,
                                                           const uint32_t* __restrict__ all_bounds, int parts, int top_m,
                                                           float* __restrict__ out_scores,
-                                                          long long* __restrict__ out_idx, int* __restrict__ out_counts) {
+                                                          long long* __restrict__ out_idx, int* __restrict__ out_counts,
+                                                          int has_cert, CertArgs cert) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
@@ -301,40 +249,26 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __rest
     const bool valid = key != 0ull && (uint32_t)(key >> 32) >= bound;
     const uint32_t idx = key_index(key);
     float score = valid ? key_score(key) : -INFINITY;
+    const unsigned long long vmask = __ballot(valid);
+    const int nv = __popcll(vmask);   // valid entries are a prefix (lists are best-first)
     if (Gf) {
         // exact fp32 dot of the normalised fp32 query and gallery rows; fixed summation
-        // order: per-lane fma chain over elements lane*4 + 256*i, then a butterfly.
+        // order: per-lane fma chain over elements lane*4 + 256*i, then a butterfly (exact_dot4).
         const float* qr = Qf + (long)q * ldqf;
-        const unsigned long long vmask = __ballot(valid);
-        const int nv = __popcll(vmask);   // valid entries are a prefix (lists are best-first)
         // four candidates at a time: their row reads are independent, so the HBM round trips overlap
         // (each candidate keeps its own fma chain in the same order: the scores do not change)
         for (int cnd0 = 0; cnd0 < nv; cnd0 += 4) {
             const float* gr[4];
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            float t[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int cn = cnd0 + u < nv ? cnd0 + u : nv - 1;
                 gr[u] = Gf + (long)__shfl(idx, cn, 64) * ldgf;
             }
-            for (int c = lane * 4; c < D; c += 256) {
-                const f32x4 a = *(const f32x4*)(qr + c);
-                f32x4 b[4];
+            exact_dot4(qr, gr, D, lane, t);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) b[u] = *(const f32x4*)(gr[u] + c);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc[u] = fmaf(a[0], b[u][0], acc[u]);
-                    acc[u] = fmaf(a[1], b[u][1], acc[u]);
-                    acc[u] = fmaf(a[2], b[u][2], acc[u]);
-                    acc[u] = fmaf(a[3], b[u][3], acc[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float t = wave_sum(acc[u]);
-                if (lane == cnd0 + u && cnd0 + u < nv) score = t;
-            }
+            for (int u = 0; u < 4; ++u)
+                if (lane == cnd0 + u && cnd0 + u < nv) score = t[u];
         }
     }
     uint64_t k2 = valid ? make_key(score, idx) : 0ull;
@@ -346,15 +280,61 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __rest
         out_idx[(long)q * k + lane] = ok ? (long long)key_index(k2) + idx_offset : -1ll;
     }
     if (lane == 0) out_counts[q] = cnt;
+    if (!has_cert) return;
+    if (!Gf) {                                 // no fp32 master rows: the returned scores are the scan's, nothing to certify
+        if (cert.cert_out && lane == 0) cert.cert_out[q] = -INFINITY;
+        return;
+    }
+
+    // ---- exactness certificate.  U = the largest bf16-scan score a row that was NOT re-scored in fp32 can have:
+    // the first candidate dropped by the shard bound if there is one, else the worst kept candidate when the list is
+    // full (every row outside it scored no better in the scan), else nothing (the whole gallery was re-scored).
+    // need = the fp32 score a row must reach to change the result: the k-th re-scored score, or the threshold when
+    // that is higher.  If need > U + eps, with eps >= |scan score - fp32 score| for every row, no such row exists.
+    const int ne = __popcll(__ballot(key != 0ull));
+    float U = -INFINITY;
+    if (nv < ne) U = key_score(readlane_u64(key, nv));
+    else if (ne == ksel) U = key_score(readlane_u64(key, ksel - 1));
+    const float G = __uint_as_float(cert.gstat[0]), Eg = __uint_as_float(cert.gstat[1]);
+    const float eps = cert_eps(cert.qstat[(long)q * 2], cert.qstat[(long)q * 2 + 1], G, Eg, D);
+    if (cert.cert_out) {                       // row-sharded search: the merge step decides, over all shards
+        if (lane == 0) cert.cert_out[q] = U + eps;
+        return;
+    }
+    const uint64_t kth = readlane_u64(k2, k - 1);
+    const float sk = kth ? key_score(kth) : -INFINITY;
+    const float need = has_thr ? fmaxf(sk, thr) : sk;
+    const bool certified = (U == -INFINITY || need > U + eps) && cert.mode != 1 && cert.mode != 2;
+    if (lane == 0) atomicAdd(cert.ws.ctr + 2, 1);
+    if (certified) return;
+    int j = 0;
+    if (lane == 0) j = atomicAdd(cert.ws.ctr + (cert.mode == 3 ? 4 : 0), 1);
+    if (cert.mode == 3) return;                // counted only
+    j = __builtin_amdgcn_readfirstlane(j);
+    if (lane == 0) {
+        float lb = need - eps;                 // rows that can enter the result have a bf16 score of at least this
+        lb -= fabsf(lb) * 2.4e-7f;             // (the subtraction's own rounding)
+        cert.ws.unc_q[j] = q;
+        cert.ws.unc_lb[j] = need == -INFINITY ? -INFINITY : lb;
+        cert.ws.col_cnt[j] = 0;
+    }
+    const bf16_t* qs = cert.Qb + (long)q * cert.ldq;
+    bf16_t* qd = cert.ws.qb_u + (long)j * cert.ws.ldqb;
+    for (int c = lane * 8; c < D; c += 512) *(uint4*)(qd + c) = *(const uint4*)(qs + c);
 }
 int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const float* Qf, long ldqf, const float* Gf,
                        long ldgf, int D, int Q, int k, int has_thr, float thr, long idx_offset, const uint32_t* all_bounds,
-                       int parts, int top_m, float* out_scores, long long* out_idx, int* out_counts, hipStream_t st) {
+                       int parts, int top_m, float* out_scores, long long* out_idx, int* out_counts, const CertArgs* cert,
+                       hipStream_t st) {
     REVO_REQUIRE(k >= 1 && k <= ksel && ksel <= 64, "search: need 1 <= k <= ksel <= 64");
     REVO_REQUIRE(!Gf || (D % 4 == 0 && ldqf % 4 == 0 && ldgf % 4 == 0), "search: fp32 rows must be 16-byte aligned");
     if (Q <= 0) return 0;
+    CertArgs c{};
+    const int has_cert = cert ? 1 : 0;
+    if (has_cert) c = *cert;
     hipLaunchKernelGGL(topk_finish_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, part, part_stride, ksel, Qf, ldqf, Gf,
-                       ldgf, D, Q, k, has_thr, thr, idx_offset, all_bounds, parts, top_m, out_scores, out_idx, out_counts);
+                       ldgf, D, Q, k, has_thr, thr, idx_offset, all_bounds, parts, top_m, out_scores, out_idx, out_counts,
+                       has_cert, c);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -563,7 +543,8 @@ int launch_topk_fill_empty(float* s, long long* i, int* c, int Q, int k, hipStre
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ scores, long score_part_stride,
                                                          const long long* __restrict__ idx, long idx_part_stride, int P, int Q, int k,
                                                          int has_thr, float thr, float* __restrict__ out_scores,
-                                                         long long* __restrict__ out_idx, int* __restrict__ out_counts) {
+                                                         long long* __restrict__ out_idx, int* __restrict__ out_counts,
+                                                         MergeCert mc) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
@@ -611,17 +592,37 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
         out_idx[(long)q * k + lane] = ok ? (long long)~((ra << 32) | (uint64_t)rb) : -1ll;
     }
     if (lane == 0) out_counts[q] = cnt;
+    if (!mc.cert) return;
+    // Exactness certificate over all shards (kernels.h): shard p published U_p + eps_p, the best fp32 score any of its
+    // rows that were not re-scored can have.  If the score a row needs to change the merged result exceeds all of them,
+    // the result is that of an exhaustive fp32 scoring; else the query goes to a second, collecting round on every shard.
+    const uint32_t kth_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ra >> 32), k - 1);
+    const uint32_t kth_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ra, k - 1);
+    const uint32_t kth_b = (uint32_t)__builtin_amdgcn_readlane((int)rb, k - 1);
+    const float sk = (kth_hi | kth_lo | kth_b) ? orderable_f32(kth_hi) : -INFINITY;
+    const float need = has_thr ? fmaxf(sk, thr) : sk;
+    float mx = -INFINITY;
+    for (int pz = lane; pz < P; pz += 64) mx = fmaxf(mx, mc.cert[(long)pz * mc.cert_part_stride + q]);
+    mx = wave_max(mx);
+    if (mx == -INFINITY || need > mx) return;
+    if (lane == 0) {
+        const int j = atomicAdd(mc.unc_count, 1);
+        mc.unc_q[j] = q;
+        mc.unc_need[j] = need;
+    }
 }
 #undef KEY96_STEP
 #undef KEY96_LESS
 int launch_topk_merge_strided(const float* scores, long score_part_stride, const long long* idx, long idx_part_stride, int P,
                               int Q, int k, int has_thr, float thr, float* out_scores, long long* out_idx, int* out_counts,
-                              hipStream_t st) {
+                              hipStream_t st, const MergeCert* mc) {
     REVO_REQUIRE(k >= 1 && k <= 64, "merge: need 1 <= k <= 64");
     REVO_REQUIRE(P >= 1, "merge: need at least one part");
     if (Q <= 0) return 0;
+    MergeCert m{};
+    if (mc) m = *mc;
     hipLaunchKernelGGL(topk_merge_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, scores, score_part_stride, idx, idx_part_stride,
-                       P, Q, k, has_thr, thr, out_scores, out_idx, out_counts);
+                       P, Q, k, has_thr, thr, out_scores, out_idx, out_counts, m);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -781,4 +781,180 @@ int topk_scan256_main_queries(int Q, long rows) {
     return main + tail < whole ? Q - rem : Q;
 }
 
+// ---------------------------------------------------------------- the collect pass ----
+// Fallback of the exactness certificate (topk_exact.hip): for the queries the finish step could not certify, every
+// gallery row whose bf16 score reaches the query's bound lb (= the score a row needs in fp32 to enter the result,
+// minus the rigorous bound of |bf16 score - fp32 score|) is appended to the query's collect list; the fp32 re-score of
+// that list is then exact, whatever the scan's ksel candidates were.  Same main loop as the scan, and its selection
+// with everything adaptive removed: the bound is constant, survivors of a pass are staged in LDS and thread i appends
+// entry i to its query's list (slot from a global counter; a list that runs full only keeps counting: that query goes
+// to the brute-force pass).  A pass that stages more than the buffer holds is discarded and the tile recomputed by
+// column groups, as in the scan.  The number of queries is read from device memory (the launch is sized for all Q
+// queries of the search; workgroups of query tiles past the count exit at once): no host round trip in a search.
+constexpr int C256_LDS = G256_LDS + S256_STG * 8 + 256 * 4 + 64;
+constexpr uint32_t C256_STG_OFF = G256_LDS;
+constexpr uint32_t C256_TAU_OFF = C256_STG_OFF + S256_STG * 8;
+constexpr uint32_t C256_CTRL_OFF = C256_TAU_OFF + 256 * 4;          // [0] running total of staged survivors
+
+template <int ROWS>
+__global__ __launch_bounds__(G256_THREADS, 2) void topk_collect256_kernel(Collect256Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tau = (float*)(smem + C256_TAU_OFF);
+    uint32_t* ctrl = (uint32_t*)(smem + C256_CTRL_OFF);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane = tid & 63;
+    const int nq = *p.n_q;
+    const int sp = blockIdx.x;                              // one workgroup per gallery slice; it walks the query tiles
+    const long tiles = (p.N + 255) / 256;
+    const long per = tiles / p.splits, rem = tiles - per * p.splits;
+    const long t0 = sp * per + (sp < rem ? sp : rem);
+    const long t1 = t0 + per + (sp < rem ? 1 : 0);
+    if (t0 >= t1) return;
+    const long row_begin = t0 * 256;
+    const uint32_t idx_base = (uint32_t)row_begin;
+    for (int q0 = 0; q0 < nq; q0 += 256) {
+    const int qvalid = (nq - q0) < 256 ? (nq - q0) : 256;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // the previous query tile's last reads of tau / the stage
+    if (tid < 256) tau[tid] = tid < qvalid ? p.lb[q0 + tid] : INFINITY;
+    if (tid == 0) ctrl[0] = 0u;
+    __syncthreads();
+
+    G256Operand A, B;
+    g256_operand_init(A, p.Qb, p.ldq, nq, q0, wave, lane);
+    g256_operand_init(B, p.Gb + row_begin * p.ldg, p.ldg, p.N - row_begin, 0, wave, lane);
+    g256_issue_prologue(A, B, smem, p.D, wave);
+
+    long t = t0;
+    int groups = 1, grp = 0;
+    uint32_t staged_before = 0;
+    while (t < t1) {
+        const long n0 = t * 256;
+        {
+            f32x4 acc[8][4];
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            gemm256_mainloop<ROWS>(A, B, smem, p.D, wave, lane, acc);
+            if (groups == 1 && t + 1 < t1) {
+                g256_operand_init(B, p.Gb + (n0 + 256) * p.ldg, p.ldg, p.N - (n0 + 256), 0, wave, lane);
+                g256_issue_prologue(A, B, smem, p.D, wave);
+            }
+            asm volatile("" : "+v"(lane) :: "memory");
+            const int lr = lane & 15, lq = lane >> 4;
+            const int rbase = (wave >> 2) * 128 + lr;
+            const int cbase = (wave & 3) * 64 + lq * 4;
+            const long left = p.N - n0;
+            const uint32_t rel0 = (uint32_t)(n0 - row_begin);
+            if (left < 256) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool past = cbase + n * 16 + j >= left;
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) acc[m][n][j] = past ? __builtin_nanf("") : acc[m][n][j];
+                    }
+            }
+            float taum[8];
+            unsigned hitm = 0;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) taum[m] = s256_lds_f32(C256_TAU_OFF + (rbase + m * 16) * 4);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mx = fmaxf(mx, acc[m][n][j]);
+                if (__ballot(mx >= taum[m]) != 0ull) hitm |= 1u << m;
+            }
+            if (hitm) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    if (!(hitm & (1u << m))) continue;          // wave-uniform
+                    const int row = rbase + m * 16;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = acc[m][n][j];
+                            const int col = cbase + n * 16 + j;
+                            const bool pass = v >= taum[m];
+                            if (__ballot(pass) == 0ull) continue;
+                            if (pass && (col & (groups - 1)) == grp) {
+                                const uint32_t pos = (uint32_t)s256_lds_inc(C256_CTRL_OFF) - staged_before;
+                                if (pos < (uint32_t)S256_STG) s256_lds_store64(C256_STG_OFF + pos * 8, s256_entry(row, v, rel0 + col));
+                            }
+                        }
+                }
+            }
+        }
+        s256_barrier_lds();
+        const uint32_t staged_total = s256_lds_u32(C256_CTRL_OFF);
+        const uint32_t staged = staged_total - staged_before;
+        staged_before = staged_total;
+        const bool overflow = staged > (uint32_t)S256_STG;
+        if (!overflow) {
+            for (uint32_t i = tid; i < staged; i += 512) {
+                const uint64_t e = s256_lds_u64(C256_STG_OFF + i * 8);
+                const int row = (int)(e >> 56);
+                const int slot = atomicAdd(p.cnt + q0 + row, 1);
+                if (slot < p.cap) p.col[(long)(q0 + row) * p.cap + slot] = s256_entry_to_key(e, idx_base);
+            }
+        }
+        s256_barrier_lds();
+        if (groups == 1 && !overflow) { ++t; continue; }
+        if (overflow) {
+            groups = groups < S256_MAXGROUPS ? groups * 2 : S256_MAXGROUPS;
+            grp = 0;
+        } else if (++grp == groups) {
+            groups = 1;
+            grp = 0;
+            ++t;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t < t1) {
+            const long nn = t * 256;
+            g256_operand_init(B, p.Gb + nn * p.ldg, p.ldg, p.N - nn, 0, wave, lane);
+            g256_issue_prologue(A, B, smem, p.D, wave);
+        }
+    }
+    }
+}
+
+// slices of the collect pass: enough to fill the chip with ONE query tile (the usual case: a handful of uncertified
+// queries), at least three gallery tiles per slice, and never more than 2^24 rows in a slice (24-bit staging index)
+int topk_collect256_splits(long N) {
+    const long tiles = (N + 255) / 256;
+    if (tiles <= 0) return 1;
+    long s = tiles / 3;
+    s = s < 1 ? 1 : (s > 256 ? 256 : s);
+    const long min_s = (tiles + 65535) / 65536;
+    return (int)(s < min_s ? min_s : s);
+}
+int launch_topk_collect256(const Collect256Args& a_in, int max_queries, hipStream_t st) {
+    Collect256Args a = a_in;
+    REVO_REQUIRE(a.D % 64 == 0 && a.ldq % 8 == 0 && a.ldg % 8 == 0, "search: D must be a multiple of 64");
+    REVO_REQUIRE(a.N < (1ll << 32), "search: a shard holds at most 2^32 rows");
+    REVO_REQUIRE(256l * a.ldg * 2 < (1l << 31) && 256l * a.ldq * 2 < (1l << 31), "search: row too long for the DMA window");
+    if (max_queries <= 0 || a.N <= 0) return 0;
+    a.splits = topk_collect256_splits(a.N);
+    const dim3 grid((unsigned)a.splits), block(G256_THREADS);
+#define C256_LAUNCH(RW)                                                                           \
+    do {                                                                                          \
+        REVO_FUNC_LDS((topk_collect256_kernel<RW>), C256_LDS);                                    \
+        hipLaunchKernelGGL((topk_collect256_kernel<RW>), grid, block, C256_LDS, st, a);           \
+    } while (0)
+    if (max_queries <= 64) C256_LAUNCH(64);
+    else if (max_queries <= 128) C256_LAUNCH(128);
+    else C256_LAUNCH(0);
+#undef C256_LAUNCH
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace revo

@@ -230,6 +230,22 @@ class Gallery:
         return scores, idx, counts
 
 
+    # -- the exactness certificate (include/revo.h, "EXACTNESS") ------------------------------------------
+    MODES = {"certified": 0, "collect": 1, "bruteforce": 2, "uncertified": 3}
+
+    def set_search_mode(self, mode="certified"):
+        """``certified`` (default): every query's result is certified exact or re-done exactly; ``collect`` /
+        ``bruteforce``: every query takes that fallback (parity tests); ``uncertified``: certificate counted only."""
+        _lib.check(self._lib.revo_search_set_mode(self._h, self.MODES[mode] if isinstance(mode, str) else int(mode)),
+                   "revo_search_set_mode")
+
+    def search_stats(self):
+        """Counters of the last search on this handle (synchronises the current stream)."""
+        out = (C.c_int32 * 4)()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.revo_search_stats(self._h, out, _lib.current_stream()), "revo_search_stats")
+        return {"uncertified": int(out[0]), "bruteforced": int(out[1]), "checked": int(out[2]), "collected_rows": int(out[3])}
+
     def search_plan(self, n_queries, k=5):
         """How a search would run (reporting): dict with the scan form, the pre-pass rows, slices and ksel."""
         out = (C.c_int64 * 4)()
@@ -258,9 +274,11 @@ class Gallery:
         Returns (scores, indices, counts); with ``out_packed`` (uint8 ``[packed_bytes(Q, k)]``) scores and indices
         are views into that buffer, laid out for :func:`merge_topk_packed`."""
         Q, k = int(n_queries), int(k)
+        cert = None
         if out_packed is not None:
             idx = out_packed[: Q * k * 8].view(torch.int64).view(Q, k)
             scores = out_packed[Q * k * 8: Q * k * 12].view(torch.float32).view(Q, k)
+            cert = out_packed[Q * k * 12: Q * k * 12 + Q * 4].view(torch.float32)     # this shard's certificate bounds
         else:
             scores = torch.empty((Q, k), dtype=torch.float32, device=self.device)
             idx = torch.empty((Q, k), dtype=torch.int64, device=self.device)
@@ -276,7 +294,30 @@ class Gallery:
             _lib.check(self._lib.revo_search_finish(
                 self._h, Q, k, int(score_threshold is not None),
                 float(score_threshold if score_threshold is not None else 0.0), int(index_offset), _lib.ptr(all_bounds),
-                parts, top_m, _lib.ptr(scores), _lib.ptr(idx), _lib.ptr(counts), _lib.current_stream()), "revo_search_finish")
+                parts, top_m, _lib.ptr(scores), _lib.ptr(idx), _lib.ptr(counts), _lib.ptr(cert), _lib.current_stream()),
+                "revo_search_finish")
+        return scores, idx, counts
+
+    def search_exact(self, q_idx, need, k, index_offset=0, out_packed=None):
+        """Second round of a row-sharded search: exact local top-k of the queries ``q_idx`` (int32 ``[n]``, rows of the
+        last :meth:`search_candidates` call) given ``need`` (fp32 ``[n]``: the score a row must reach to change the
+        merged result).  Results in compact rows ``[n, k]``; with ``out_packed`` laid out for :func:`merge_topk_packed`."""
+        n, k = int(q_idx.shape[0]), int(k)
+        _require_cuda(q_idx, "q_idx", self.device)
+        _require_cuda(need, "need", self.device)
+        assert q_idx.dtype == torch.int32 and need.dtype == torch.float32 and need.shape[0] == n
+        if out_packed is not None:
+            idx = out_packed[: n * k * 8].view(torch.int64).view(n, k)
+            scores = out_packed[n * k * 8: n * k * 12].view(torch.float32).view(n, k)
+            out_packed[n * k * 12: n * k * 12 + n * 4].view(torch.float32).fill_(float("-inf"))   # exact: nothing left to certify
+        else:
+            scores = torch.empty((n, k), dtype=torch.float32, device=self.device)
+            idx = torch.empty((n, k), dtype=torch.int64, device=self.device)
+        counts = torch.empty((n,), dtype=torch.int32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            _lib.check(self._lib.revo_search_exact(self._h, n, _lib.ptr(q_idx.contiguous()), _lib.ptr(need.contiguous()), k, 0,
+                                                   0.0, int(index_offset), _lib.ptr(scores), _lib.ptr(idx), _lib.ptr(counts),
+                                                   _lib.current_stream()), "revo_search_exact")
         return scores, idx, counts
 
 
@@ -286,25 +327,35 @@ def search_ksel(k):
 
 
 def packed_bytes(n_queries, k):
-    """Size of one packed result block ([Q, k] int64 indices, then [Q, k] fp32 scores, padded to 16 bytes)."""
+    """Size of one packed result block ([Q, k] int64 indices, [Q, k] fp32 scores, [Q] fp32 certificate bounds,
+    padded to 16 bytes)."""
     return int(_lib.load().revo_topk_packed_bytes(int(n_queries), int(k)))
 
 
-def merge_topk_packed(packed, parts, n_queries, k, score_threshold=None):
-    """Merge ``parts`` packed result blocks (uint8, back to back: one all-gather) into [Q, k]; K14."""
+def merge_topk_packed(packed, parts, n_queries, k, score_threshold=None, certify=False):
+    """Merge ``parts`` packed result blocks (uint8, back to back: one all-gather) into [Q, k]; K14.
+    ``certify``: also check every query's exactness certificate over all shards; returns a fourth item
+    ``(unc_count int32 [1], unc_q int32 [Q], unc_need fp32 [Q])`` (device; the first ``unc_count`` entries are valid)."""
     _require_cuda(packed, "packed")
     Q, k = int(n_queries), int(k)
     assert packed.dtype == torch.uint8 and packed.numel() == parts * packed_bytes(Q, k)
     scores = torch.empty((Q, k), dtype=torch.float32, device=packed.device)
     idx = torch.empty((Q, k), dtype=torch.int64, device=packed.device)
     counts = torch.empty((Q,), dtype=torch.int32, device=packed.device)
+    unc = None
+    if certify:
+        unc = (torch.zeros((1,), dtype=torch.int32, device=packed.device),
+               torch.empty((max(Q, 1),), dtype=torch.int32, device=packed.device),
+               torch.empty((max(Q, 1),), dtype=torch.float32, device=packed.device))
     lib = _lib.load()
     with torch.cuda.device(packed.device):
         _lib.check(lib.revo_topk_merge_packed(_lib.ptr(packed), int(parts), Q, k, int(score_threshold is not None),
                                               float(score_threshold if score_threshold is not None else 0.0),
-                                              _lib.ptr(scores), _lib.ptr(idx), _lib.ptr(counts), _lib.current_stream()),
+                                              _lib.ptr(scores), _lib.ptr(idx), _lib.ptr(counts),
+                                              _lib.ptr(unc[0]) if unc else None, _lib.ptr(unc[1]) if unc else None,
+                                              _lib.ptr(unc[2]) if unc else None, _lib.current_stream()),
                    "revo_topk_merge_packed")
-    return scores, idx, counts
+    return (scores, idx, counts, unc) if certify else (scores, idx, counts)
 
 
 def merge_topk(part_scores, part_indices, k, score_threshold=None):

@@ -13,10 +13,16 @@ scale-out of that call.  A search of Q queries (identical on every rank) for the
      instead of ksel: the fp32 row gathers, the part of a search that does not shrink with the shard,
      shrink with it) and takes its local top k with global row ids
   4. all-gather #2 of the packed per-rank results (12 * k bytes per query and rank, one buffer)
-  5. the same merge on every rank (score descending, global row id ascending).
+  5. the same merge on every rank (score descending, global row id ascending), which also checks every query's
+     exactness certificate over all shards (include/revo.h, "EXACTNESS": each shard ships, next to its results, the
+     best fp32 score a row it did NOT re-score can have)
+  6. only if some query fails that check (none on ordinary data; near-duplicate clusters wider than the scan's
+     candidate lists): every rank re-does those queries exactly on its shard (collecting pass + fp32 re-score, brute
+     force if need be) and a second packed all-gather + merge replaces their results.  The list of such queries is the
+     same on every rank (same merged data), so the ranks take this branch together.
 
 Both exchanges are latency-bound on xGMI (kilobytes to a few MB, no all-reduce).  The result equals the
-unsharded search of the concatenated gallery.
+unsharded search of the concatenated gallery bit for bit: both are the top-k of an exhaustive fp32 scoring.
 
 The compute steps come from a *backend* object so that the protocol -- offsets, gather layouts, ordering --
 can be exercised on CPU with the gloo backend by the tests; the product wiring (:func:`from_gallery`) uses
@@ -27,7 +33,9 @@ the HIP kernels and nothing else.  Backend interface:
     candidates(queries, k, top_m) -> int32 [Q, top_m]
     finish(n_queries, k, all_bounds [P, Q, top_m], index_offset) -> uint8 [packed_bytes(Q, k)]
     packed_bytes(n_queries, k) -> int
-    merge(packed_all uint8 [P * packed_bytes], parts, n_queries, k, threshold) -> (scores, indices, counts)
+    merge(packed_all uint8 [P * packed_bytes], parts, n_queries, k, threshold, certify=False)
+        -> (scores, indices, counts[, (unc_count int32 [1], unc_q int32 [Q], unc_need fp32 [Q])])
+    exact(q_idx int32 [n], need fp32 [n], k, index_offset) -> uint8 [packed_bytes(n, k)]
 """
 import torch
 import torch.distributed as dist
@@ -59,8 +67,13 @@ class GalleryBackend:
         self.gallery.search_finish(n_queries, k, all_bounds, None, index_offset, out_packed=out)
         return out
 
-    def merge(self, packed_all, parts, n_queries, k, threshold):
-        return self._engine.merge_topk_packed(packed_all, parts, n_queries, k, threshold)
+    def merge(self, packed_all, parts, n_queries, k, threshold, certify=False):
+        return self._engine.merge_topk_packed(packed_all, parts, n_queries, k, threshold, certify=certify)
+
+    def exact(self, q_idx, need, k, index_offset):
+        out = torch.empty((self.packed_bytes(int(q_idx.shape[0]), k),), dtype=torch.uint8, device=self.gallery.device)
+        self.gallery.search_exact(q_idx, need, k, index_offset, out_packed=out)
+        return out
 
 
 class ShardedSearch:
@@ -70,6 +83,7 @@ class ShardedSearch:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.local_rows = int(local_rows)
+        self.last_uncertified = 0          # queries of the last search that needed the second round
         self.offset, self.total_rows = self._exchange_offsets()
 
     @classmethod
@@ -135,4 +149,58 @@ class ShardedSearch:
         packed = self.backend.finish(Q, k, allb.view(self.world, Q, top_m), self.offset)
         allp = torch.empty((self.world * packed.numel(),), dtype=torch.uint8, device=packed.device)
         self._all_gather(allp, packed)                                           # exchange 2: packed per-rank top-k
-        return self.backend.merge(allp, self.world, Q, k, threshold)
+        scores, idx, counts, unc = self.backend.merge(allp, self.world, Q, k, threshold, certify=True)
+        n = int(unc[0].item())                                                   # identical on every rank
+        self.last_uncertified = n
+        if n > 0:
+            # second round: the uncertified queries, in one canonical order on every rank, exactly on every shard
+            qs, order = torch.sort(unc[1][:n])
+            need = unc[2][:n][order].contiguous()
+            packed2 = self.backend.exact(qs.contiguous(), need, k, self.offset)
+            allp2 = torch.empty((self.world * packed2.numel(),), dtype=torch.uint8, device=packed2.device)
+            self._all_gather(allp2, packed2)                                     # exchange 3 (rare)
+            s2, i2, c2 = self.backend.merge(allp2, self.world, n, k, threshold)
+            rows = qs.long()
+            scores[rows] = s2
+            idx[rows] = i2
+            counts[rows] = c2
+        return scores, idx, counts
+
+
+class LocalShards:
+    """The same protocol over several shards held by ONE process (a list of backends, e.g. the eight shards of a
+    1 M-row gallery on one GPU in the tests and in scripts/sharded_stage_bench.py; or one handle per GPU of a
+    single-process deployment): the "all-gathers" are concatenations.  ``offsets[p]`` = global id of shard p's row 0."""
+
+    def __init__(self, backends, offsets):
+        self.backends = list(backends)
+        self.offsets = [int(o) for o in offsets]
+        self.last_uncertified = 0
+
+    @classmethod
+    def from_galleries(cls, galleries):
+        offs, tot = [], 0
+        for g in galleries:
+            offs.append(tot)
+            tot += len(g)
+        return cls([GalleryBackend(g) for g in galleries], offs)
+
+    def search(self, queries, k, threshold=None):
+        P, Q = len(self.backends), queries.shape[0]
+        ksel = self.backends[0].ksel(k)
+        top_m = min(ksel, max(8, -(-ksel // P)))
+        allb = torch.stack([b.candidates(queries, k, top_m) for b in self.backends])            # [P, Q, top_m]
+        allp = torch.cat([b.finish(Q, k, allb, off) for b, off in zip(self.backends, self.offsets)])
+        scores, idx, counts, unc = self.backends[0].merge(allp, P, Q, k, threshold, certify=True)
+        n = int(unc[0].item())
+        self.last_uncertified = n
+        if n > 0:
+            qs, order = torch.sort(unc[1][:n])
+            need = unc[2][:n][order].contiguous()
+            allp2 = torch.cat([b.exact(qs.contiguous(), need, k, off) for b, off in zip(self.backends, self.offsets)])
+            s2, i2, c2 = self.backends[0].merge(allp2, P, n, k, threshold)
+            rows = qs.long()
+            scores[rows] = s2
+            idx[rows] = i2
+            counts[rows] = c2
+        return scores, idx, counts

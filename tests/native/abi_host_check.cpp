@@ -127,8 +127,14 @@ int main() {
             EXPECT(revo_gallery_append(g, v, 11, 1, 0, nullptr) == -2 && err_has("capacity"));
             EXPECT(revo_search_topk(g, v, 1, 0, 0, 0.f, 0, s, i, cnt, nullptr) == -2 && err_has("k must be"));
             EXPECT(revo_search_topk(g, v, 1, 51, 0, 0.f, 0, s, i, cnt, nullptr) == -2);
-            EXPECT(revo_search_finish(g, 3, 5, 0, 0.f, 0, nullptr, 0, 0, s, i, cnt, nullptr) == -2 && err_has("no matching"));
+            EXPECT(revo_search_finish(g, 3, 5, 0, 0.f, 0, nullptr, 0, 0, s, i, cnt, nullptr, nullptr) == -2 && err_has("no matching"));
             EXPECT(revo_gallery_read(g, 0, 1, v, 0) == -2 && err_has("outside"));
+            EXPECT(revo_search_set_mode(g, 4) == -2 && revo_search_set_mode(g, 2) == 0 && revo_search_set_mode(g, 0) == 0);
+            int32_t st4[4] = {7, 7, 7, 7};
+            EXPECT(revo_search_stats(g, st4, nullptr) == 0 && st4[0] == -1 && st4[1] == 0);      // no search yet
+            int32_t qi[1] = {0}; float nd[1] = {0.f};
+            EXPECT(revo_search_exact(g, 2, qi, nd, 5, 0, 0.f, 0, s, i, cnt, nullptr) == -2 && err_has("more entries"));
+            EXPECT(revo_search_exact(g, 1, qi, nd, 51, 0, 0.f, 0, s, i, cnt, nullptr) == -2);
             EXPECT(revo_gallery_destroy(g) == 0);
         }
     }
@@ -139,13 +145,16 @@ int main() {
     EXPECT(revo_gallery_read(nullptr, 0, 0, nullptr, 0) == -2);
     EXPECT(revo_search_topk(nullptr, nullptr, 1, 5, 0, 0.f, 0, nullptr, nullptr, nullptr, nullptr) == -2);
     EXPECT(revo_search_candidates(nullptr, nullptr, 1, 5, 8, nullptr, nullptr) == -2);
-    EXPECT(revo_search_finish(nullptr, 1, 5, 0, 0.f, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr) == -2);
+    EXPECT(revo_search_finish(nullptr, 1, 5, 0, 0.f, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr) == -2);
     EXPECT(revo_search_plan(nullptr, 1, 5, nullptr) == -2);
     EXPECT(revo_search_ksel(1) == 32 && revo_search_ksel(16) == 32 && revo_search_ksel(17) == 64 && revo_search_ksel(50) == 64);
     EXPECT(revo_search_ksel(0) == -1 && revo_search_ksel(51) == -1);
-    EXPECT(revo_topk_packed_bytes(10, 5) == 608 && revo_topk_packed_bytes(3, 1) == 48 && revo_topk_packed_bytes(-1, 5) == -1);
+    EXPECT(revo_topk_packed_bytes(10, 5) == 640 && revo_topk_packed_bytes(3, 1) == 48 && revo_topk_packed_bytes(-1, 5) == -1);
     EXPECT(revo_topk_merge(nullptr, nullptr, 1, 1, 1, 0, 0.f, nullptr, nullptr, nullptr, nullptr) == -2);
-    EXPECT(revo_topk_merge_packed(nullptr, 1, 1, 1, 0, 0.f, nullptr, nullptr, nullptr, nullptr) == -2);
+    EXPECT(revo_topk_merge_packed(nullptr, 1, 1, 1, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == -2);
+    EXPECT(revo_search_exact(nullptr, 1, nullptr, nullptr, 5, 0, 0.f, 0, nullptr, nullptr, nullptr, nullptr) == -2);
+    EXPECT(revo_search_set_mode(nullptr, 0) == -2);
+    EXPECT(revo_search_stats(nullptr, nullptr, nullptr) == -2);
 
     // ---- single kernels and hooks: argument checks that do not need a device
     EXPECT(revo_op_set_gemm_tile(64) == -2 && revo_op_set_gemm_tile(0) == 0);

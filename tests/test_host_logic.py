@@ -105,7 +105,7 @@ def test_preprocess_matches_reference_transform():
 
 
 # --------------------------------------------------------------- gloo, world 2 ---
-def _shard_worker(rank, world, port, tmp, N, D, Q, k):
+def _shard_worker(rank, world, port, tmp, N, D, Q, k, noise=0.0):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     from reverso_amd import sharded
@@ -120,27 +120,36 @@ def _shard_worker(rank, world, port, tmp, N, D, Q, k):
     lo = sum(sizes[:rank])
     mine = gal[lo:lo + sizes[rank]]
 
-    ss = sharded.ShardedSearch(osearch.OracleShardBackend(mine), sizes[rank])
+    backend = osearch.OracleShardBackend(mine, scan_noise=noise, row_offset=lo)
+    ss = sharded.ShardedSearch(backend, sizes[rank])
     assert ss.offset == lo and ss.total_rows == N
     # data-parallel queries: each rank contributes its slice, gather gives everyone all of them
     per = Q // world
     allq = ss.gather_queries(torch.from_numpy(qs[rank * per:(rank + 1) * per]))
     assert np.array_equal(allq.numpy(), qs[: per * world])
     out = {}
+    second_rounds = 0
     for thr in (None, 0.05):
         s, i, c = ss.search(allq, k, thr)
         out[str(thr)] = (s.numpy(), i.numpy(), c.numpy())
+        second_rounds += ss.last_uncertified
+    # a noisy scan (the bf16 scan's stand-in) must have sent some queries, not all, through the second, exact round;
+    # an exact scan sends only queries whose k-th place ties with the candidate list's last (none here)
+    assert (second_rounds > 0 and backend.exact_calls > 0) if noise > 0 else (second_rounds == 0 and backend.exact_calls == 0)
     np.savez(os.path.join(tmp, f"rank{rank}.npz"), **{f"{t}_{n}": v for t, (a, b, c) in out.items()
                                                         for n, v in (("s", a), ("i", b), ("c", c))})
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_search_protocol_gloo(tmp_path):
+@pytest.mark.parametrize("noise", [0.0, 0.07])
+def test_sharded_search_protocol_gloo(tmp_path, noise):
+    """World-size-2 run of the sharded search's protocol (offsets, both all-gathers, the merge, the certificate check
+    and -- with a noisy scan -- the second, exact round) on CPU: the result must be the exhaustive search's."""
     import torch.multiprocessing as mp
     N, D, Q, k, world = 1001, 64, 6, 7, 2
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_shard_worker, args=(world, port, str(tmp_path), N, D, Q, k), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + (7 if noise else 0)
+    mp.spawn(_shard_worker, args=(world, port, str(tmp_path), N, D, Q, k, noise), nprocs=world, join=True)
     rng = np.random.default_rng(7)
     gal = osearch.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
     gal[10:14] = gal[10]
