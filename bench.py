@@ -82,10 +82,13 @@ def cpu_baseline(cfg, gallery_rows, dim, k, n_images, search_rows):
         G.add(torch.from_numpy(gal).to(dev), normalize=False)
         qs = torch.from_numpy(q).to(dev)
         s_gpu, i_gpu, _ = G.search(qs, k)
+        cert = G.search_stats()
         rs, ri, _ = osearch.search(gal, q, k)
         exact = {"embed_cosine_vs_oracle_min": float((ge * emb).sum(-1).min()),
                  "topk_index_match_rate": float((i_gpu.cpu().numpy() == ri).mean()),
                  "topk_max_abs_score_err": float(np.abs(s_gpu.cpu().numpy() - rs).max()),
+                 # queries whose exactness certificate failed and were re-done by the exact fallback (include/revo.h)
+                 "uncertified_queries": cert["uncertified"], "certificate_checked": cert["checked"],
                  "sample": f"{n_images} oracle embeddings as queries over the {search_rows}x{dim} gallery sample, k = {k}"}
         G.close()
         eng.close()
@@ -119,6 +122,11 @@ def main():
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--debug-flags", type=int, default=0, help="A/B experiments: revo_op_set_gemm_debug flags (0 = product path); "
                                                                "needs REVO_EXPERIMENTS=1 (librevo_exp.so, `make -C revers-o_amd/csrc exp`)")
+    ap.add_argument("--search-dim", type=int, default=0,
+                    help="dimension of the gallery of the --search-queries leg (0 = the tower's output dimension, the headline "
+                         "gallery itself).  BASELINE.json configs[4] writes its gallery as 10M x 1536 while PE-Core-G14-448 "
+                         "emits 1280-dimensional embeddings (SURVEY.md 8(a) note): --variant PE-Core-G14-448 --gallery 10000000 "
+                         "--search-dim 1536 runs the search leg on the gallery as written")
     ap.add_argument("--search-queries", type=int, default=10000,
                     help="extra, untimed-by-the-headline measurement: a batch of this many queries against the local "
                          "gallery shard (BASELINE.json configs[3]); 0 disables it")
@@ -217,15 +225,18 @@ def main():
     # profiles/roofline_traffic.json, produced by scripts/pmc_summary.py.  null when the
     # workload differs from the profiled one.
     traffic = None
+    traffic_source = None
     try:
         with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
             tj = json.load(f)
         if tj.get("variant") == cfg.name and tj.get("batch") == B:
             traffic = tj.get("gemm_bytes_per_launch")
+            traffic_source = ("profiles/roofline_traffic.json: rocprofv3 PMC passes of this command taken at "
+                              f"{tj.get('taken', 'an earlier commit')} (NOT measured by this run)")
     except Exception:
         traffic = None
     roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "kernel": "gemm256p_kernel (+ the leftover-row kernels of the same linear layer; one layer call = one launch)",
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "kernel": "gemm256p_kernel (+ the leftover-row kernels of the same linear layer; one layer call = one launch)",
                 "avg_launch_ms": avg_ms, "launches": gemm_launches,
                 "algorithmic_flops_per_launch": flops_per_launch}
     # per layer type: the four linear layers of a block have different shapes and epilogues
@@ -257,6 +268,8 @@ def main():
                                     "unit": "GB/s", "frac": tot_bytes / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "ms_per_step": tot_ms, "kernels": sorted(search_classes)}
     classes_ms = {k: round(v["ms"] / bsteps, 4) for k, v in sorted(prof_all.items())}
+    # exactness certificate of the headline searches (the last step's): queries that needed the exact fallback
+    cert_headline = gal.search_stats() if world == 1 else {"uncertified": ss.last_uncertified}
 
     # BASELINE.json configs[3]: a large batch of replicated queries against the whole gallery THROUGH the sharded
     # search (per-shard scan, both all-gathers, merge) -- the MFMA-bound regime of the fused scan (north_star:
@@ -265,6 +278,15 @@ def main():
     search_big = None
     if args.search_queries > 0 and shard_rows > 0:
         Qn = args.search_queries
+        tower_dim = D
+        if args.search_dim and args.search_dim != D:
+            # the query-batch leg on a gallery of another dimension (configs[4] as written): its own shard, same seeds
+            D = args.search_dim
+            gal = engine.Gallery(D, max(shard_rows, 1), device=local_rank)
+            gg = torch.Generator(device=dev).manual_seed(42 + rank)
+            for s in range(0, shard_rows, 131072):
+                gal.add(torch.randn(min(131072, shard_rows - s), D, generator=gg, device=dev))
+            ss = sharded.ShardedSearch.from_gallery(gal)
         qg = torch.Generator(device=dev).manual_seed(7)               # the same queries on every rank
         qbig = torch.randn(Qn, D, generator=qg, device=dev)
         reps = 3
@@ -275,6 +297,7 @@ def main():
             ss.search(qbig, args.k)
         fence()
         dts = (time.perf_counter() - t1) / reps
+        cert_big = gal.search_stats() if world == 1 else {"uncertified": ss.last_uncertified}
         if world > 1:
             tt = torch.tensor([dts], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -298,7 +321,11 @@ def main():
                       "scan_ms": scan_ms_big, "scan_rows": shard_rows - planb["prepass_rows"], "slices": planb["slices"],
                       "scan_tflops": fl / (scan_ms_big * 1e-3) / 1e12 if scan_ms_big else None,
                       "scan_frac_of_mfma_peak": fl / (scan_ms_big * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if scan_ms_big else None,
-                      "end_to_end_tflops_all_gpus": fl_all / dts / 1e12}
+                      "end_to_end_tflops_all_gpus": fl_all / dts / 1e12,
+                      # exactness certificate: queries of the batch that failed it and were re-done by the exact fallback
+                      # (collecting pass over the gallery; their cost is inside sharded_ms)
+                      "uncertified_queries": cert_big["uncertified"],
+                      "exact_stage_ms": p2.get("topk_exact", {}).get("ms", 0.0) / max(p2.get("topk_exact", {}).get("launches", 1), 1)}
         if world > 1 and rank == 0:
             # the 1-GPU time of the SAME search in this process: the whole gallery on this one device
             full = engine.Gallery(D, args.gallery, device=local_rank)
@@ -336,6 +363,9 @@ def main():
             # whole step (embed + search) against the MFMA peak, SURVEY.md 8(d): images/s x FLOPs/image -- not the kernel-class `roofline.frac`
             "embed_frac_of_peak": cfg.flops_per_image() * B * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS / world,
             "search_query_batch": search_big,
+            "certificate": {"uncertified_queries_last_step": cert_headline["uncertified"],
+                            "note": "every query's top-k is certified equal to an exhaustive fp32 scoring or re-done exactly "
+                                    "(include/revo.h EXACTNESS); the fallback's time is inside ms_per_step"},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, args.gallery, D, args.k, args.cpu_images, min(args.gallery, 250_000))

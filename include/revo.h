@@ -171,8 +171,11 @@ int32_t revo_op_gemm(int32_t epilogue, const void* a_bf16, int64_t lda, const vo
 int32_t revo_op_gemm_rope(const void* a_bf16, int64_t lda, const void* b_bf16, int64_t ldb, int32_t m, int32_t n, int32_t k,
                           void* c_bf16, int64_t ldc, const float* bias, const float* cos_sin, int32_t seq,
                           int32_t head_dim, int32_t rope_cols, void* stream);
-/* ---- test hooks: kernel-variant selection.  Every variant computes the same result (split-K changes the
- * fp32 summation order only).  Process-global, not thread-safe; the product path never calls them. */
+#ifdef REVO_EXPERIMENTS
+/* Kernel-variant selection and timing experiments: compiled only into librevo_exp.so (`make exp`: the same sources
+ * with -DREVO_EXPERIMENTS; used by scripts/ and by the forced-tile runs of tests/test_gpu_kernels.py), never into
+ * librevo.so, whose kernels are chosen by its size heuristics alone.  Process-global, not thread-safe.
+ * Every variant computes the same result (split-K changes the fp32 summation order only). */
 /* 0 = size heuristic (default), 128 or 256 = force that GEMM tile */
 int32_t revo_op_set_gemm_tile(int32_t tile);
 /* bits 4-7 = force the XCD arrangement (N-stripes 1, 2, 4 or 8; 0 = heuristic), bits 8-11 = force the attention
@@ -180,9 +183,7 @@ int32_t revo_op_set_gemm_tile(int32_t tile);
  * 256 x 256 GEMM, bit 17 = no split-K for the leftover rows of a residual GEMM, bit 18 = 256 x 256 tiles also for
  * problems with fewer than 100 of them; 0 = normal */
 int32_t revo_op_set_variant(int32_t flags);
-#ifdef REVO_EXPERIMENTS
-/* Timing experiments: compiled only into librevo_exp.so (`make exp`, used by scripts/), never into librevo.so.
- * The variant bits above plus: bit 0 = skip the GEMM epilogue stores, bit 1 = skip the GEMM main loop,
+/* Timing experiments.  The variant bits above plus: bit 0 = skip the GEMM epilogue stores, bit 1 = skip the GEMM main loop,
  * bit 13 = skip the scan's selection, bit 15 = skip the scan's slow path (all four: WRONG RESULTS),
  * bit 14 = count scan events for revo_debug_scan_stats. */
 int32_t revo_op_set_gemm_debug(int32_t flags);

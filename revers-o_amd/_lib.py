@@ -63,8 +63,6 @@ SIGNATURES = {
     "revo_topk_merge_packed": (_i32, [_p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p, _p, _p, _p]),
     "revo_op_gemm": (_i32, [_i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p]),
     "revo_op_gemm_rope": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
-    "revo_op_set_gemm_tile": (_i32, [_i32]),
-    "revo_op_set_variant": (_i32, [_i32]),
     "revo_op_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i64, _i32, _p]),
     "revo_op_rope": (_i32, [_p, _i64, _p, _i32, _i32, _i32, _i32, _p]),
     "revo_op_attention": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),
@@ -77,10 +75,13 @@ SIGNATURES = {
 
 # only in librevo_exp.so (built by `make exp` with -DREVO_EXPERIMENTS; timing scripts under scripts/)
 EXPERIMENT_SIGNATURES = {
+    "revo_op_set_gemm_tile": (_i32, [_i32]),
+    "revo_op_set_variant": (_i32, [_i32]),
     "revo_op_set_gemm_debug": (_i32, [_i32]),
     "revo_debug_scan_stats": (_i32, [C.POINTER(C.c_int64)]),
     "revo_debug_read_workspace": (_i64, [_p, _i64, _i64, _p]),
 }
+BASE_SIGNATURES = dict(SIGNATURES)
 if os.environ.get("REVO_LIBRARY_PATH"):            # bisecting / A-B runs of another build of the same ABI
     LIB_PATH = os.environ["REVO_LIBRARY_PATH"]
 elif os.environ.get("REVO_EXPERIMENTS") == "1":
@@ -89,6 +90,27 @@ if os.environ.get("REVO_EXPERIMENTS") == "1":
     SIGNATURES = dict(SIGNATURES, **EXPERIMENT_SIGNATURES)
 
 _lib = None
+_lib_exp = None
+
+
+def load_exp():
+    """librevo_exp.so next to the product library: the same sources built with -DREVO_EXPERIMENTS, i.e. the whole ABI plus
+    the kernel-variant and timing switches (tests of forced GEMM tiles, scripts/).  A separate library with its own
+    state: handles must stay with the library that created them."""
+    global _lib_exp
+    if _lib_exp is not None:
+        return _lib_exp
+    import torch  # noqa: F401
+    path = os.path.join(_HERE, "librevo_exp.so")
+    if not os.path.exists(path):
+        raise RevoError(f"{path} not found: build it with `make -C revers-o_amd/csrc exp`")
+    lib = C.CDLL(path)
+    for name, (res, args) in dict(BASE_SIGNATURES, **EXPERIMENT_SIGNATURES).items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib_exp = lib
+    return lib
 
 
 def load():
@@ -116,6 +138,8 @@ def load():
 def check(rc, what=""):
     if rc != 0:
         msg = load().revo_last_error().decode("utf-8", "replace")
+        if _lib_exp is not None:       # the experiment library keeps its own (thread-local) message
+            msg = (msg + " | " if msg else "") + _lib_exp.revo_last_error().decode("utf-8", "replace")
         raise RevoError(f"{what} failed (status {rc}): {msg}")
 
 

@@ -1003,19 +1003,17 @@ extern "C" int32_t revo_op_gemm(int32_t epi, const void* a, int64_t lda, const v
                                 void* stream) {
     API_BEGIN
     REVO_REQUIRE(epi >= 0 && epi <= 3, "op_gemm: epilogue must be 0..3");
-    // the residual epilogue may cut the K range of its last, partly filled round of tiles (split-K
-    // tail): give it the scratch the ViT forward would (there: the idle qkv buffer)
-    static float* op_ws[16] = {};                     // one per device, allocated on first use, never freed
+    // the residual epilogue may cut the K range of its last, partly filled round of tiles (split-K tail): give it
+    // the scratch the ViT forward would, for the duration of this call (stream-ordered allocation: nothing is kept
+    // by the library between calls, nothing waits)
     constexpr long OP_WS_ELEMS = 16l << 20;
-    int dev = 0;
-    REVO_HIP_CHECK(hipGetDevice(&dev));
+    hipStream_t st = (hipStream_t)stream;
     float* ws = nullptr;
-    if (epi == revo::EPI_RESID_F32 && dev >= 0 && dev < 16) {
-        if (!op_ws[dev]) REVO_HIP_CHECK(hipMalloc((void**)&op_ws[dev], OP_WS_ELEMS * 4));
-        ws = op_ws[dev];
-    }
-    return gemm("gemm_op", epi, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, m, n, k, c, ldc, bias, gamma,
-                (hipStream_t)stream, ws, OP_WS_ELEMS);
+    if (epi == revo::EPI_RESID_F32) REVO_HIP_CHECK(hipMallocAsync((void**)&ws, OP_WS_ELEMS * 4, st));
+    const int rc = gemm("gemm_op", epi, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, m, n, k, c, ldc, bias, gamma, st, ws,
+                        ws ? OP_WS_ELEMS : 0);
+    if (ws) REVO_HIP_CHECK(hipFreeAsync(ws, st));
+    return rc;
     API_END
 }
 extern "C" int32_t revo_op_gemm_rope(const void* a, int64_t lda, const void* b, int64_t ldb, int32_t m, int32_t n,
@@ -1028,7 +1026,8 @@ extern "C" int32_t revo_op_gemm_rope(const void* a, int64_t lda, const void* b, 
     return revo::launch_gemm(revo::EPI_BF16_ROPE, g, (hipStream_t)stream);
     API_END
 }
-// result-preserving kernel-variant switches (test hooks; see revo.h)
+#ifdef REVO_EXPERIMENTS
+// result-preserving kernel-variant switches (librevo_exp.so only; see revo.h)
 extern "C" int32_t revo_op_set_variant(int32_t flags) {
     revo::gemm_force_gy((flags >> 4) & 15);
     revo::attention_force_nw((flags >> 8) & 15);
@@ -1038,7 +1037,11 @@ extern "C" int32_t revo_op_set_variant(int32_t flags) {
     revo::gemm_set_min_tiles256(((flags >> 18) & 1) ? 0 : 100);
     return 0;
 }
-#ifdef REVO_EXPERIMENTS
+extern "C" int32_t revo_op_set_gemm_tile(int32_t tile) {
+    REVO_REQUIRE(tile == 0 || tile == 128 || tile == 256, "set_gemm_tile: 0, 128 or 256");
+    revo::gemm_force_tile(tile);
+    return 0;
+}
 // timing experiments (librevo_exp.so only): the variant bits plus the switches that skip work
 extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
     revo::gemm_set_debug(flags & 3);
@@ -1062,11 +1065,6 @@ extern "C" int32_t revo_debug_scan_stats(int64_t* out4) {
     return 0;
 }
 #endif
-extern "C" int32_t revo_op_set_gemm_tile(int32_t tile) {
-    REVO_REQUIRE(tile == 0 || tile == 128 || tile == 256, "set_gemm_tile: 0, 128 or 256");
-    revo::gemm_force_tile(tile);
-    return 0;
-}
 extern "C" int32_t revo_op_layernorm(const float* x, int64_t ldx, const float* w, const float* b, float eps,
                                      int32_t rows, int32_t width, void* out, int64_t ldo, int32_t out_is_bf16,
                                      void* stream) {

@@ -145,7 +145,7 @@ struct Collect256Args {
     const bf16_t* Qb; long ldq;   // compacted bf16 query rows of the uncertified entries
     const bf16_t* Gb; long ldg;
     long N; int D;
-    int splits;                   // set by the launcher
+    int splits, small_modes;      // set by the launcher
     const int* n_q;               // device: number of entries (query tiles past it exit)
     const float* lb;              // [entries] bf16-score bound
     int* cnt;                     // [entries] rows appended

@@ -805,6 +805,9 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_collect256_kernel(Collec
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = tid & 63;
     const int nq = *p.n_q;
+    // three instantiations are launched when the search has more than 64 queries; the entry count picks the one that
+    // works: <= 64 entries run at the HBM rate (ROWS = 64), <= 128 nearly (ROWS = 128), more at the MFMA rate
+    if (ROWS == 64 ? nq > 64 : (ROWS == 128 ? (nq <= 64 || nq > 128) : (nq <= 128 && p.small_modes))) return;
     const int sp = blockIdx.x;                              // one workgroup per gallery slice; it walks the query tiles
     const long tiles = (p.N + 255) / 256;
     const long per = tiles / p.splits, rem = tiles - per * p.splits;
@@ -949,9 +952,10 @@ int launch_topk_collect256(const Collect256Args& a_in, int max_queries, hipStrea
         REVO_FUNC_LDS((topk_collect256_kernel<RW>), C256_LDS);                                    \
         hipLaunchKernelGGL((topk_collect256_kernel<RW>), grid, block, C256_LDS, st, a);           \
     } while (0)
-    if (max_queries <= 64) C256_LAUNCH(64);
-    else if (max_queries <= 128) C256_LAUNCH(128);
-    else C256_LAUNCH(0);
+    a.small_modes = 1;
+    C256_LAUNCH(64);
+    if (max_queries > 64) C256_LAUNCH(128);
+    if (max_queries > 128) C256_LAUNCH(0);
 #undef C256_LAUNCH
     REVO_HIP_CHECK(hipGetLastError());
     return 0;

@@ -1,6 +1,7 @@
 """Micro-benchmark of the bf16 MFMA GEMM kernels through the C ABI (revo_op_gemm).
     python scripts/gemm_bench.py [M N K epi]...   (default: a sweep)"""
 import os, sys, json
+os.environ.setdefault("REVO_EXPERIMENTS", "1")   # the tile switch lives in librevo_exp.so (make -C revers-o_amd/csrc exp)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import reverso_amd

@@ -157,8 +157,6 @@ int main() {
     EXPECT(revo_search_stats(nullptr, nullptr, nullptr) == -2);
 
     // ---- single kernels and hooks: argument checks that do not need a device
-    EXPECT(revo_op_set_gemm_tile(64) == -2 && revo_op_set_gemm_tile(0) == 0);
-    EXPECT(revo_op_set_variant(0) == 0);
     EXPECT(revo_op_gemm(9, nullptr, 0, nullptr, 0, 1, 1, 64, nullptr, 0, nullptr, nullptr, nullptr) == -2);
     {
         char buf[4];

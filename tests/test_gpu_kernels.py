@@ -16,12 +16,25 @@ pytestmark = pytest.mark.gpu
 EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32 = 0, 1, 2, 3
 
 
-@pytest.fixture(params=[128, 256], autouse=True)
-def gemm_tile(request, lib):
-    """Every test in this file runs once per GEMM tile configuration."""
-    _lib.check(lib.revo_op_set_gemm_tile(request.param))
-    yield request.param
-    _lib.check(lib.revo_op_set_gemm_tile(0))
+@pytest.fixture(params=[0, 128, 256], autouse=True)
+def gemm_tile(request):
+    """Every test in this file runs once per GEMM tile configuration: 0 = the product library (librevo.so) with its
+    size heuristic in charge; 128 / 256 = that tile forced.  The force / variant switches are not part of the product
+    ABI: they exist only in librevo_exp.so (`make exp`, the same sources with -DREVO_EXPERIMENTS), which the forced
+    runs load instead."""
+    return request.param
+
+
+@pytest.fixture
+def lib(gemm_tile):
+    if gemm_tile == 0:
+        yield _lib.load()
+        return
+    exp = _lib.load_exp()
+    _lib.check(exp.revo_op_set_gemm_tile(gemm_tile))
+    yield exp
+    _lib.check(exp.revo_op_set_gemm_tile(0))
+    _lib.check(exp.revo_op_set_variant(0))
 
 
 def _gemm(lib, epi, a, b, c, bias=None, gamma=None):
@@ -220,9 +233,8 @@ def test_attention_huge_logits(lib, dev, S, hd, scale):
 def test_gemm_skinny_all_epilogues(lib, dev, gemm_tile, M, N, K):
     """M <= 64 with the tile heuristic in charge (tile 0) goes to the skinny kernel: all four
     epilogues against an fp32 reference.  Runs once (not per forced tile)."""
-    if gemm_tile != 128:
-        pytest.skip("heuristic path: one run is enough")
-    _lib.check(lib.revo_op_set_gemm_tile(0))
+    if gemm_tile != 0:
+        pytest.skip("heuristic path: runs once, on the product library")
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g).to(dev).bfloat16()
     b = (torch.randn(N, K, generator=g) * 0.1).to(dev).bfloat16()
@@ -289,7 +301,7 @@ def test_gemm_splitk_tail_residual(lib, dev, gemm_tile, M, N, K):
     range cut across CUs (fp32 partial planes + a fixed-order reduce).  Same result as with the split
     disabled up to fp32 summation order, deterministic run to run, and right against an fp32 reference."""
     if gemm_tile != 128:
-        pytest.skip("heuristic path: one run is enough")
+        pytest.skip("heuristic path with variant switches: one run on the experiment library is enough")
     _lib.check(lib.revo_op_set_gemm_tile(0))
     g = torch.Generator(device=dev).manual_seed(M + K)
     a = torch.randn(M, K, generator=g, device=dev).bfloat16()
@@ -317,9 +329,8 @@ def test_gemm_splitk_tail_residual(lib, dev, gemm_tile, M, N, K):
 def test_gemm_128x64_variant_all_epilogues(lib, dev, gemm_tile, M, N, K):
     """Between 128 and 384 tiles of 128 x 128 (about one per CU) the heuristic takes 128 x 64 tiles so that
     several workgroups share a CU.  All four epilogues against an fp32 reference."""
-    if gemm_tile != 128:
-        pytest.skip("heuristic path: one run is enough")
-    _lib.check(lib.revo_op_set_gemm_tile(0))
+    if gemm_tile != 0:
+        pytest.skip("heuristic path: runs once, on the product library")
     g = torch.Generator(device=dev).manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g, device=dev).bfloat16()
     b = (torch.randn(N, K, generator=g, device=dev) * 0.1).bfloat16()
@@ -343,9 +354,8 @@ def test_gemm_128x64_variant_all_epilogues(lib, dev, gemm_tile, M, N, K):
 def test_gemm_random_shapes_through_the_heuristic(lib, dev, gemm_tile):
     """Seeded random problem sizes with the tile heuristic in charge: whatever kernel family a size lands in
     (skinny, 128 x 64, 128 x 128, 256 x 256 per tile or persistent, split-K) must agree with an fp32 reference."""
-    if gemm_tile != 128:
-        pytest.skip("heuristic path: one run is enough")
-    _lib.check(lib.revo_op_set_gemm_tile(0))
+    if gemm_tile != 0:
+        pytest.skip("heuristic path: runs once, on the product library")
     rng = np.random.default_rng(2025)
     for case in range(40):
         M = int(rng.choice([1, 3, 17, 64, 65, 127, 128, 300, 577, 1024, 1154, 2308, 4160, 9232]))
@@ -380,9 +390,8 @@ def test_gemm_random_shapes_through_the_heuristic(lib, dev, gemm_tile):
 def test_gemm_repeat_determinism_large_grids(lib, dev, gemm_tile):
     """Every kernel family, grids larger than one resident set of workgroups: the same call five times
     must give the same bits (no timing-dependent reads)."""
-    if gemm_tile != 128:
-        pytest.skip("heuristic path: one run is enough")
-    _lib.check(lib.revo_op_set_gemm_tile(0))
+    if gemm_tile != 0:
+        pytest.skip("heuristic path: runs once, on the product library")
     g = torch.Generator(device=dev).manual_seed(77)
     for (M, N, K) in [(1970, 2304, 768), (2364, 3072, 768), (2167, 768, 3072), (4160, 1024, 1024), (9000, 1024, 4096),
                       (36928, 1024, 1024), (64, 4096, 1024), (1000, 4096, 512)]:
