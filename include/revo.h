@@ -70,7 +70,7 @@ int32_t revo_vit_forward(revo_vit* vit, const void* images, int32_t image_dtype,
 int32_t revo_vit_set_debug_layers(revo_vit* vit, int32_t n_layers);
 int32_t revo_vit_read_residual(revo_vit* vit, int32_t batch, float* dst, void* stream);
 /* other intermediate buffers of the last forward (device to device): which = 0 the residual stream (fp32 [batch*seq, width]),
- * 1 the output of the last LayerNorm -- ln_post after a whole forward -- (bf16 [batch*seq, width]), 2 the attention-pool
+ * 1 the ln_post output after a whole forward (fp32 [batch*seq, width]: the head works in fp32), 2 the attention-pool
  * output after its MLP residual, before proj (fp32 [batch, width]) */
 int32_t revo_vit_read_tap(revo_vit* vit, int32_t which, int32_t batch, void* dst, void* stream);
 int32_t revo_vit_seq_len(const revo_vit* vit);

@@ -140,7 +140,7 @@ def encode_image(params, cfg, images, taps=None):
     tap("embed", x)
     x = layer_norm(x, p["visual.ln_pre.weight"], p["visual.ln_pre.bias"], cfg.ln_eps)
     tap("ln_pre", x)
-    ang = rope_angles(cfg, dt)
+    ang = rope_angles(cfg, dt).to(images.device)      # (the oracle also runs on a device tensor: tests/test_gpu_l14_error_budget.py)
     for i in range(cfg.layers):
         pre = f"visual.transformer.resblocks.{i}."
         h = layer_norm(x, p[pre + "ln_1.weight"], p[pre + "ln_1.bias"], cfg.ln_eps)

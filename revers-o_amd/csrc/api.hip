@@ -177,13 +177,16 @@ struct revo_vit {
     bf16_t* w_patch = nullptr; float *cls = nullptr, *pos = nullptr, *lnpre_w = nullptr, *lnpre_b = nullptr,
             *lnpost_w = nullptr, *lnpost_b = nullptr;
     std::vector<LayerW> layers;
-    float* q_probe = nullptr; bf16_t* w_kv = nullptr; float* b_kv = nullptr; bf16_t* w_po = nullptr; float* b_po = nullptr;
-    float *pln_w = nullptr, *pln_b = nullptr; bf16_t* w_pfc1 = nullptr; float* b_pfc1 = nullptr; bf16_t* w_pfc2 = nullptr;
-    float* b_pfc2 = nullptr; bf16_t* w_proj = nullptr; float2* rope_cs = nullptr;
+    // attention-pool head, all fp32 (head.hip): probe query folded into the key projection (qk, ck), value / out / MLP /
+    // proj weights as uploaded
+    float *q_probe = nullptr, *qk = nullptr, *ck = nullptr, *w_v = nullptr, *b_v = nullptr, *w_po = nullptr, *b_po = nullptr;
+    float *pln_w = nullptr, *pln_b = nullptr, *w_pfc1 = nullptr, *b_pfc1 = nullptr, *w_pfc2 = nullptr, *b_pfc2 = nullptr,
+          *w_projT = nullptr;
+    float2* rope_cs = nullptr;
     // workspace
-    bf16_t *patches = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr, *pool_att = nullptr,
-           *pool_h = nullptr, *pool_m = nullptr, *pool_ob = nullptr;
-    float *x = nullptr, *pool_o = nullptr, *feat = nullptr;
+    bf16_t *patches = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
+    float *x = nullptr, *pool_logits = nullptr, *pool_u = nullptr, *pool_att = nullptr, *pool_o = nullptr, *pool_h = nullptr,
+          *pool_m = nullptr, *feat = nullptr;
     float* splitk_ws = nullptr;        // fp32 partial planes of the split-K residual GEMMs
 
     template <class T> int dalloc(T** out, size_t count) {
@@ -302,7 +305,11 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
 
     const revo_tensor* t;
     if (!(t = wm.get("visual.conv1.weight", (int64_t)W * Kreal))) return -2;
-    CHECK_RC(up_bf16(v.get(), stage, t->data, W, Kreal, v->Kp, &v->w_patch));
+    // split-precision patch embedding: rows ( hi | lo | hi ) of w / 255 (elementwise.hip patchify_kernel)
+    CHECK_RC(v->dalloc(&v->w_patch, (size_t)W * 3 * v->Kp));
+    REVO_HIP_CHECK(hipMemcpy(stage, t->data, (size_t)W * Kreal * 4, hipMemcpyDefault));
+    CHECK_RC(revo::launch_split_hi_lo_hi(stage, W, Kreal, 1.0f / 255.0f, v->w_patch, v->Kp, 0));
+    REVO_HIP_CHECK(hipStreamSynchronize(0));
     if (c.use_cls) CHECK_RC(up_f32(v.get(), wm, "visual.class_embedding", W, &v->cls));
     CHECK_RC(up_f32(v.get(), wm, "visual.positional_embedding", (int64_t)S * W, &v->pos));
     CHECK_RC(up_f32(v.get(), wm, "visual.ln_pre.weight", W, &v->lnpre_w));
@@ -335,7 +342,7 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
             CHECK_RC(up_f32(v.get(), wm, p + "ls_2.gamma", W, &L.ls2));
         }
     }
-    // attention-pool head
+    // attention-pool head: fp32 weights; the probe's query and the key projection folded into qk / ck (head.hip)
     {
         const std::string p = "visual.attn_pool.";
         float *probe = nullptr, *wi = nullptr, *bi = nullptr;
@@ -346,26 +353,25 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
         hipLaunchKernelGGL(revo::probe_q_kernel, dim3((W + 3) / 4), dim3(256), 0, 0, wi, bi, probe, W,
                            1.0f / sqrtf((float)v->phd), v->q_probe);
         REVO_HIP_CHECK(hipGetLastError());
-        CHECK_RC(v->dalloc(&v->w_kv, (size_t)2 * W * W));
-        CHECK_RC(revo::launch_f32_to_bf16(wi + (size_t)W * W, W, v->w_kv, W, 2 * W, W, 0));
-        v->b_kv = bi + W;
+        CHECK_RC(v->dalloc(&v->qk, (size_t)c.pool_heads * W));
+        CHECK_RC(v->dalloc(&v->ck, (size_t)c.pool_heads));
+        CHECK_RC(revo::launch_probe_qk(v->q_probe, wi + (size_t)W * W, bi + W, W, c.pool_heads, v->qk, v->ck, 0));
+        v->w_v = wi + (size_t)2 * W * W;
+        v->b_v = bi + 2 * W;
         REVO_HIP_CHECK(hipStreamSynchronize(0));
-        if (!(t = wm.get(p + "attn.out_proj.weight", (int64_t)W * W))) return -2;
-        CHECK_RC(up_bf16(v.get(), stage, t->data, W, W, W, &v->w_po));
+        CHECK_RC(up_f32(v.get(), wm, p + "attn.out_proj.weight", (int64_t)W * W, &v->w_po));
         CHECK_RC(up_f32(v.get(), wm, p + "attn.out_proj.bias", W, &v->b_po));
         CHECK_RC(up_f32(v.get(), wm, p + "layernorm.weight", W, &v->pln_w));
         CHECK_RC(up_f32(v.get(), wm, p + "layernorm.bias", W, &v->pln_b));
-        if (!(t = wm.get(p + "mlp.c_fc.weight", (int64_t)PM * W))) return -2;
-        CHECK_RC(up_bf16(v.get(), stage, t->data, PM, W, W, &v->w_pfc1));
+        CHECK_RC(up_f32(v.get(), wm, p + "mlp.c_fc.weight", (int64_t)PM * W, &v->w_pfc1));
         CHECK_RC(up_f32(v.get(), wm, p + "mlp.c_fc.bias", PM, &v->b_pfc1));
-        if (!(t = wm.get(p + "mlp.c_proj.weight", (int64_t)W * PM))) return -2;
-        CHECK_RC(up_bf16(v.get(), stage, t->data, W, PM, PM, &v->w_pfc2));
+        CHECK_RC(up_f32(v.get(), wm, p + "mlp.c_proj.weight", (int64_t)W * PM, &v->w_pfc2));
         CHECK_RC(up_f32(v.get(), wm, p + "mlp.c_proj.bias", W, &v->b_pfc2));
     }
     if (!(t = wm.get("visual.proj", (int64_t)W * D))) return -2;
-    CHECK_RC(v->dalloc(&v->w_proj, (size_t)D * W));
+    CHECK_RC(v->dalloc(&v->w_projT, (size_t)D * W));
     REVO_HIP_CHECK(hipMemcpy(stage, t->data, (size_t)W * D * 4, hipMemcpyDefault));
-    CHECK_RC(revo::launch_transpose_f32_to_bf16(stage, W, D, v->w_proj, W, 0));
+    CHECK_RC(revo::launch_transpose_f32(stage, W, D, v->w_projT, 0));
     REVO_HIP_CHECK(hipStreamSynchronize(0));
 
     // 2-D rope table: [S][hd/2] (cos, sin); x-axis pairs first, then y-axis; cls row unrotated
@@ -393,17 +399,18 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
 
     // workspace for max_batch images
     const size_t rows = (size_t)max_batch * S, B = (size_t)max_batch;
-    CHECK_RC(v->dalloc(&v->patches, (size_t)max_batch * v->G2 * v->Kp));
+    CHECK_RC(v->dalloc(&v->patches, (size_t)max_batch * v->G2 * 3 * v->Kp));
     CHECK_RC(v->dalloc(&v->x, rows * W));
     CHECK_RC(v->dalloc(&v->h, rows * W));
     CHECK_RC(v->dalloc(&v->qkv, rows * 3 * W));
     CHECK_RC(v->dalloc(&v->att, rows * W));
     CHECK_RC(v->dalloc(&v->mlp, rows * M));
+    CHECK_RC(v->dalloc(&v->pool_logits, B * c.pool_heads * S));
+    CHECK_RC(v->dalloc(&v->pool_u, B * c.pool_heads * W));
     CHECK_RC(v->dalloc(&v->pool_att, B * W));
     CHECK_RC(v->dalloc(&v->pool_o, B * W));
     CHECK_RC(v->dalloc(&v->pool_h, B * W));
     CHECK_RC(v->dalloc(&v->pool_m, B * PM));
-    CHECK_RC(v->dalloc(&v->pool_ob, B * W));
     CHECK_RC(v->dalloc(&v->feat, B * D));
     CHECK_RC(v->dalloc(&v->splitk_ws, SPLITK_WS_ELEMS));
     REVO_HIP_CHECK(hipDeviceSynchronize());
@@ -440,9 +447,9 @@ extern "C" int32_t revo_vit_read_tap(revo_vit* vit, int32_t which, int32_t batch
     size_t bytes = 0;
     switch (which) {
         case 0: src = vit->x; bytes = rows * W * 4; break;                  // fp32 residual stream
-        case 1: src = vit->h; bytes = rows * W * 2; break;                  // bf16 output of the last LayerNorm (ln_post after a full forward)
+        case 1: src = vit->x; bytes = rows * W * 4; break;                  // fp32 ln_post output (in place in the residual buffer; after a whole forward)
         case 2: src = vit->pool_o; bytes = (size_t)batch * W * 4; break;    // fp32 attention-pool output (after its MLP residual, before proj)
-        default: REVO_REQUIRE(false, "read_tap: which must be 0 (residual), 1 (last LayerNorm output, bf16) or 2 (pooled)");
+        default: REVO_REQUIRE(false, "read_tap: which must be 0 (residual), 1 (ln_post output) or 2 (pooled)");
     }
     REVO_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
@@ -469,39 +476,44 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
     using namespace revo;
     // views of the workspace at this range
     struct View {
-        bf16_t *patches, *h, *qkv, *att, *mlp, *pool_att, *pool_h, *pool_m, *pool_ob;
-        float *x, *pool_o, *feat;
+        bf16_t *patches, *h, *qkv, *att, *mlp;
+        float *x, *pool_logits, *pool_u, *pool_att, *pool_o, *pool_h, *pool_m, *feat;
     } w;
     const size_t r0 = (size_t)b0 * S;
-    w.patches = vv->patches + (size_t)b0 * vv->G2 * vv->Kp;
+    const int PH = c.pool_heads;
+    w.patches = vv->patches + (size_t)b0 * vv->G2 * 3 * vv->Kp;
     w.x = vv->x + r0 * W; w.h = vv->h + r0 * W; w.qkv = vv->qkv + r0 * 3 * W; w.att = vv->att + r0 * W;
     w.mlp = vv->mlp + r0 * Md;
+    w.pool_logits = vv->pool_logits + (size_t)b0 * PH * S; w.pool_u = vv->pool_u + (size_t)b0 * PH * W;
     w.pool_att = vv->pool_att + (size_t)b0 * W; w.pool_o = vv->pool_o + (size_t)b0 * W;
     w.pool_h = vv->pool_h + (size_t)b0 * W; w.pool_m = vv->pool_m + (size_t)b0 * PM;
-    w.pool_ob = vv->pool_ob + (size_t)b0 * W; w.feat = vv->feat + (size_t)b0 * D;
+    w.feat = vv->feat + (size_t)b0 * D;
     const size_t img_elems = (size_t)3 * c.image_size * c.image_size;
     const void* images = (const char*)images_all + (size_t)b0 * img_elems * (image_dtype == 1 ? 1 : 4);
     float* out = out_all + (size_t)b0 * D;
     struct FW {
         // names used by the schedule below: workspace from the view, everything else from the handle
-        bf16_t *patches, *h, *qkv, *att, *mlp, *pool_att, *pool_h, *pool_m, *pool_ob;
-        float *x, *pool_o, *feat;
+        bf16_t *patches, *h, *qkv, *att, *mlp;
+        float *x, *pool_logits, *pool_u, *pool_att, *pool_o, *pool_h, *pool_m, *feat;
         int Kp, G2, hd, phd, debug_layers;
         bf16_t* w_patch; float *pos, *cls, *lnpre_w, *lnpre_b, *lnpost_w, *lnpost_b;
         const std::vector<LayerW>& layers;
-        float* q_probe; bf16_t* w_kv; float* b_kv; bf16_t* w_po; float* b_po; float *pln_w, *pln_b;
-        bf16_t* w_pfc1; float* b_pfc1; bf16_t* w_pfc2; float* b_pfc2; bf16_t* w_proj; float2* rope_cs;
-    } fw{w.patches, w.h, w.qkv, w.att, w.mlp, w.pool_att, w.pool_h, w.pool_m, w.pool_ob, w.x, w.pool_o, w.feat,
+        float *qk, *ck, *w_v, *b_v, *w_po, *b_po, *pln_w, *pln_b, *w_pfc1, *b_pfc1, *w_pfc2, *b_pfc2, *w_projT;
+        float2* rope_cs;
+    } fw{w.patches, w.h, w.qkv, w.att, w.mlp, w.x, w.pool_logits, w.pool_u, w.pool_att, w.pool_o, w.pool_h, w.pool_m, w.feat,
          vv->Kp, vv->G2, vv->hd, vv->phd, vv->debug_layers, vv->w_patch, vv->pos, vv->cls, vv->lnpre_w, vv->lnpre_b,
-         vv->lnpost_w, vv->lnpost_b, vv->layers, vv->q_probe, vv->w_kv, vv->b_kv, vv->w_po, vv->b_po, vv->pln_w,
-         vv->pln_b, vv->w_pfc1, vv->b_pfc1, vv->w_pfc2, vv->b_pfc2, vv->w_proj, vv->rope_cs};
+         vv->lnpost_w, vv->lnpost_b, vv->layers, vv->qk, vv->ck, vv->w_v, vv->b_v, vv->w_po, vv->b_po, vv->pln_w,
+         vv->pln_b, vv->w_pfc1, vv->b_pfc1, vv->w_pfc2, vv->b_pfc2, vv->w_projT, vv->rope_cs};
     const FW* v = &fw;
 
-    {   // K1 + K2: patch embed GEMM, position add, cls row
+    {   // K1 + K2: patch embed GEMM in split precision (patchify_kernel: the row of a patch holds its values twice --
+        // exact integers for u8 images -- or as hi | hi | lo; the weight rows are hi | lo | hi of w / 255), position add, cls row
+        const int parts = image_dtype == 1 ? 2 : 3;
         { ProfScope ps("patchify", st);
           CHECK_RC(launch_patchify(images, image_dtype == 1, B, c.image_size, c.patch_size, v->patches, v->Kp, st)); }
         GemmArgs a{};
-        a.A = v->patches; a.lda = v->Kp; a.B = v->w_patch; a.ldb = v->Kp; a.M = B * v->G2; a.N = W; a.K = v->Kp;
+        a.A = v->patches; a.lda = (long)parts * v->Kp; a.B = v->w_patch; a.ldb = 3l * v->Kp; a.M = B * v->G2; a.N = W;
+        a.K = parts * v->Kp;
         a.C = v->x; a.ldc = W; a.pos = v->pos; a.S = S; a.G2 = v->G2; a.cls = c.use_cls ? 1 : 0;
         { ProfScope ps("gemm_patch", st); CHECK_RC(launch_gemm(EPI_PATCH, a, st)); }
         if (c.use_cls) { ProfScope ps("elementwise", st); CHECK_RC(launch_cls_rows(v->x, W, v->cls, v->pos, B, S, W, st)); }
@@ -536,20 +548,22 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
     }
     if (v->debug_layers >= 0) return 0;   // parity hook: residual stream only
 
-    // ln_post -> attention pool -> proj -> normalise
+    // ln_post (fp32, in place) -> attention pool -> proj -> normalise: all fp32 (head.hip says why)
     { ProfScope ps("layernorm", st);
-      CHECK_RC(launch_layernorm(v->x, W, v->lnpost_w, v->lnpost_b, c.ln_eps, rows, W, v->h, W, 1, st)); }
-    CHECK_RC(gemm("gemm_pool_kv", EPI_BF16, v->h, W, v->w_kv, W, rows, 2 * W, W, v->qkv, 2 * W, v->b_kv, nullptr, st));
+      CHECK_RC(launch_layernorm(v->x, W, v->lnpost_w, v->lnpost_b, c.ln_eps, rows, W, v->x, W, 0, st)); }
     { ProfScope ps("pool_attention", st);
-      CHECK_RC(launch_pool_attention(v->q_probe, v->qkv, 2 * W, v->pool_att, W, B, S, c.pool_heads, v->phd, st)); }
-    CHECK_RC(gemm("gemm_pool", EPI_F32, v->pool_att, W, v->w_po, W, B, W, W, v->pool_o, W, v->b_po, nullptr, st));
+      CHECK_RC(launch_pool_head_rows(v->x, W, v->qk, v->ck, B, S, W, PH, v->pool_logits, v->pool_u, st)); }
+    { ProfScope ps("gemm_pool", st);
+      // values: head h's output columns from head h's pooled row
+      CHECK_RC(launch_gemm_f32_skinny(0, v->pool_u, (long)PH * W, W, v->phd, v->w_v, W, v->b_v, B, W, W, v->pool_att, W, st));
+      CHECK_RC(launch_gemm_f32_skinny(0, v->pool_att, W, 0, 0, v->w_po, W, v->b_po, B, W, W, v->pool_o, W, st)); }
     { ProfScope ps("layernorm", st);
-      CHECK_RC(launch_layernorm(v->pool_o, W, v->pln_w, v->pln_b, c.ln_eps, B, W, v->pool_h, W, 1, st)); }
-    CHECK_RC(gemm("gemm_pool", EPI_BF16_GELU, v->pool_h, W, v->w_pfc1, W, B, PM, W, v->pool_m, PM, v->b_pfc1, nullptr, st));
-    CHECK_RC(gemm("gemm_pool", EPI_RESID_F32, v->pool_m, PM, v->w_pfc2, PM, B, W, PM, v->pool_o, W, v->b_pfc2, nullptr, st));
-    { ProfScope ps("elementwise", st); CHECK_RC(launch_f32_to_bf16(v->pool_o, W, v->pool_ob, W, B, W, st)); }
+      CHECK_RC(launch_layernorm(v->pool_o, W, v->pln_w, v->pln_b, c.ln_eps, B, W, v->pool_h, W, 0, st)); }
     float* feat = normalize ? v->feat : out;
-    CHECK_RC(gemm("gemm_pool", EPI_F32, v->pool_ob, W, v->w_proj, W, B, D, W, feat, D, nullptr, nullptr, st));
+    { ProfScope ps("gemm_pool", st);
+      CHECK_RC(launch_gemm_f32_skinny(1, v->pool_h, W, 0, 0, v->w_pfc1, W, v->b_pfc1, B, PM, W, v->pool_m, PM, st));
+      CHECK_RC(launch_gemm_f32_skinny(2, v->pool_m, PM, 0, 0, v->w_pfc2, PM, v->b_pfc2, B, W, PM, v->pool_o, W, st));
+      CHECK_RC(launch_gemm_f32_skinny(0, v->pool_o, W, 0, 0, v->w_projT, W, nullptr, B, D, W, feat, D, st)); }
     if (normalize) {
         ProfScope ps("l2norm", st);
         CHECK_RC(launch_l2norm_rows(v->feat, D, out, D, nullptr, 0, B, D, st));

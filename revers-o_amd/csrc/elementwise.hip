@@ -160,11 +160,20 @@ int launch_layernorm(const float* x, long ldx, const float* w, const float* b, f
 }
 
 // ------------------------------------------------------------- patchify ----
-// Each thread produces 8 consecutive k of one patch row (one 16-byte store).
+// im2col for the SPLIT-PRECISION patch GEMM (api.hip): the row of a patch holds PARTS copies / parts of its Kp values.
+//   u8 images   (PARTS = 2): ( a | a ),            a = 2 v - 255: an odd integer of at most 8 bits, EXACT in bf16
+//                            (ToTensor + Normalize(0.5, 0.5) is (2 v - 255) / 255; the 1 / 255 lives in the weights)
+//   f32 images  (PARTS = 3): ( hi | hi | lo ),     hi = bf16(255 x), lo = bf16(255 x - hi)
+// against weight rows ( hi | lo | hi ) of w / 255: a.w_hi + a.w_lo (+ a_lo.w_hi), accumulated in fp32 by the MFMA
+// chain -- the patch embedding to ~2^-16 instead of 2^-8 for twice (three times) 0.2 % of the tower's FLOPs.  (The
+// embedded tokens feed all 24 blocks: their rounding was a fifth of the residual stream's final error.)
+// Each thread produces 8 consecutive k of one patch row (one 16-byte store per part).
 template <bool U8>
 __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ images, int B, int img, int P, int G,
-                                                       bf16_t* __restrict__ out, long ld) {
-    const int chunks = (int)(ld >> 3);
+                                                       bf16_t* __restrict__ out, long Kp) {
+    constexpr int PARTS = U8 ? 2 : 3;
+    const long ld = Kp * PARTS;
+    const int chunks = (int)(Kp >> 3);
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)B * G * G * chunks;
     if (gid >= total) return;
@@ -183,12 +192,8 @@ __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ 
             const int c = k / PP, rem = k - c * PP;
             const int py = rem / P, px = rem - py * P;
             const long off = (((long)b * 3 + c) * img + (gy * P + py)) * img + (gx * P + px);
-            if (U8) {
-                const float u = (float)((const uint8_t*)images)[off];
-                f = (u / 255.0f - 0.5f) / 0.5f;   // ToTensor then Normalize(0.5, 0.5)
-            } else {
-                f = ((const float*)images)[off];
-            }
+            if (U8) f = 2.0f * (float)((const uint8_t*)images)[off] - 255.0f;
+            else f = ((const float*)images)[off] * 255.0f;
         }
         v[j] = f;
     }
@@ -197,18 +202,33 @@ __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ 
     o.y = pack_bf16x2(v[2], v[3]);
     o.z = pack_bf16x2(v[4], v[5]);
     o.w = pack_bf16x2(v[6], v[7]);
-    *(uint4*)(out + prow * ld + c8 * 8) = o;
+    bf16_t* dst = out + prow * ld + c8 * 8;
+    *(uint4*)dst = o;
+    *(uint4*)(dst + Kp) = o;
+    if (!U8) {
+        const uint32_t hw[4] = {o.x, o.y, o.z, o.w};
+        float lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lo[j] = v[j] - bf16_to_f32((bf16_t)(hw[j >> 1] >> ((j & 1) * 16)));
+        uint4 l;
+        l.x = pack_bf16x2(lo[0], lo[1]);
+        l.y = pack_bf16x2(lo[2], lo[3]);
+        l.z = pack_bf16x2(lo[4], lo[5]);
+        l.w = pack_bf16x2(lo[6], lo[7]);
+        *(uint4*)(dst + 2 * Kp) = l;
+    }
 }
 
-int launch_patchify(const void* images, int is_u8, int B, int img, int P, bf16_t* out, long ld, hipStream_t st) {
+// out rows: [B*G*G][parts * Kp] with parts = 2 (u8) or 3 (f32); see the kernel
+int launch_patchify(const void* images, int is_u8, int B, int img, int P, bf16_t* out, long Kp, hipStream_t st) {
     REVO_REQUIRE(img % P == 0, "patchify: image size must be a multiple of the patch size");
-    REVO_REQUIRE(ld % 8 == 0 && ld >= 3 * P * P, "patchify: bad leading dimension");
+    REVO_REQUIRE(Kp % 8 == 0 && Kp >= 3 * P * P, "patchify: bad part width");
     const int G = img / P;
-    const long total = (long)B * G * G * (ld / 8);
+    const long total = (long)B * G * G * (Kp / 8);
     if (total <= 0) return 0;
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (is_u8) hipLaunchKernelGGL((patchify_kernel<true>), grid, block, 0, st, images, B, img, P, G, out, ld);
-    else hipLaunchKernelGGL((patchify_kernel<false>), grid, block, 0, st, images, B, img, P, G, out, ld);
+    if (is_u8) hipLaunchKernelGGL((patchify_kernel<true>), grid, block, 0, st, images, B, img, P, G, out, Kp);
+    else hipLaunchKernelGGL((patchify_kernel<false>), grid, block, 0, st, images, B, img, P, G, out, Kp);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,271 @@
+// The attention-pool head of the PE tower (K9-K10 of SURVEY.md section 2b; upstream AttentionPooling + proj behind
+// pe_model.encode_image, core_system.py:341/:442) in fp32.
+//
+// Why fp32, and why it costs nothing.  The head works on ONE vector per image: every rounding of that vector goes
+// straight into the embedding, whereas the roundings of the 577 token rows of the body average out in the pooling.
+// Measured on PE-Core-L14-336 against the fp32 oracle (tests/test_gpu_l14_error_budget.py): embedding error 5.97e-3
+// with a bf16 head, of which the 24 blocks of the body account for 3.06e-3 -- the head was the larger half.  And the
+// head's one big GEMM, the K/V projection of all tokens (2.4 GFLOP per image), is not needed at all:
+//   * the pool's query is the learned probe, input independent, so the logits  q_h . (W_k x_s + b_k)  are
+//     (W_k,h^T q_h) . x_s + q_h . b_k,h : one [heads x W] matrix prepared at load time against the ln_post rows;
+//   * the values enter only through the softmax-weighted sum, and  sum_s p_s (W_v x_s + b_v) = W_v (sum_s p_s x_s) + b_v :
+//     pool the ln_post rows first (per head), then ONE skinny fp32 GEMM per image.
+// Both identities are exact in real arithmetic; in fp32 the head now agrees with the oracle to ~1e-6.  What is left
+// are four skinny GEMMs ([batch, W] operands, fp32 weights streamed once: 40 MB for L14) and two passes over the
+// fp32 ln_post rows.
+#include "kernels.h"
+
+namespace revo {
+
+// ---------------------------------------------------------------- load time ----
+// qk[h][i] = sum_{o in head h} q[o] * Wk[o][i],  ck[h] = sum_{o in head h} q[o] * bk[o]     (q already scaled by hd^-1/2)
+__global__ __launch_bounds__(256) void probe_qk_kernel(const float* __restrict__ q, const float* __restrict__ Wk,
+                                                       const float* __restrict__ bk, int W, int heads,
+                                                       float* __restrict__ qk, float* __restrict__ ck) {
+    const int hd = W / heads;
+    const int h = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < W) {
+        float acc = 0.f;
+        for (int o = h * hd; o < (h + 1) * hd; ++o) acc = fmaf(q[o], Wk[(long)o * W + i], acc);
+        qk[(long)h * W + i] = acc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        float acc = 0.f;
+        for (int o = h * hd + (int)threadIdx.x; o < (h + 1) * hd; o += 64) acc = fmaf(q[o], bk[o], acc);
+        acc = wave_sum(acc);
+        if (threadIdx.x == 0) ck[h] = acc;
+    }
+}
+int launch_probe_qk(const float* q, const float* Wk, const float* bk, int W, int heads, float* qk, float* ck, hipStream_t st) {
+    hipLaunchKernelGGL(probe_qk_kernel, dim3((W + 255) / 256, heads), dim3(256), 0, st, q, Wk, bk, W, heads, qk, ck);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ logits ----
+// logits[(b * H + h) * S + s] = qk_h . x[b * S + s] + ck_h ; one wave per token row, the row in registers
+constexpr int PL_MAXH = 16;
+__global__ __launch_bounds__(256) void pool_logits_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ qk,
+                                                          const float* __restrict__ ck, int rows, int S, int W, int H,
+                                                          float* __restrict__ logits) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ldx;
+    float acc[PL_MAXH];
+#pragma unroll
+    for (int h = 0; h < PL_MAXH; ++h) acc[h] = 0.f;
+    for (int c = lane * 4; c < W; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+#pragma unroll
+        for (int h = 0; h < PL_MAXH; ++h) {
+            if (h < H) {
+                const f32x4 w = *(const f32x4*)(qk + (long)h * W + c);
+                acc[h] = fmaf(v[0], w[0], acc[h]);
+                acc[h] = fmaf(v[1], w[1], acc[h]);
+                acc[h] = fmaf(v[2], w[2], acc[h]);
+                acc[h] = fmaf(v[3], w[3], acc[h]);
+            }
+        }
+    }
+    const long b = row / S, s = row - b * S;
+#pragma unroll
+    for (int h = 0; h < PL_MAXH; ++h) {
+        if (h < H) {
+            const float t = wave_sum(acc[h]);
+            if (lane == 0) logits[(b * H + h) * S + s] = t + ck[h];
+        }
+    }
+}
+
+// --------------------------------------------------------------- pooled rows ----
+// u[(b * H + h) * W + c] = sum_s softmax_s(logits[b, h, :])[s] * x[b * S + s][c]
+// grid (W / 64, B): a workgroup owns 64 columns of one image; its four waves take the token rows s = w, w + 4, ...
+// (every element of x is read once, by one lane), each thread carries all H heads; the four partial sums meet in LDS
+// in a fixed order.  The softmax of the image's H x S logits is recomputed by every workgroup (a few thousand exps).
+__global__ __launch_bounds__(256) void pool_accumulate_kernel(const float* __restrict__ x, long ldx,
+                                                              const float* __restrict__ logits, int S, int W, int H,
+                                                              float* __restrict__ u) {
+    extern __shared__ float psm[];                    // [H][S] probabilities, then [4][H][64] partial sums
+    float* red = psm + (long)H * S;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * 64 + lane;
+    for (int h = w; h < H; h += 4) {
+        const float* lg = logits + ((long)b * H + h) * S;
+        float m = -INFINITY;
+        for (int s = lane; s < S; s += 64) m = fmaxf(m, lg[s]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int s = lane; s < S; s += 64) {
+            const float e = expf(lg[s] - m);
+            psm[(long)h * S + s] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int s = lane; s < S; s += 64) psm[(long)h * S + s] *= inv;
+    }
+    __syncthreads();
+    float acc[PL_MAXH];
+#pragma unroll
+    for (int h = 0; h < PL_MAXH; ++h) acc[h] = 0.f;
+    if (c < W) {
+        const float* xc = x + (long)b * S * ldx + c;
+#pragma unroll 4
+        for (int s = w; s < S; s += 4) {
+            const float v = xc[(long)s * ldx];
+#pragma unroll
+            for (int h = 0; h < PL_MAXH; ++h)
+                if (h < H) acc[h] = fmaf(psm[(long)h * S + s], v, acc[h]);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < PL_MAXH; ++h)
+        if (h < H) red[((long)w * H + h) * 64 + lane] = acc[h];
+    __syncthreads();
+    if (c < W)
+        for (int h = w; h < H; h += 4) {
+            const float t = ((red[((long)0 * H + h) * 64 + lane] + red[((long)1 * H + h) * 64 + lane]) +
+                             red[((long)2 * H + h) * 64 + lane]) + red[((long)3 * H + h) * 64 + lane];
+            u[((long)b * H + h) * W + c] = t;
+        }
+}
+int launch_pool_head_rows(const float* x, long ldx, const float* qk, const float* ck, int B, int S, int W, int H,
+                          float* logits, float* u, hipStream_t st) {
+    REVO_REQUIRE(H >= 1 && H <= PL_MAXH && W % 4 == 0 && ldx % 4 == 0, "pool head: at most 16 heads, width a multiple of 4");
+    const long rows = (long)B * S;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(pool_logits_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, qk, ck, (int)rows, S, W, H,
+                       logits);
+    const size_t lds = ((size_t)H * S + 4 * (size_t)H * 64) * 4;
+    REVO_REQUIRE(lds <= 160 * 1024, "pool head: sequence too long for the probability table in LDS");
+    REVO_FUNC_LDS(pool_accumulate_kernel, (int)lds);
+    hipLaunchKernelGGL(pool_accumulate_kernel, dim3((W + 63) / 64, B), dim3(256), lds, st, x, ldx, logits, S, W, H, u);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------- skinny fp32 GEMM ----
+// C[M][N] (+)= epi(A[M][K] . Wt[N][K]^T + bias), everything fp32, M = batch (tens of rows), the weights streamed once.
+// A workgroup owns 16 output columns; its four waves split K; v_mfma_f32_16x16x4_f32 with the operands straight from
+// global memory: a lane loads 16 bytes (4 consecutive k) of its row, and MFMA j of a 16-k chunk contracts the j-th
+// element of every lane's quadruple (any partition of k does: everything is summed).  The waves' partial tiles meet in
+// LDS and are added in a fixed order (deterministic).  Rows are taken 64 at a time.
+// Grouped A (the value projection of the pool): output columns [g * group_cols, (g + 1) * group_cols) read their A rows
+// at A + g * a_group_stride (one pooled row per head).
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+template <int EPI>   // 0: C = acc + bias, 1: C = gelu_erf(acc + bias), 2: C += acc + bias
+__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const float* __restrict__ A, long lda, long a_group_stride,
+                                                              int group_cols, const float* __restrict__ Wt, long ldw,
+                                                              const float* __restrict__ bias, int M, int N, int K,
+                                                              float* __restrict__ C, long ldc) {
+    __shared__ float part[4][64][17];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const float* Ab = A + (group_cols > 0 ? (long)(n0 / group_cols) * a_group_stride : 0);
+    const int nr = n0 + r < N ? n0 + r : N - 1;                      // a ragged last column block re-reads a valid row
+    const float* wrow = Wt + (long)nr * ldw + kq * 4;
+    const int kper = ((K / 16 + 3) / 4) * 16;                        // k range of a wave, a multiple of 16
+    const int k0 = w * kper, k1 = (k0 + kper) < K ? (k0 + kper) : K;
+    for (int m0 = 0; m0 < M; m0 += 64) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* arow[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int m = m0 + mb * 16 + r;
+            arow[mb] = Ab + (long)(m < M ? m : M - 1) * lda + kq * 4;
+        }
+        for (int k = k0; k < k1; k += 16) {
+            const f32x4 wv = *(const f32x4*)(wrow + k);
+            f32x4 av[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) av[mb] = *(const f32x4*)(arow[mb] + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], av[mb][j], acc[mb], 0, 0, 0);
+        }
+        // lane holds C[row mb*16 + (lane & 15)][cols (lane >> 4) * 4 + 0..3] of its K share
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) part[w][mb * 16 + r][kq * 4 + v] = acc[mb][v];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+            const int row = e >> 4, col = e & 15;
+            const int m = m0 + row, n = n0 + col;
+            if (m < M && n < N) {
+                float t = ((part[0][row][col] + part[1][row][col]) + part[2][row][col]) + part[3][row][col];
+                if (bias) t += bias[n];
+                float* cp = C + (long)m * ldc + n;
+                if (EPI == 1) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));
+                if (EPI == 2) t += *cp;
+                *cp = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+int launch_gemm_f32_skinny(int epi, const float* A, long lda, long a_group_stride, int group_cols, const float* Wt, long ldw,
+                           const float* bias, int M, int N, int K, float* C, long ldc, hipStream_t st) {
+    REVO_REQUIRE(epi >= 0 && epi <= 2, "fp32 gemm: epilogue 0..2");
+    REVO_REQUIRE(K % 16 == 0 && lda % 4 == 0 && ldw % 4 == 0, "fp32 gemm: K must be a multiple of 16, rows 16-byte aligned");
+    REVO_REQUIRE(group_cols == 0 || (group_cols % 16 == 0 && a_group_stride % 4 == 0), "fp32 gemm: bad A grouping");
+    if (M <= 0 || N <= 0) return 0;
+    const dim3 grid((unsigned)((N + 15) / 16)), block(256);
+    if (epi == 0) hipLaunchKernelGGL((gemm_f32_skinny_kernel<0>), grid, block, 0, st, A, lda, a_group_stride, group_cols, Wt, ldw, bias, M, N, K, C, ldc);
+    else if (epi == 1) hipLaunchKernelGGL((gemm_f32_skinny_kernel<1>), grid, block, 0, st, A, lda, a_group_stride, group_cols, Wt, ldw, bias, M, N, K, C, ldc);
+    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<2>), grid, block, 0, st, A, lda, a_group_stride, group_cols, Wt, ldw, bias, M, N, K, C, ldc);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// dst[c][r] = src[r][c]  (fp32; visual.proj is stored [W][D], the GEMMs want [D][W])
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, int rows, int cols,
+                                                            float* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = src[(long)(r0 + i) * cols + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) dst[(long)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+int launch_transpose_f32(const float* src, int rows, int cols, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, src, rows, cols, dst);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// fp32 [rows][cols] -> bf16 [rows][3 * ld]: ( hi | lo | hi ) of scale * src, hi = bf16(v), lo = bf16(v - hi), zero padded
+// to ld per part: the patch-embedding weights for the split-precision patch GEMM (api.hip)
+__global__ __launch_bounds__(256) void split_hi_lo_hi_kernel(const float* __restrict__ src, long rows, int cols, float scale,
+                                                             bf16_t* __restrict__ dst, long ld) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * ld) return;
+    const long r = i / ld;
+    const int c = (int)(i - r * ld);
+    bf16_t hi = 0, lo = 0;
+    if (c < cols) {
+        const float v = src[r * cols + c] * scale;
+        hi = f32_to_bf16(v);
+        lo = f32_to_bf16(v - bf16_to_f32(hi));
+    }
+    bf16_t* d = dst + r * 3 * ld;
+    d[c] = hi; d[ld + c] = lo; d[2 * ld + c] = hi;
+}
+int launch_split_hi_lo_hi(const float* src, long rows, int cols, float scale, bf16_t* dst, long ld, hipStream_t st) {
+    const long n = rows * ld;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(split_hi_lo_hi_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, rows, cols, scale, dst, ld);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace revo

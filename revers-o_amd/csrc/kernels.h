@@ -48,9 +48,21 @@ void gemm_force_tile(int t);   // 0 = heuristic, 128 or 256 = forced
 // out = LayerNorm(x) * w + b over rows of width W (fp32 statistics, two-pass).
 int launch_layernorm(const float* x, long ldx, const float* w, const float* b, float eps, int rows, int W,
                      void* out, long ldo, int out_is_bf16, hipStream_t st);
-// images NCHW (u8: normalised (v/255-0.5)/0.5 on the fly; f32: already normalised)
-// -> im2col matrix [B*G*G][ld] bf16, k = c*P*P + py*P + px, zero padded to ld.
-int launch_patchify(const void* images, int is_u8, int B, int img, int P, bf16_t* out, long ld, hipStream_t st);
+// images NCHW (u8 pixel values; f32: already normalised to [-1, 1]) -> im2col matrix for the split-precision patch GEMM:
+// rows [B*G*G][parts * Kp] bf16, k = c*P*P + py*P + px zero padded to Kp, parts = 2 (u8: the exact integers 2v - 255,
+// twice) or 3 (f32: hi | hi | lo of 255 x); the weights carry the 1/255 (elementwise.hip, head.hip split_hi_lo_hi)
+int launch_patchify(const void* images, int is_u8, int B, int img, int P, bf16_t* out, long Kp, hipStream_t st);
+// ---- the attention-pool head in fp32 (head.hip)
+int launch_probe_qk(const float* q, const float* Wk, const float* bk, int W, int heads, float* qk, float* ck, hipStream_t st);
+// logits [B][H][S] of the probe against the fp32 ln_post rows x, then u [B][H][W] = softmax-weighted sums of the rows
+int launch_pool_head_rows(const float* x, long ldx, const float* qk, const float* ck, int B, int S, int W, int H,
+                          float* logits, float* u, hipStream_t st);
+// C[M][N] (+)= epi(A . Wt^T + bias) in fp32, M small; epi 0 plain, 1 exact-erf GELU, 2 C += ; group_cols > 0: output
+// columns [g * group_cols, ...) read A at A + g * a_group_stride
+int launch_gemm_f32_skinny(int epi, const float* A, long lda, long a_group_stride, int group_cols, const float* Wt, long ldw,
+                           const float* bias, int M, int N, int K, float* C, long ldc, hipStream_t st);
+int launch_transpose_f32(const float* src, int rows, int cols, float* dst, hipStream_t st);
+int launch_split_hi_lo_hi(const float* src, long rows, int cols, float scale, bf16_t* dst, long ld, hipStream_t st);
 // x[b*S + 0][:] = cls + pos[0]
 int launch_cls_rows(float* x, long ldx, const float* cls, const float* pos, int B, int S, int W, hipStream_t st);
 // in-place interleaved-pair rotation of the q and k thirds of qkv [rows][3W]

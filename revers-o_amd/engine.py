@@ -132,21 +132,21 @@ class VitEngine:
 
     def taps(self, images):
         """Parity-test hook: intermediate activations of one forward as fp32 CPU-comparable tensors:
-        ``embed`` [B,S,W] (patch embed + position + class token, before ln_pre), ``ln_post`` [B,S,W] (bf16 in the
-        engine), ``pooled`` [B,W] (attention-pool output before proj) and the ``embedding`` [B,D]."""
+        ``embed`` [B,S,W] (patch embed + position + class token, before ln_pre), ``ln_post`` [B,S,W] (fp32: the head
+        works in fp32), ``pooled`` [B,W] (attention-pool output before proj) and the ``embedding`` [B,D]."""
         _require_cuda(images, "images", self.device)
         B = images.shape[0]
         assert B <= self.max_batch
         cfg = self.cfg
         out = {"embed": self.residual_after(images, -2)}
         emb = self.embed(images)
-        lnp = torch.empty((B, cfg.seq, cfg.width), dtype=torch.bfloat16, device=self.device)
+        lnp = torch.empty((B, cfg.seq, cfg.width), dtype=torch.float32, device=self.device)
         pooled = torch.empty((B, cfg.width), dtype=torch.float32, device=self.device)
         with self._lock, torch.cuda.device(self.device):
             st = _lib.current_stream()
             _lib.check(self._lib.revo_vit_read_tap(self._h, 1, B, _lib.ptr(lnp), st), "revo_vit_read_tap")
             _lib.check(self._lib.revo_vit_read_tap(self._h, 2, B, _lib.ptr(pooled), st), "revo_vit_read_tap")
-        out.update(ln_post=lnp.float(), pooled=pooled, embedding=emb)
+        out.update(ln_post=lnp, pooled=pooled, embedding=emb)
         return out
 
 

@@ -3,7 +3,9 @@ container (minutes of CPU time: the GPU box only reads the .npz files).
 
     python tests/golden/make_golden_l14.py [batch|outlier|crops ...]
 
-* l14_batch64.npz   oracle embeddings of 8 of the 64 images of the headline batch (seeded weights and images).
+* l14_batch64.npz   oracle embeddings of ALL 64 images of the headline batch (seeded weights and images), and for two
+                    of them the residual stream after blocks 6 / 12 / 24, the ln_post output (8 token rows each) and the
+                    pooled vector: the error growth through the tower's depth is visible block by block.
 * l14_outlier.npz   the same tower with injected outlier channels (a few LayerNorm gains of 20, a few
                     residual-stream channels driven ~100x larger by their out-proj / fc2 rows): the regime real
                     ViT checkpoints are in and N(0, 0.02) synthetic weights are not.
@@ -30,7 +32,10 @@ from reverso_amd import weights  # noqa: E402
 from oracle import pe_vit  # noqa: E402
 
 VARIANT = "PE-Core-L14-336"
-BATCH_IDX = [0, 9, 18, 27, 36, 45, 54, 63]
+BATCH_IDX = list(range(64))
+TAP_IMAGES = [0, 63]                                  # images whose intermediate activations are stored
+TAP_TOKENS = [0, 1, 2, 24, 25, 300, 575, 576]         # token rows kept of every tap (class token, corners, middle)
+TAP_BLOCKS = [5, 11, 23]
 
 
 def batch_case():
@@ -99,8 +104,15 @@ def crop_weights():
 def make_batch(path):
     cfg, sd, u8 = batch_case()
     ref = pe_vit.embed(sd, cfg, pe_vit.preprocess_u8(u8[BATCH_IDX]))
-    np.savez_compressed(path, idx=np.array(BATCH_IDX), embedding=ref.numpy(),
-                        image_sum=np.int64(u8.long().sum().item()))
+    taps = {}
+    with torch.no_grad():
+        pe_vit.encode_image(sd, cfg, pe_vit.preprocess_u8(u8[TAP_IMAGES]), taps)
+    extra = {f"tap_block{b}": taps[f"block{b}"][:, TAP_TOKENS].numpy() for b in TAP_BLOCKS}
+    extra["tap_ln_post"] = taps["ln_post"][:, TAP_TOKENS].numpy()
+    extra["tap_pooled"] = taps["pooled"].numpy()
+    np.savez_compressed(path, idx=np.array(BATCH_IDX), embedding=ref.numpy(), tap_images=np.array(TAP_IMAGES),
+                        tap_tokens=np.array(TAP_TOKENS), tap_blocks=np.array(TAP_BLOCKS),
+                        image_sum=np.int64(u8.long().sum().item()), **extra)
 
 
 def make_outlier(path):

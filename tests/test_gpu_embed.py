@@ -3,7 +3,8 @@ the committed golden vectors, layer by layer and end to end.
 
 Tolerances: the product computes matmuls in bf16 with fp32 accumulation and keeps
 the residual stream in fp32; the oracle is fp32 throughout.  Stated bounds:
-residual stream max|d| <= 3e-2 * max|x| per block, final embedding cosine >= 0.999
+residual stream max|d| <= 3e-2 * max|x| per block, final embedding cosine >= 0.9999 and centred cosine >= 0.99
+(tests/_parity.py)
 and cosine scores against a gallery within 1e-3 (north_star)."""
 import os
 import sys
@@ -20,6 +21,8 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 import make_golden  # noqa: E402
+sys.path.insert(0, HERE)
+from _parity import assert_embeddings_match  # noqa: E402
 
 
 def _gold(name):
@@ -51,8 +54,7 @@ def test_tiny_vit_layer_by_layer(dev, fname, cname):
         assert np.abs(taps["embed"][:, 0].cpu().numpy() - ref0[None]).max() <= 1e-6
     emb = eng.embed(img).cpu().numpy()
     ref = gold["embedding"]
-    cos = (emb * ref).sum(-1)
-    assert np.all(cos >= 0.999), cos
+    assert_embeddings_match(emb, ref, what=cname)
     assert np.abs(np.linalg.norm(emb, axis=-1) - 1).max() < 1e-5
     un = eng.embed(img, normalize=False).cpu().numpy()
     refun = gold["tap_proj"]
@@ -67,9 +69,12 @@ def test_uint8_input_matches_float_preprocess(dev):
     u8 = torch.randint(0, 256, (5, 3, cfg.image_size, cfg.image_size), generator=g, dtype=torch.uint8)
     e_u8 = eng.embed(u8.to(dev)).cpu()
     e_f = eng.embed(pe_vit.preprocess_u8(u8).to(dev)).cpu()
-    assert torch.equal(e_u8, e_f)                       # same bf16 patch matrix either way
+    # uint8 pixels enter the patch GEMM as exact integers, float images as hi + lo bf16 parts: the embedded tokens agree
+    # to ~1e-6, and where that flips a bf16 rounding further down the tower the embeddings differ by bf16 noise
+    assert (e_u8 - e_f).abs().max().item() <= 1e-3 and ((e_u8 * e_f).sum(-1) >= 0.99999).all()
     ref = pe_vit.embed(sd, cfg, pe_vit.preprocess_u8(u8))
-    assert ((e_u8 * ref).sum(-1) >= 0.999).all()
+    assert_embeddings_match(e_u8, ref)
+    assert_embeddings_match(e_f, ref)
     # batching: max_batch chunks and batch-1 calls give identical rows
     eng2 = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=2)
     e2 = eng2.embed(u8.to(dev)).cpu()
@@ -90,7 +95,7 @@ def test_b16_single_block_golden(dev):
     assert np.abs(x0 - gold["ln_pre"]).max() <= 3e-2 * np.abs(gold["ln_pre"]).max()
     assert np.abs(x1 - gold["block0"]).max() <= 3e-2 * np.abs(gold["block0"]).max()
     emb = eng.embed(images.to(dev)).cpu().numpy()
-    assert (emb * gold["embedding"]).sum() >= 0.999
+    assert (emb * gold["embedding"]).sum() >= 0.9999
     eng.close()
 
 
@@ -105,8 +110,7 @@ def test_b16_full_depth_vs_oracle(dev):
     ref = pe_vit.embed(sd, cfg, pe_vit.preprocess_u8(u8))
     eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=8)
     emb = eng.embed(u8.to(dev)).cpu()
-    cos = (emb * ref).sum(-1)
-    assert (cos >= 0.999).all(), cos
+    assert_embeddings_match(emb, ref, what="B16")
     # cosine scores of the embeddings against a fixed random gallery agree to 1e-3
     gal = torch.nn.functional.normalize(torch.randn(2000, cfg.out_dim, generator=g), dim=-1)
     assert ((emb @ gal.T) - (ref @ gal.T)).abs().max().item() <= 1e-3
@@ -129,7 +133,7 @@ def test_g14_shape_family_single_block(dev):
     eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=2)
     emb = eng.embed(u8.to(dev)).cpu()
     assert emb.shape == (2, 1280)
-    assert ((emb * ref).sum(-1) >= 0.999).all(), (emb * ref).sum(-1)
+    assert_embeddings_match(emb, ref, what="G14 2 blocks")
     eng.close()
 
 
@@ -161,8 +165,7 @@ def test_l14_headline_batch_vs_oracle_and_batch_invariance(dev):
     assert torch.isfinite(emb).all()
     assert ((emb.norm(dim=-1) - 1).abs() <= 1e-5).all()
     ref = pe_vit.embed(sd, cfg, pe_vit.preprocess_u8(u8[[0, 63]]))
-    cos = (emb[[0, 63]] * ref).sum(-1)
-    assert (cos >= 0.999).all(), cos
+    assert_embeddings_match(emb[[0, 63]], ref, what="L14 batch 64")
     gal = torch.nn.functional.normalize(torch.randn(2000, cfg.out_dim, generator=g), dim=-1)
     assert ((emb[[0, 63]] @ gal.T) - (ref @ gal.T)).abs().max().item() <= 1e-3
     one = eng.embed(u8[5:6].to(dev)).cpu()

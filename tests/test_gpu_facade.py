@@ -67,7 +67,7 @@ def test_config1_b16_32_jpegs_top5(system):
     stored = r.vector_db.gallery.read().cpu().numpy()
     order = [r.vector_db.payloads[i]["filename"] for i in range(32)]
     assert order == [os.path.basename(p) for p in files]
-    assert ((stored * ref).sum(-1) >= 0.999).all()
+    assert ((stored * ref).sum(-1) >= 0.9999).all()
 
     # query = one gallery image, reference flow: process_image_direct_pe then search_similar
     q = 7

@@ -1,14 +1,16 @@
 """The headline tower (PE-Core-L14-336) against oracle outputs that were computed in the build container
 (tests/golden/make_golden_l14.py: minutes of CPU time, so the GPU box compares with the committed vectors):
 
-* 8 of the 64 images of the headline batch (persistent 256 x 256 GEMMs, split-K tails, 8-wave attention);
+* all 64 images of the headline batch (persistent 256 x 256 GEMMs, split-K tails, 8-wave attention), two of them
+  with per-block activations;
 * the same tower with injected outlier channels (LayerNorm gains of 20, residual channels ~100x larger),
   the regime of trained checkpoints;
 * BASELINE.json configs[2] end to end through the facade: 64 JPEGs x 3 detector boxes -> device crop + resize ->
   PE-L14 embed -> gallery -> search (core_system.py:406, :541-591), every stored vector against the oracle's
   embedding of the PIL crop.
 
-Tolerances: cosine(GPU, oracle) >= 0.999 and cosine scores against a probe gallery within 1e-3 (north_star)."""
+Tolerances: cosine(GPU, oracle) >= 0.9999, centred cosine >= 0.99 (tests/_parity.py) and cosine scores against a probe
+gallery within 1e-3 (north_star) on EVERY pair."""
 import os
 import sys
 
@@ -24,6 +26,8 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 import make_golden_l14 as mg  # noqa: E402
+sys.path.insert(0, HERE)
+from _parity import assert_embeddings_match  # noqa: E402
 
 
 def _gold(name):
@@ -35,21 +39,43 @@ def _probe_gallery(D, n=2000, seed=3):
     return torch.nn.functional.normalize(torch.randn(n, D, generator=g), dim=-1)
 
 
-def test_l14_headline_batch_8_images_vs_golden(dev):
+def test_l14_headline_batch_64_images_vs_golden(dev):
+    """All 64 images of the headline batch against the oracle's embeddings, and for two of them the residual stream after
+    blocks 6 / 12 / 24, the ln_post rows and the pooled vector: where the distance from the oracle comes from, block by
+    block (bf16 operands in the body: it grows like the square root of the depth; the head is fp32 and adds nothing)."""
     gold = _gold("l14_batch64.npz")
     cfg, sd, u8 = mg.batch_case()
     assert int(u8.long().sum()) == int(gold["image_sum"])            # the seeded inputs are the ones the oracle saw
     eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=64)
     emb = eng.embed(u8.to(dev)).cpu()
     idx = gold["idx"].tolist()
+    assert idx == list(range(64))
     ref = torch.from_numpy(gold["embedding"])
-    cos = (emb[idx] * ref).sum(-1)
-    assert (cos >= 0.999).all(), cos
+    stats = assert_embeddings_match(emb[idx], ref, what="L14 headline batch")
+    assert stats["cosine_min"] >= 0.99999 and stats["centred_cosine_min"] >= 0.999, stats     # measured: 0.999995 / 0.9999
     gal = _probe_gallery(cfg.out_dim)
-    assert ((emb[idx] @ gal.T) - (ref @ gal.T)).abs().max().item() <= 1e-3
+    assert ((emb[idx] @ gal.T) - (ref @ gal.T)).abs().max().item() <= 1e-3                    # all 64 x 2000 pairs
+    # intermediate activations of two images (the engine's taps are those of its last forward: embed them alone)
+    timg, ttok = gold["tap_images"].tolist(), gold["tap_tokens"].tolist()
+    two = u8[timg].to(dev)
+    rel = {}
+    for b in gold["tap_blocks"].tolist():
+        x = eng.residual_after(two, b + 1)[:, ttok].cpu()
+        r = torch.from_numpy(gold[f"tap_block{b}"])
+        rel[f"block{b}"] = float((x - r).norm() / r.norm())
+    taps = eng.taps(two)
+    r = torch.from_numpy(gold["tap_ln_post"])
+    rel["ln_post"] = float((taps["ln_post"][:, ttok].cpu() - r).norm() / r.norm())
+    r = torch.from_numpy(gold["tap_pooled"])
+    rel["pooled"] = float((taps["pooled"].cpu() - r).norm() / r.norm())
+    rel["embedding"] = float((taps["embedding"].cpu() - ref[timg]).norm() / ref[timg].norm())
+    print("L14 relative distance from the oracle by stage:", {k: round(v, 5) for k, v in rel.items()})
+    # measured: block5 3.1e-3, block11 3.9e-3, block23 4.6e-3, ln_post 4.5e-3, pooled 3.2e-3, embedding 3.0e-3
+    assert rel["block5"] <= 5e-3 and rel["block11"] <= 6e-3 and rel["block23"] <= 7e-3 and rel["ln_post"] <= 7e-3, rel
+    assert rel["pooled"] <= 5e-3 and rel["embedding"] <= 4.5e-3, rel
+    assert rel["pooled"] <= rel["ln_post"] * 1.05, rel       # the fp32 head adds no error of its own: pooling only averages
     # the same images embedded alone take other GEMM tilings: still the oracle's vectors
-    alone = eng.embed(u8[idx[:2]].to(dev)).cpu()
-    assert ((alone * ref[:2]).sum(-1) >= 0.999).all()
+    assert_embeddings_match(taps["embedding"].cpu(), ref[timg])
     eng.close()
 
 
@@ -63,8 +89,8 @@ def test_l14_outlier_channels_vs_golden(dev):
     eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=4)
     emb = eng.embed(u8.to(dev)).cpu()
     ref = torch.from_numpy(gold["embedding"])
-    cos = (emb * ref).sum(-1)
-    assert torch.isfinite(emb).all() and (cos >= 0.999).all(), cos
+    assert torch.isfinite(emb).all()
+    assert_embeddings_match(emb, ref, what="L14 outlier channels")
     gal = _probe_gallery(cfg.out_dim)
     assert ((emb @ gal.T) - (ref @ gal.T)).abs().max().item() <= 1e-3
     # the residual stream itself: the outlier channels after block 5 are as large on the device as in the oracle
@@ -106,15 +132,13 @@ def test_config2_l14_crops_create_database_and_search(tmp_path, dev):
     stored = r.vector_db.gallery.read(0, n).cpu()
     # stored order: files sorted by name, boxes in detection order == the golden order
     ref = torch.from_numpy(gold["embedding"])
-    cos = (stored * ref).sum(-1)
-    assert (cos >= 0.999).all(), (float(cos.min()), int(cos.argmin()))
-    # cosine scores against a probe gallery: the 1e-3 bound on the sample size the other parity tests use (8 vectors x
-    # 2000 probes); over all 192 x 2000 = 384 000 random pairs the extreme value is measured at 1.03e-3 (bf16 operands:
-    # |GPU - oracle| ~ 7e-3 per embedding, i.e. sigma ~ 2e-4 per random pair), so the full set is held to 1.5e-3
+    assert_embeddings_match(stored, ref, what="configs[2] crops")
+    # cosine scores against a probe gallery: north_star's 1e-3 on ALL 192 x 2000 = 384 000 pairs (with the fp32 head the
+    # embeddings are 3e-3 from the oracle's, sigma ~ 1e-4 per random pair: the extreme of 384 000 pairs is ~5e-4)
     gal = _probe_gallery(stored.shape[1])
     d = ((stored @ gal.T) - (ref @ gal.T)).abs()
-    assert d[:8].max().item() <= 1e-3 and d.max().item() <= 1.5e-3, (d[:8].max().item(), d.max().item())
-    assert d.mean().item() <= 2.5e-4
+    assert d.max().item() <= 1e-3, d.max().item()
+    assert d.mean().item() <= 1.5e-4
     payload = r.vector_db.payloads[5]
     assert payload["filename"] == files[1][0] and payload["bbox"] == [int(v) for v in boxes[1, 2]]
     # search (core_system.py:650-717): the oracle's embedding of a crop as the query.  Indices must equal the brute-force
