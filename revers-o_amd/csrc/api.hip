@@ -715,7 +715,8 @@ constexpr long SEARCH_SMALL_ROWS = 16384;     // below this the 128 x 128 scan w
 
 // Phase 1 of a search: normalise the queries, scan the gallery (bf16 MFMA scores) and leave each query's best
 // ksel candidates, sorted best first, in the handle (cand / cand_stride).  The gallery must not be empty.
-static int search_candidates(revo_gallery* g, const float* queries, int Q, int ksel, hipStream_t st) {
+static int search_candidates(revo_gallery* g, const float* queries, int Q, int ksel, hipStream_t st,
+                             uint32_t* bounds = nullptr, int top_m = 0) {
     using namespace revo;
     const int D = g->D;
     const long N = g->size;
@@ -795,8 +796,7 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
             CHECK_RC(launch_gemm(EPI_F32, ga, st));
             REVO_HIP_CHECK(hipMemsetAsync(hist, 0, hist_bytes, st));
             CHECK_RC(launch_topk_select_rows(pre_scores, n_pre, (int)n_pre, Q, prelist, ksel, 0, tau_base, ksel, hist, NB,
-                                             topk_scan256_hist_shift(), st));
-            REVO_HIP_CHECK(hipMemcpyAsync(tau_live, tau_base, (size_t)Q * 4, hipMemcpyDeviceToDevice, st));
+                                             topk_scan256_hist_shift(), st, tau_live));
         }
         { ProfScope ps("topk_scan", st);
           for (int i = 0; i < nparts; ++i) {
@@ -810,7 +810,7 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
               const Part& pt = parts[i];
               CHECK_RC(launch_topk_reduce_segs((const uint64_t*)(wsb + pt.seg_off), (const int*)(wsb + pt.cnt_off), pt.splits,
                                                prelist + (size_t)pt.q0 * ksel, final_lists + (size_t)pt.q0 * ksel, pt.nq, ksel,
-                                               st));
+                                               st, bounds ? bounds + (size_t)pt.q0 * top_m : nullptr, top_m));
           } }
         g->cand = final_lists; g->cand_stride = ksel;
     } else {
@@ -823,6 +823,7 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
         { ProfScope ps("topk_scan", st); CHECK_RC(launch_topk_scan(a, st)); }
         { ProfScope ps("topk_reduce", st); CHECK_RC(launch_topk_reduce(g->part, Q, splits, ksel, st)); }
         g->cand = g->part; g->cand_stride = (long)splits * ksel;
+        if (bounds) { ProfScope ps("topk_bounds", st); CHECK_RC(launch_topk_publish(g->cand, g->cand_stride, Q, top_m, bounds, st)); }
     }
     g->cand_Q = Q; g->cand_ksel = ksel;
     return 0;
@@ -905,9 +906,8 @@ extern "C" int32_t revo_search_candidates(revo_gallery* g, const float* queries,
         REVO_HIP_CHECK(hipMemsetAsync(bounds, 0, (size_t)Q * top_m * 4, st));
         return 0;
     }
-    CHECK_RC(search_candidates(g, queries, Q, ksel, st));
-    ProfScope ps("topk_bounds", st);
-    return revo::launch_topk_publish(g->cand, g->cand_stride, Q, top_m, bounds, st);
+    // (the published scores come out of the final selection kernel: no launch of their own)
+    return search_candidates(g, queries, Q, ksel, st, bounds, top_m);
     API_END
 }
 extern "C" int32_t revo_search_finish(revo_gallery* g, int32_t Q, int32_t k, int32_t has_thr, float thr,

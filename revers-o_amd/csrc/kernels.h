@@ -198,13 +198,16 @@ unsigned long long* topk_scan256_stats();
 int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
                         int splits, uint64_t* seg, int* seg_cnt, uint32_t* tau_g, const uint32_t* tau_base, uint32_t* hist,
                         int ksel, hipStream_t st);
-// out[q][ksel] = best ksel distinct keys (sorted, best first) of prelist[q][ksel] and the query's segments
+// out[q][ksel] = best ksel distinct keys (sorted, best first) of prelist[q][ksel] and the query's segments;
+// bounds (optional) [Q][top_m]: the order-preserving u32 scan scores of each query's best top_m candidates (what
+// launch_topk_publish writes: the row-sharded search's published admission scores, without a launch of their own)
 int launch_topk_reduce_segs(const uint64_t* seg, const int* seg_cnt, int splits, const uint64_t* prelist, uint64_t* out,
-                            int Q, int ksel, hipStream_t st);
+                            int Q, int ksel, hipStream_t st, uint32_t* bounds = nullptr, int top_m = 0);
 // pre-pass of the 256 x 256 scan: KSEL best columns of every row of a [Q][n] fp32 score matrix -> part[q][slot];
 // tau0[q] = the KSEL-th score; hist (optional): the kept scores are counted into the query's histogram
 int launch_topk_select_rows(const float* scores, long ld, int n, int Q, uint64_t* part, long part_row_stride, int slot,
-                            uint32_t* tau0, int ksel, uint32_t* hist, int hist_buckets, int hist_shift, hipStream_t st);
+                            uint32_t* tau0, int ksel, uint32_t* hist, int hist_buckets, int hist_shift, hipStream_t st,
+                            uint32_t* tau_copy = nullptr);
 // all-padding result for an empty gallery
 int launch_topk_fill_empty(float* s, long long* i, int* c, int Q, int k, hipStream_t st);
 // merge P per-shard result lists [P][Q][k] -> [Q][k]

@@ -392,7 +392,8 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
                                                                         int Q, uint64_t* __restrict__ part,
                                                                         long part_row_stride, int slot,
                                                                         uint32_t* __restrict__ tau0, uint32_t* __restrict__ hist,
-                                                                        int hist_buckets, int hist_shift) {
+                                                                        int hist_buckets, int hist_shift,
+                                                                        uint32_t* __restrict__ tau_copy) {
     __shared__ uint64_t partial[SEL_MAXW][64];
     __shared__ uint64_t cand[SEL_MAXW][64];     // per wave: survivors of pass 2, compacted
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
         if (lane < KSEL) part[(long)q * part_row_stride + (long)slot * KSEL + lane] = run;
         const uint64_t last = readlane_u64(run, KSEL - 1);
         const uint32_t base = f32_orderable(last ? key_score(last) : -INFINITY);      // order-preserving u32
-        if (lane == 0) tau0[q] = base;
+        if (lane == 0) { tau0[q] = base; if (tau_copy) tau_copy[q] = base; }     // tau_copy: the scan's live bounds start here
         // seed the query's score histogram (origin = this bound) with the kept scores: the scan counts its
         // survivors into the same buckets, so "KSEL scores at or above an edge" includes the pre-pass rows
         if (hist && last && lane < KSEL && run) {
@@ -493,17 +494,18 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
     }
 }
 int launch_topk_select_rows(const float* scores, long ld, int n, int Q, uint64_t* part, long part_row_stride, int slot,
-                            uint32_t* tau0, int ksel, uint32_t* hist, int hist_buckets, int hist_shift, hipStream_t st) {
+                            uint32_t* tau0, int ksel, uint32_t* hist, int hist_buckets, int hist_shift, hipStream_t st,
+                            uint32_t* tau_copy) {
     if (Q <= 0) return 0;
     REVO_REQUIRE(n >= 1 && n <= SEL_STRIP * SEL_MAXW, "search: the pre-pass selection takes at most 65536 columns");
     REVO_REQUIRE(n % 4 == 0 && ld % 4 == 0 && (((uintptr_t)scores) & 15) == 0, "search: pre-pass score rows must be 16-byte aligned");
     const int nw = (n + SEL_STRIP - 1) / SEL_STRIP;
     if (ksel == 32)
         hipLaunchKernelGGL((topk_select_rows_kernel<32>), dim3(Q), dim3(nw * 64), 0, st, scores, ld, n, Q, part,
-                           part_row_stride, slot, tau0, hist, hist_buckets, hist_shift);
+                           part_row_stride, slot, tau0, hist, hist_buckets, hist_shift, tau_copy);
     else
         hipLaunchKernelGGL((topk_select_rows_kernel<64>), dim3(Q), dim3(nw * 64), 0, st, scores, ld, n, Q, part,
-                           part_row_stride, slot, tau0, hist, hist_buckets, hist_shift);
+                           part_row_stride, slot, tau0, hist, hist_buckets, hist_shift, tau_copy);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -620,7 +620,8 @@ template <int KSEL, int RW>
 __global__ __launch_bounds__((RW == 1 ? 4 : RW) * 64) void topk_reduce_segs_kernel(const uint64_t* __restrict__ seg,
                                                                                   const int* __restrict__ seg_cnt, int splits,
                                                                                   const uint64_t* __restrict__ prelist,
-                                                                                  uint64_t* __restrict__ out, int Q) {
+                                                                                  uint64_t* __restrict__ out, int Q,
+                                                                                  uint32_t* __restrict__ bounds, int top_m) {
     constexpr int SEG = 2 * KSEL;
     constexpr int NWV = RW == 1 ? 4 : RW;               // waves per workgroup
     __shared__ uint64_t partial[RW == 1 ? 1 : RW][64];
@@ -660,6 +661,8 @@ __global__ __launch_bounds__((RW == 1 ? 4 : RW) * 64) void topk_reduce_segs_kern
     if (fill > 0) run = s256_fold_chunk<KSEL>(run, chunk, ws, lane);
     if constexpr (RW == 1) {
         if (lane < KSEL) out[q * KSEL + lane] = run;
+        // row-sharded search: the scan scores of the best top_m candidates, published for the bound exchange (was a launch of its own)
+        if (bounds && lane < top_m) bounds[q * top_m + lane] = (uint32_t)(run >> 32);
         return;
     }
     partial[w][lane] = run;
@@ -671,19 +674,20 @@ __global__ __launch_bounds__((RW == 1 ? 4 : RW) * 64) void topk_reduce_segs_kern
             run = s256_merge_step<KSEL>(run, other, ws, lane);
         }
         if (lane < KSEL) out[q * KSEL + lane] = run;
+        if (bounds && lane < top_m) bounds[q * top_m + lane] = (uint32_t)(run >> 32);
     }
 }
 int launch_topk_reduce_segs(const uint64_t* seg, const int* seg_cnt, int splits, const uint64_t* prelist, uint64_t* out,
-                            int Q, int ksel, hipStream_t st) {
+                            int Q, int ksel, hipStream_t st, uint32_t* bounds, int top_m) {
     if (Q <= 0) return 0;
     if (splits <= 32) {
         const dim3 grid((unsigned)((Q + 3) / 4)), block(4 * 64);
-        if (ksel == 32) hipLaunchKernelGGL((topk_reduce_segs_kernel<32, 1>), grid, block, 0, st, seg, seg_cnt, splits, prelist, out, Q);
-        else hipLaunchKernelGGL((topk_reduce_segs_kernel<64, 1>), grid, block, 0, st, seg, seg_cnt, splits, prelist, out, Q);
+        if (ksel == 32) hipLaunchKernelGGL((topk_reduce_segs_kernel<32, 1>), grid, block, 0, st, seg, seg_cnt, splits, prelist, out, Q, bounds, top_m);
+        else hipLaunchKernelGGL((topk_reduce_segs_kernel<64, 1>), grid, block, 0, st, seg, seg_cnt, splits, prelist, out, Q, bounds, top_m);
     } else {
         const dim3 grid((unsigned)Q), block(S256_RW * 64);
-        if (ksel == 32) hipLaunchKernelGGL((topk_reduce_segs_kernel<32, S256_RW>), grid, block, 0, st, seg, seg_cnt, splits, prelist, out, Q);
-        else hipLaunchKernelGGL((topk_reduce_segs_kernel<64, S256_RW>), grid, block, 0, st, seg, seg_cnt, splits, prelist, out, Q);
+        if (ksel == 32) hipLaunchKernelGGL((topk_reduce_segs_kernel<32, S256_RW>), grid, block, 0, st, seg, seg_cnt, splits, prelist, out, Q, bounds, top_m);
+        else hipLaunchKernelGGL((topk_reduce_segs_kernel<64, S256_RW>), grid, block, 0, st, seg, seg_cnt, splits, prelist, out, Q, bounds, top_m);
     }
     REVO_HIP_CHECK(hipGetLastError());
     return 0;

@@ -48,6 +48,15 @@ class GalleryBackend:
         from . import engine
         self._engine = engine
         self.gallery = gallery
+        self._buf = {}          # packed result blocks, reused from search to search (no allocation in the steady state)
+
+    def _packed(self, tag, n_queries, k):
+        key = (tag, int(n_queries), int(k))
+        if key not in self._buf:
+            if len(self._buf) > 16:
+                self._buf.clear()
+            self._buf[key] = torch.empty((self.packed_bytes(n_queries, k),), dtype=torch.uint8, device=self.gallery.device)
+        return self._buf[key]
 
     def ksel(self, k):
         return self._engine.search_ksel(k)
@@ -62,7 +71,7 @@ class GalleryBackend:
         return self.gallery.search_candidates(queries, k, top_m)
 
     def finish(self, n_queries, k, all_bounds, index_offset):
-        out = torch.empty((self.packed_bytes(n_queries, k),), dtype=torch.uint8, device=self.gallery.device)
+        out = self._packed("finish", n_queries, k)
         # the threshold is applied after the merge (a per-element predicate: same result, one code path)
         self.gallery.search_finish(n_queries, k, all_bounds, None, index_offset, out_packed=out)
         return out
@@ -71,7 +80,7 @@ class GalleryBackend:
         return self._engine.merge_topk_packed(packed_all, parts, n_queries, k, threshold, certify=certify)
 
     def exact(self, q_idx, need, k, index_offset):
-        out = torch.empty((self.packed_bytes(int(q_idx.shape[0]), k),), dtype=torch.uint8, device=self.gallery.device)
+        out = self._packed("exact", int(q_idx.shape[0]), k)
         self.gallery.search_exact(q_idx, need, k, index_offset, out_packed=out)
         return out
 
@@ -84,7 +93,16 @@ class ShardedSearch:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.local_rows = int(local_rows)
         self.last_uncertified = 0          # queries of the last search that needed the second round
+        self._gbuf = {}                    # gather targets, reused from search to search
         self.offset, self.total_rows = self._exchange_offsets()
+
+    def _gather_buf(self, tag, shape, dtype, device):
+        key = (tag, tuple(shape), dtype)
+        if key not in self._gbuf:
+            if len(self._gbuf) > 16:
+                self._gbuf.clear()
+            self._gbuf[key] = torch.empty(shape, dtype=dtype, device=device)
+        return self._gbuf[key]
 
     @classmethod
     def from_gallery(cls, gallery, group=None):
@@ -144,10 +162,10 @@ class ShardedSearch:
         if self.world == 1:
             return self.backend.search(queries, k, threshold)                    # one shard: the plain single-GPU search
         mine = self.backend.candidates(queries, k, top_m)                        # [Q, top_m] int32
-        allb = torch.empty((self.world * Q, top_m), dtype=mine.dtype, device=mine.device)
+        allb = self._gather_buf("bounds", (self.world * Q, top_m), mine.dtype, mine.device)
         self._all_gather(allb, mine)                                             # exchange 1: admission scores
         packed = self.backend.finish(Q, k, allb.view(self.world, Q, top_m), self.offset)
-        allp = torch.empty((self.world * packed.numel(),), dtype=torch.uint8, device=packed.device)
+        allp = self._gather_buf("packed", (self.world * packed.numel(),), torch.uint8, packed.device)
         self._all_gather(allp, packed)                                           # exchange 2: packed per-rank top-k
         scores, idx, counts, unc = self.backend.merge(allp, self.world, Q, k, threshold, certify=True)
         n = int(unc[0].item())                                                   # identical on every rank

@@ -55,12 +55,29 @@ for p, Gp in enumerate(shards):
 s2, i2, c2 = engine.merge_topk_packed(packed, P, Q, k)
 kept = int((packed.view(P, pb)[:, : Q * k * 8].contiguous().view(torch.int64) >= 0).sum())
 comm_ms = 2 * 0.06     # assumption: two latency-bound RCCL all-gathers (0.3 MB and 1.2 MB per rank) at ~60 us each on xGMI
-t8 = tc + tf + tm + comm_ms
+# the certificate's second round: the whole protocol in one process over the 8 shards tells how many queries
+# need it; its per-rank cost = the exact pass of ONE shard for those queries (+ a third, small all-gather when it happens)
+from reverso_amd import sharded
+ls = sharded.LocalShards.from_galleries(shards)
+s3, i3, c3 = ls.search(q, k)
+n_unc = ls.last_uncertified
+full_unc = None
+full.search(q, k); full_unc = full.search_stats()["uncertified"]
+t_exact = 0.0
+if n_unc:
+    qi = torch.arange(n_unc, dtype=torch.int32, device=dev)
+    need = torch.full((n_unc,), 0.12, device=dev)
+    shards[0].search_candidates(q, k, top_m)
+    t_exact, _ = timed(lambda: shards[0].search_exact(qi, need, k, 0))
+    comm_ms += 0.06
+t8 = tc + tf + tm + comm_ms + t_exact
 print(json.dumps({
     "N": N, "Q": Q, "shards": P, "top_m": top_m,
     "one_gpu_ms": round(t1, 4), "one_gpu_stage_ms": {c: round(v, 4) for c, v in sorted(st1.items())},
     "per_rank_phase1_ms": round(tc, 4), "phase1_stage_ms": {c: round(v, 4) for c, v in sorted(stc.items())},
     "per_rank_finish_bounded_ms": round(tf, 4), "finish_unbounded_ms": round(tfu, 4), "merge_ms": round(tm, 4),
     "assumed_comm_ms": comm_ms, "projected_8gpu_ms": round(t8, 4), "projected_speedup": round(t1 / t8, 3),
-    "results_equal_unsharded": bool(torch.equal(i2, i_ref) and torch.equal(s2, s_ref) and torch.equal(c2, c_ref)),
+    "uncertified_queries_sharded": n_unc, "uncertified_queries_one_gpu": full_unc, "per_rank_exact_round_ms": round(t_exact, 4),
+    "results_equal_unsharded": bool(torch.equal(i3, i_ref) and torch.equal(s3, s_ref) and torch.equal(c3, c_ref)),
+    "first_round_equal_unsharded": bool(torch.equal(i2, i_ref) and torch.equal(s2, s_ref) and torch.equal(c2, c_ref)),
     "results_kept_per_query_all_ranks": round(kept / Q, 2)}), flush=True)

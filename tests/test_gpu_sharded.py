@@ -68,3 +68,58 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_search(tmp_path, dev):
             assert np.array_equal(got["q"], q.cpu().numpy())
             assert np.array_equal(got[f"{thr}_i"], i) and np.array_equal(got[f"{thr}_c"], c)
             assert np.array_equal(got[f"{thr}_s"], s)
+
+
+def _nccl_worker(rank, world, port, tmp, N, D, Q, k):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import reverso_amd  # noqa: F401
+    from reverso_amd import engine, sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    g = torch.Generator().manual_seed(5)
+    gal = torch.randn(N, D, generator=g)
+    gal[100:160] = gal[100]                      # a tie group wider than the candidate list: forces the exact second round
+    q = torch.randn(Q, D, generator=g)
+    q[0] = gal[100]
+    sizes = [N // world + (1 if r < N % world else 0) for r in range(world)]
+    lo = sum(sizes[:rank])
+    G = engine.Gallery(D, sizes[rank], device=rank)
+    G.add(gal[lo:lo + sizes[rank]].to(dev))
+    ss = sharded.ShardedSearch.from_gallery(G)
+    out = {}
+    for thr in (None, 0.1):
+        s, i, c = ss.search(q.to(dev), k, thr)
+        out[str(thr)] = (s.cpu().numpy(), i.cpu().numpy(), c.cpu().numpy(), ss.last_uncertified)
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), **{f"{t}_{n}": v for t, (a, b, c, u) in out.items()
+                                                        for n, v in (("s", a), ("i", b), ("c", c), ("u", np.int64(u)))})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path wants one device per rank: needs two GPUs")
+def test_two_ranks_over_rccl_equal_the_single_gpu_search(tmp_path, dev):
+    """The product's N > 1 wiring exactly as bench.py --gpus N runs it: one process per GPU, torch.distributed "nccl"
+    (= RCCL) all-gathers of device tensors, including the certificate's second round.  Runs wherever two GPUs are
+    visible (the one-GPU boxes of this pool skip it; the driver's multi-GPU node runs it)."""
+    import torch.multiprocessing as mp
+    from reverso_amd import engine
+    N, D, Q, k, world = 60001, 256, 37, 10, 2
+    port = 29700 + (os.getpid() % 2000)
+    mp.spawn(_nccl_worker, args=(world, port, str(tmp_path), N, D, Q, k), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(5)
+    gal = torch.randn(N, D, generator=g)
+    gal[100:160] = gal[100]
+    q = torch.randn(Q, D, generator=g)
+    q[0] = gal[100]
+    G = engine.Gallery(D, N, device=0)
+    G.add(gal.to(dev))
+    for thr in (None, 0.1):
+        s, i, c = (t.cpu().numpy() for t in G.search(q.to(dev), k, thr))
+        for rank in range(world):
+            got = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+            assert np.array_equal(got[f"{thr}_i"], i) and np.array_equal(got[f"{thr}_c"], c) and np.array_equal(got[f"{thr}_s"], s)
+            assert int(got[f"{thr}_u"]) >= 1
