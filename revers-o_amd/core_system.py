@@ -17,7 +17,9 @@ What differs underneath:
 
 There is no CPU fallback: constructing the class without a GPU raises.
 """
+import json
 import os
+from datetime import datetime
 import shutil
 import threading
 import time
@@ -37,6 +39,7 @@ from .weights import load_state_dict, synth_weights
 
 DB_ROOT = "./simple_reverso_db"
 IMAGE_EXTENSIONS = ['.jpg', '.jpeg', '.png', '.bmp', '.tiff', '.webp']
+BUILDING = ".building"      # suffix of the directory a collection is built in (renamed over the old one when complete)
 
 
 
@@ -66,7 +69,8 @@ class SimpleReverso:
     """Simplified visual investigation system (MI355X-native hot path)."""
 
     def __init__(self, model_name=DEFAULT_VARIANT, checkpoint=None, device=0, db_root=DB_ROOT, max_batch=64,
-                 detector=None, decode_workers=8, synthetic_seed=0, region_mode="global", device_resize=False):
+                 detector=None, decode_workers=8, synthetic_seed=0, region_mode="global", device_resize=False,
+                 checkpoint_interval_s=30.0):
         print("🚀 Initializing Simple Revers-o...")
         if region_mode not in ("global", "crop"):
             raise ValueError("region_mode must be 'global' (the reference's behaviour, core_system.py:406) or 'crop'")
@@ -76,7 +80,7 @@ class SimpleReverso:
         # True: decoded frames are uploaded as they are and squash-resized by the HIP kernel
         # (same pixels as the host PIL resize, bit for bit); False: PIL resize in the decode pool
         self.device_resize = bool(device_resize)
-        self.checkpoint_interval_s = 30.0     # a checkpoint rewrites all vectors collected so far
+        self.checkpoint_interval_s = float(checkpoint_interval_s)     # a checkpoint writes the vectors added since the last one (a delta shard)
         self.db_root = db_root
         self.max_batch = int(max_batch)
         self.detector = detector
@@ -94,6 +98,7 @@ class SimpleReverso:
         self._last_processed_file = None
         self._partial_embeddings = []
         self._partial_metadata = []
+        self._build_store = None        # the collection a create_database call is building (closed when the call returns)
         print("✅ Simple Revers-o ready!")
 
     # ------------------------------------------------------------- DB admin --
@@ -102,7 +107,7 @@ class SimpleReverso:
         if not os.path.exists(self.db_root):
             return []
         return [n for n in os.listdir(self.db_root)
-                if os.path.isdir(os.path.join(self.db_root, n)) and n != "checkpoints"]
+                if os.path.isdir(os.path.join(self.db_root, n)) and n != "checkpoints" and not n.endswith(BUILDING)]
 
     def load_database(self, database_name):
         """core_system.py:90-119"""
@@ -112,7 +117,7 @@ class SimpleReverso:
         if not os.path.exists(db_path):
             return f"❌ Database not found: {database_name}"
         try:
-            if not os.path.exists(os.path.join(db_path, "meta.json")):
+            if not (os.path.exists(os.path.join(db_path, st.MANIFEST)) or os.path.exists(os.path.join(db_path, "meta.json"))):
                 return f"❌ Collection not found in database: {database_name}"
             with self._lock:
                 if self.vector_db is not None:
@@ -334,15 +339,19 @@ class SimpleReverso:
         db_path = os.path.join(self.db_root, database_name)
         ckpt_base = os.path.join(self.db_root, "checkpoints", f"{database_name}_checkpoint")
         processed_files = set()
-        # vectors left over from an earlier call (a stop, an exception) never leak into this collection
-        self._partial_embeddings, self._partial_metadata = [], []
-        if resume_from_checkpoint and os.path.exists(ckpt_base + ".json"):
+        # The collection is built in <db>.building (the finished one, if any, stays searchable until the new one is
+        # complete) and its manifest of delta shards is the checkpoint: a resume re-opens it.
+        self._partial_embeddings, self._partial_metadata = [], []          # (kept for callers that look at them: always empty now)
+        build_path = db_path + BUILDING
+        self._build_store = None
+        if resume_from_checkpoint and os.path.exists(os.path.join(build_path, st.MANIFEST)):
             try:
-                processed_files, self._partial_embeddings, self._partial_metadata = st.load_checkpoint(ckpt_base)
+                self._build_store = st.GalleryStore.load(build_path, device=self.device.index or 0, allow_partial=True)
+                processed_files = set(self._build_store.files_done)
                 log_status(f"📋 Resuming from checkpoint: {len(processed_files)} files already processed")
             except Exception as e:
                 log_status(f"⚠️ Error loading checkpoint: {str(e)}. Starting fresh.")
-                processed_files, self._partial_embeddings, self._partial_metadata = set(), [], []
+                processed_files, self._build_store = set(), None
         try:
             return self._create_database_body(folder_path, database_name, text_prompt, use_direct_pe, resume_from_checkpoint,
                                               include_subfolders, log_status, status_messages, db_path, ckpt_base,
@@ -351,6 +360,9 @@ class SimpleReverso:
             self._stop_requested = False
             self._partial_embeddings = []
             self._partial_metadata = []
+            if self._build_store is not None:               # stopped or failed: the shards on disk are the checkpoint
+                self._build_store.close()
+                self._build_store = None
 
     def _create_database_body(self, folder_path, database_name, text_prompt, use_direct_pe, resume_from_checkpoint,
                               include_subfolders, log_status, status_messages, db_path, ckpt_base, processed_files):
@@ -368,12 +380,11 @@ class SimpleReverso:
             return str(log_status(f"❌ No images found in {folder_path}"))
         if resume_from_checkpoint:
             image_files = [f for f in image_files if f not in processed_files]
-            if not image_files and not self._partial_embeddings:
+            if not image_files and self._build_store is None:
                 return str(log_status("✅ All files already processed. Database is complete."))
             if not image_files:
-                # every file was embedded before the stop / crash, but the collection was never written
-                # (the last embed batch checkpoints before the storage phase): go straight to storage
-                log_status(f"📋 All files already embedded: storing {len(self._partial_embeddings)} vectors from the checkpoint")
+                # every file was embedded before the stop / crash, but the collection was never completed: finish it
+                log_status(f"📋 All files already embedded: storing {len(self._build_store)} vectors from the checkpoint")
         if image_files:
             log_status(f"📊 Found {len(image_files)} images to process", 0.1)
         if include_subfolders:
@@ -383,10 +394,29 @@ class SimpleReverso:
 
         processed = failed = 0
 
+        build_path = db_path + BUILDING
+        collection_name = f"simple_reverso_{database_name}"
+        if self._build_store is None:
+            if os.path.isdir(build_path):
+                shutil.rmtree(build_path)
+            self._build_store = st.GalleryStore(self.pe_model.cfg.out_dim, device=self.device.index or 0,
+                                                capacity=max(len(image_files), 1024), collection=collection_name,
+                                                path=build_path)
+        store_db = self._build_store
+
         def checkpoint():
+            """the rows and finished files since the last one, as a delta shard of the collection being built; the small
+            JSON next to the reference's checkpoint path only says where the build lives"""
             try:
-                st.save_checkpoint(ckpt_base, processed_files, self._partial_embeddings, self._partial_metadata,
-                                   database_name, folder_path)
+                rows = store_db.flush()
+                os.makedirs(os.path.dirname(ckpt_base), exist_ok=True)
+                with open(ckpt_base + ".json.tmp", "w") as f:
+                    json.dump({"database_name": database_name, "folder_path": folder_path, "build_path": build_path,
+                               "timestamp": datetime.now().isoformat(), "processed_files": len(store_db.files_done),
+                               "n_embeddings": len(store_db)}, f, indent=2)
+                os.replace(ckpt_base + ".json.tmp", ckpt_base + ".json")
+                if rows:
+                    log_status(f"💾 Checkpoint: shard {store_db._shards - 1} ({rows} vectors, {len(store_db)} in all)")
             except Exception as e:
                 log_status(f"⚠️ Error saving checkpoint: {str(e)}")
 
@@ -421,33 +451,30 @@ class SimpleReverso:
         last_ckpt = time.monotonic()
         crop_mode = self.region_mode == "crop" and not use_direct_pe
         pipelined = host_resize and not crop_mode
-        stage = host_out = None
-        if not crop_mode:
-            host_out = [torch.empty((B, self.pe_model.cfg.out_dim), dtype=torch.float32).pin_memory() for _ in range(2)]
+        stage = None
         if pipelined:
             stage = [torch.zeros((B, 3, model_size, model_size), dtype=torch.uint8).pin_memory() for _ in range(2)]
         pending = submit(0)
 
         def finalize(item):
-            """bookkeeping of one embedded batch: metadata, region embeddings in crop mode, partial lists, checkpoint"""
+            """bookkeeping of one embedded batch: metadata per image, then the batch's vectors -- still on the device --
+            go straight into the collection being built (device-to-device append; nothing visits the host)"""
             nonlocal failed
-            s, paths, pils, embs, event, by_file, last = item
-            if event is not None:
-                event.synchronize()
+            s, paths, pils, dev_emb, by_file, last = item
             gi = 0
-            batch_items = []                       # (path, pil, metas, global vector or None)
+            batch_items = []                       # (path, pil, metas, row of dev_emb or None)
             for j, (path, im) in enumerate(zip(paths, pils)):
                 i = s + j
                 filename = os.path.basename(path)
                 log_status(f"🔄 Processing {i + 1}/{len(image_files)}: {filename}", 0.1 + 0.7 * (i / len(image_files)))
                 if isinstance(im, Exception):
                     log_status(f"❌ Error processing {filename}: {str(im)}")
-                    processed_files.add(path)
+                    done_files.append(path)
                     failed += 1
                     continue
-                e = None
-                if embs is not None:
-                    e = embs[j] if by_file else embs[gi]      # staged batches have one row per file, the others one per decoded file
+                row = None
+                if dev_emb is not None:
+                    row = j if by_file else gi                # staged batches have one row per file, the others one per decoded file
                     gi += 1
                 if use_direct_pe:
                     metas = [{"region_id": _uuid4(), "bbox": [0, 0, im.width, im.height], "area_ratio": 1.0,
@@ -457,7 +484,7 @@ class SimpleReverso:
                     n_reg = self.detect_regions(im, text_prompt)
                     if n_reg == 0:
                         log_status(f"⚠️ No regions found in {filename}, skipping")
-                        processed_files.add(path)
+                        done_files.append(path)
                         failed += 1
                         continue
                     _, metas = self._region_metadata(im, self.detected_regions)
@@ -467,55 +494,47 @@ class SimpleReverso:
                     m["filename"] = filename
                     m["original_region_id"] = m.get("region_id", _uuid4())
                     m["region_id"] = _uuid4()
-                batch_items.append((path, im, metas, e))
+                batch_items.append((path, im, metas, row))
             if crop_mode:
                 # region crops of the whole batch: frames go to the device once, one crop + resize launch, forwards of
-                # max_batch crops -- all asynchronous; the vectors are stored when the NEXT batch has been launched
-                flush_regions()
+                # max_batch crops; the vectors stay on the device
                 with torch.cuda.device(self.device):
                     dev = self._embed_regions_batch([(im, metas) for _, im, metas, _ in batch_items], to_host=False)
-                    n = dev.shape[0]
-                    slot = region_host[0] & 1
-                    if region_bufs[slot] is None or region_bufs[slot].shape[0] < n:
-                        region_bufs[slot] = torch.empty((max(n, 256), dev.shape[1]), dtype=torch.float32).pin_memory()
-                    host = region_bufs[slot][:n]
-                    host.copy_(dev, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                region_host[0] += 1
-                region_pending.append((batch_items, host, ev, last))
-                if last:
-                    flush_regions()
+                store(batch_items, dev, None, last)
                 return
-            store(batch_items, None, last)
+            store(batch_items, None, dev_emb, last)
 
-        def store(batch_items, region_vecs, last):
-            """the embedded batch enters the partial lists (and only now counts as processed: a checkpoint never names a
-            file whose vectors it does not hold)"""
+        done_files = []                            # files finished (stored, failed or empty) since the last upsert
+
+        def store(batch_items, region_vecs, dev_emb, last):
+            """the embedded batch enters the collection (and only now counts as processed: a shard never names a file
+            whose vectors it does not hold)"""
             nonlocal processed, last_ckpt
-            ri = 0
-            for path, im, metas, e in batch_items:
-                if region_vecs is not None:
-                    self._partial_embeddings.extend(region_vecs[ri + t].clone() for t in range(len(metas)))
-                    ri += len(metas)
-                else:
-                    self._partial_embeddings.extend(e.clone() for _ in metas)
-                self._partial_metadata.extend(metas)
-                processed_files.add(path)
+            metas_all, rows = [], []
+            for path, im, metas, row in batch_items:
+                metas_all.extend(metas)
+                if region_vecs is None:
+                    rows.extend([row] * len(metas))            # every region of an image stores its global vector (core_system.py:406-408)
+                done_files.append(path)
                 processed += 1
                 self._last_processed_file = path
-            # checkpoints rewrite everything collected so far: at most one per interval, and one at the end
+            if metas_all:
+                with self._lock, torch.cuda.device(self.device):
+                    if region_vecs is not None:
+                        vec = region_vecs
+                    elif rows == list(range(len(rows))) and len(rows) == dev_emb.shape[0]:
+                        vec = dev_emb
+                    else:
+                        vec = dev_emb.index_select(0, torch.tensor(rows, dtype=torch.int64, device=dev_emb.device))
+                    store_db.upsert(vec, [m["region_id"] for m in metas_all], metas_all, files=list(done_files))
+            else:
+                store_db.upsert(torch.zeros((0, store_db.dim)), [], [], files=list(done_files))
+            processed_files.update(done_files)
+            done_files.clear()
+            # a checkpoint writes only what is new: at most one per interval, and one at the end
             if time.monotonic() - last_ckpt >= self.checkpoint_interval_s or last:
                 checkpoint()
                 last_ckpt = time.monotonic()
-
-        region_pending, region_bufs, region_host = [], [None, None], [0]
-
-        def flush_regions():
-            while region_pending:
-                batch_items, host, ev, last = region_pending.pop(0)
-                ev.synchronize()
-                store(batch_items, host, last)
 
         inflight = None
         h2d_done = [None, None]
@@ -524,7 +543,6 @@ class SimpleReverso:
                 if inflight is not None:
                     finalize(inflight)
                     inflight = None
-                flush_regions()
                 log_status("🛑 Stop requested. Saving progress...")
                 checkpoint()
                 return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
@@ -536,7 +554,7 @@ class SimpleReverso:
             pils = [r[0] for r in results]
             good = [r for r in results if not isinstance(r[0], Exception)]
             # global vectors of the whole batch in one forward (not needed when every region is cropped)
-            embs = event = None
+            dev_emb = None
             if good and not crop_mode:
                 if pipelined:
                     # every file of the batch has its row in the staging buffer (a failed file's row keeps whatever it
@@ -547,56 +565,39 @@ class SimpleReverso:
                         h2d_done[it & 1] = torch.cuda.Event()
                         h2d_done[it & 1].record()
                         dev_emb = self.pe_model.embed(dev_in)
-                        embs = host_out[it & 1][:len(paths)]
-                        embs.copy_(dev_emb, non_blocking=True)
-                        event = torch.cuda.Event()
-                        event.record()
                 else:
                     # device resize: the decoded frames go up as they are, one crop + resize launch, one forward
                     with self._lock, torch.cuda.device(self.device):
                         frames = [torch.from_numpy(np.array(pp.to_pil(im), dtype=np.uint8)).to(self.device, non_blocking=True)
                                   for im, _ in good]
                         dev_emb = self.pe_model.embed(pp.crop_resize_device(frames, None, model_size))
-                        embs = host_out[it & 1][:len(good)]
-                        embs.copy_(dev_emb, non_blocking=True)
-                        event = torch.cuda.Event()
-                        event.record()
-            cur = (s, paths, pils, embs, event, pipelined, s + B >= len(image_files))
+            cur = (s, paths, pils, dev_emb, pipelined, s + B >= len(image_files))
             if inflight is not None:
                 finalize(inflight)
             inflight = cur
         if inflight is not None:
             finalize(inflight)
-        flush_regions()
 
-        if not self._partial_embeddings:
+        if len(store_db) == 0:
             return str(log_status("❌ No embeddings extracted from any images"))
 
-        vector_dim = self._partial_embeddings[0].shape[0]
-        collection_name = f"simple_reverso_{database_name}"
+        log_status(f"📦 Recreated collection: {collection_name}", 0.8)
+        if self._stop_requested:
+            # a stop between the last embed batch and the completion of the collection: everything is in the shards
+            log_status("🛑 Stop requested during database storage. Progress saved.")
+            checkpoint()
+            return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
         with self._lock:
-            if os.path.isdir(db_path):
-                shutil.rmtree(db_path)                          # recreate_collection: start fresh
-            store = st.GalleryStore(vector_dim, device=self.device.index or 0,
-                                    capacity=len(self._partial_embeddings), collection=collection_name, path=db_path)
-            log_status(f"📦 Recreated collection: {collection_name}", 0.8)
-            n = len(self._partial_embeddings)
-            batch = 100
-            for j in range(0, n, batch):
-                if self._stop_requested:
-                    log_status("🛑 Stop requested during database storage. Progress saved.")
-                    checkpoint()
-                    store.close()
-                    return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
-                vec = torch.stack(self._partial_embeddings[j:j + batch])
-                metas = self._partial_metadata[j:j + batch]
-                store.upsert(vec, [m["region_id"] for m in metas], metas)
-                log_status(f"💾 Stored batch {j // batch + 1}/{(n + batch - 1) // batch} ({len(metas)} points)",
-                           0.8 + 0.1 * (j / n))
-            store.save()
+            store_db.save()                                     # the last delta shard + the "complete" line
+            log_status(f"💾 Stored {len(store_db)} points in {store_db._shards} shards", 0.9)
             if self.vector_db is not None:
                 self.vector_db.close()
-            self.vector_db = store
+            if os.path.isdir(db_path):
+                shutil.rmtree(db_path)                          # recreate_collection: the new one replaces the old one only now
+            os.replace(build_path, db_path)
+            store_db.path = db_path
+            self.vector_db = store_db
+            self._build_store = None
             self.current_database = collection_name
         if os.path.exists(ckpt_base + ".json"):
             st.remove_checkpoint(ckpt_base)
@@ -605,7 +606,7 @@ class SimpleReverso:
         log_status(f"✅ Successfully processed: {processed} images")
         if failed > 0:
             log_status(f"⚠️ Failed to process: {failed} images")
-        log_status(f"🔍 Total embeddings stored: {len(self._partial_embeddings)}")
+        log_status(f"🔍 Total embeddings stored: {len(self.vector_db)}")
         log_status(f"🎯 Database '{database_name}' ready for searching!", 1.0)
         return "\n".join(status_messages)
 

@@ -193,10 +193,11 @@ class Gallery:
             _require_cuda(v, "vectors", self.device)
         start = len(self)
         with self._lock, torch.cuda.device(self.device):
+            # a device source is read by kernels on torch's current stream: its memory is not reused before they have
+            # run (the caching allocator is stream-ordered), so nothing waits here -- an ingest appends batch after
+            # batch without a host round trip; a host source is staged and synchronised inside the call
             _lib.check(self._lib.revo_gallery_append(self._h, _lib.ptr(v), v.shape[0], int(bool(normalize)),
                                                      int(v.is_cuda), _lib.current_stream()), "revo_gallery_append")
-            if v.is_cuda:
-                torch.cuda.current_stream().synchronize()   # v may be a temporary
         return start
 
     def read(self, start=0, n=None):

@@ -3,14 +3,20 @@
 Stands where the reference keeps a ``QdrantClient(path=...)`` with one COSINE
 collection (``core_system.py:100``, ``:521``, ``:600-603``, ``:608-622``, ``:659-664``).
 Qdrant's sqlite format is not a compatibility target (third-party, un-pinned;
-SURVEY.md §8(f) row 2): a database directory here holds
+SURVEY.md §8(f) row 2).  A database directory here is append-only:
 
-    vectors.f32.npy     normalised fp32 rows (the gallery's master copy)
-    meta.json           {"collection", "dim", "ids": [...], "payloads": [...]}
-    .lock               present while a process has the database open
+    manifest.jsonl          line 1: {"format": 2, "collection", "dim"}; then one line per DELTA SHARD, in order:
+                            {"shard": i, "file", "rows", "ids": [...], "payloads": [...], "files_done": [...]};
+                            a last line {"complete": true, "rows": N} once a build has finished
+    vectors.00000.f32.npy   the shard's normalised fp32 rows (the gallery's master copy)
+    .lock                   present while a process has the database open
 
-and ``checkpoints/<name>_checkpoint.{json,npy}`` make the reference's (inoperative,
-``core_system.py:480-489``, ``:524-538``) resume actually work.
+A save / checkpoint writes only the rows added since the last one (one .npy + one manifest line, the .npy first and
+under a temporary name: a crash leaves at worst an orphan file no line points to) -- never the whole set: building a
+1 M-vector gallery writes 4 GB once, not 4 GB per checkpoint.  The manifest of an unfinished build (no "complete"
+line) IS its checkpoint: ``files_done`` says which source files the shards' rows cover (``create_database`` resumes
+from there; the reference's own checkpoint is inoperative, ``core_system.py:480-489``, ``:524-538``).
+Round-1/2 directories (one ``vectors.f32.npy`` + ``meta.json``) still load.
 """
 import json
 import os
@@ -20,6 +26,35 @@ import numpy as np
 import torch
 
 from .engine import Gallery
+
+MANIFEST = "manifest.jsonl"
+
+
+def read_manifest(man):
+    """Parse a manifest.  Returns (header, shard records in order, complete, bytes of the file that are whole lines).
+    A torn last line -- the process died while appending -- ends the parse: everything before it stands."""
+    header, shards, complete, good = None, [], False, 0
+    with open(man, "rb") as f:
+        for raw in f:
+            if not raw.endswith(b"\n"):
+                break
+            ln = raw.strip()
+            if ln:
+                try:
+                    rec = json.loads(ln)
+                except ValueError:
+                    break
+                if header is None:
+                    header = rec
+                elif rec.get("complete"):
+                    complete = True
+                else:
+                    complete = False                   # rows appended after a save: complete again at the next save
+                    shards.append(rec)
+            good += len(raw)
+    if header is None:
+        raise ValueError(f"{man}: empty manifest")
+    return header, shards, complete, good
 
 
 @dataclass
@@ -31,7 +66,7 @@ class ScoredPoint:
 
 
 class GalleryStore:
-    def __init__(self, dim, device=0, capacity=65536, collection="simple_reverso", path=None):
+    def __init__(self, dim, device=0, capacity=65536, collection="simple_reverso", path=None, _fresh=True):
         self.dim = int(dim)
         self.device = device
         self.collection = collection
@@ -39,9 +74,17 @@ class GalleryStore:
         self.ids = []
         self.payloads = []
         self.gallery = Gallery(self.dim, max(int(capacity), 1), device=device)
+        self.complete = False
+        self._flushed = 0            # rows already in shards on disk
+        self._shards = 0
+        self._files_pending = []     # source files whose rows were added since the last flush
+        self.files_done = set()      # source files covered by the shards on disk
         if path:
             os.makedirs(path, exist_ok=True)
             open(os.path.join(path, ".lock"), "a").close()
+            if _fresh:
+                with open(os.path.join(path, MANIFEST), "w") as f:
+                    f.write(json.dumps({"format": 2, "collection": collection, "dim": self.dim}) + "\n")
 
     def __len__(self):
         return len(self.ids)
@@ -49,23 +92,28 @@ class GalleryStore:
     def _grow(self, need):
         if need <= self.gallery.capacity:
             return
-        cap = max(need, 2 * self.gallery.capacity)
+        cap = max(need, 2 * self.gallery.capacity)         # geometric: a build of N rows copies < 2 N rows in all
         old = self.gallery
         new = Gallery(self.dim, cap, device=self.device)
         n = len(old)
         if n:
-            new.add(old.read(0, n), normalize=False)
+            new.add(old.read(0, n), normalize=False)       # device to device
         old.close()
         self.gallery = new
 
-    def upsert(self, vectors, ids, payloads):
-        """vectors: [n, dim] fp32 tensor (host or device); rows are normalised at insert."""
+    def upsert(self, vectors, ids, payloads, files=None):
+        """vectors: [n, dim] fp32 tensor, host or DEVICE (an ingest appends its embeddings where they are: they never
+        visit the host); rows are normalised at insert.  ``files``: source files these rows complete (resume bookkeeping)."""
         vectors = torch.as_tensor(vectors, dtype=torch.float32)
         assert vectors.shape[0] == len(ids) == len(payloads)
-        self._grow(len(self) + vectors.shape[0])
-        self.gallery.add(vectors, normalize=True)
-        self.ids.extend(ids)
-        self.payloads.extend(payloads)
+        if vectors.shape[0]:
+            self._grow(len(self) + vectors.shape[0])
+            self.gallery.add(vectors, normalize=True)
+            self.ids.extend(ids)
+            self.payloads.extend(payloads)
+        if files:
+            self._files_pending.extend(files)
+        self.complete = False
 
     def search(self, query_vector, limit, score_threshold=None):
         """One query, qdrant-style result list (core_system.py:659-664)."""
@@ -77,24 +125,96 @@ class GalleryStore:
         return [ScoredPoint(self.ids[j], float(sc), self.payloads[j]) for sc, j in zip(s, i)]
 
     # -- persistence ----------------------------------------------------------
+    def flush(self, path=None):
+        """Write the rows (and finished source files) added since the last flush as one delta shard.  Returns the rows written."""
+        path = path or self.path
+        n = len(self)
+        new = n - self._flushed
+        if new <= 0 and not self._files_pending:
+            return 0
+        name = None
+        if new > 0:
+            name = f"vectors.{self._shards:05d}.f32.npy"
+            vec = self.gallery.read(self._flushed, new).cpu().numpy()
+            tmp = os.path.join(path, name + ".tmp.npy")
+            np.save(tmp, vec)
+            os.replace(tmp, os.path.join(path, name))
+        line = {"shard": self._shards, "file": name, "rows": new, "ids": self.ids[self._flushed:n],
+                "payloads": self.payloads[self._flushed:n], "files_done": self._files_pending}
+        with open(os.path.join(path, MANIFEST), "a") as f:
+            f.write(json.dumps(line) + "\n")
+            f.flush()
+            os.fsync(f.fileno())
+        self.files_done.update(self._files_pending)
+        self._files_pending = []
+        self._flushed = n
+        self._shards += 1
+        return new
+
     def save(self, path=None):
+        """Flush what is new and mark the collection complete."""
         path = path or self.path
         os.makedirs(path, exist_ok=True)
-        n = len(self)
-        vec = self.gallery.read(0, n).cpu().numpy() if n else np.zeros((0, self.dim), np.float32)
-        np.save(os.path.join(path, "vectors.f32.npy"), vec)
-        with open(os.path.join(path, "meta.json"), "w") as f:
-            json.dump({"collection": self.collection, "dim": self.dim, "ids": self.ids, "payloads": self.payloads}, f)
+        if path != self.path:                              # saving somewhere else: write everything there
+            other = os.path.join(path, MANIFEST)
+            with open(other, "w") as f:
+                f.write(json.dumps({"format": 2, "collection": self.collection, "dim": self.dim}) + "\n")
+            keep = (self._flushed, self._shards, self._files_pending, self.path)
+            self._flushed, self._shards, self._files_pending = 0, 0, sorted(self.files_done) + self._files_pending
+            try:
+                self.flush(path)
+                with open(other, "a") as f:
+                    f.write(json.dumps({"complete": True, "rows": len(self)}) + "\n")
+            finally:
+                self._flushed, self._shards, self._files_pending, self.path = keep
+            return
+        self.flush(path)
+        if not self.complete:
+            with open(os.path.join(path, MANIFEST), "a") as f:
+                f.write(json.dumps({"complete": True, "rows": len(self)}) + "\n")
+                f.flush()
+                os.fsync(f.fileno())
+            self.complete = True
 
     @classmethod
-    def load(cls, path, device=0):
+    def load(cls, path, device=0, allow_partial=False, capacity=0):
+        """Open a database directory.  An unfinished build (no "complete" line) raises unless ``allow_partial``
+        (``create_database(resume_from_checkpoint=True)`` continues it)."""
+        man = os.path.join(path, MANIFEST)
+        if not os.path.exists(man):
+            return cls._load_v1(path, device)
+        header, shards, complete, good_bytes = read_manifest(man)
+        if not complete and not allow_partial:
+            raise ValueError(f"{path}: unfinished build (resume it with create_database(resume_from_checkpoint=True))")
+        if good_bytes < os.path.getsize(man):
+            # a torn last line (the process died while appending): cut it off before anything is appended behind it
+            with open(man, "r+b") as f:
+                f.truncate(good_bytes)
+        rows = sum(s["rows"] for s in shards)
+        st = cls(header["dim"], device=device, capacity=max(rows, capacity, 1), collection=header["collection"], path=path,
+                 _fresh=False)
+        for s in shards:
+            if s["rows"]:
+                vec = np.load(os.path.join(path, s["file"]))
+                if vec.shape != (s["rows"], st.dim):
+                    raise ValueError(f"{path}/{s['file']}: {vec.shape} does not match its manifest line")
+                st.gallery.add(torch.from_numpy(vec), normalize=False)      # stored rows are already normalised
+                st.ids.extend(s["ids"])
+                st.payloads.extend(s["payloads"])
+            st.files_done.update(s.get("files_done", []))
+        st._flushed, st._shards, st.complete = rows, len(shards), complete
+        return st
+
+    @classmethod
+    def _load_v1(cls, path, device):
         with open(os.path.join(path, "meta.json")) as f:
             meta = json.load(f)
         vec = np.load(os.path.join(path, "vectors.f32.npy"))
-        st = cls(meta["dim"], device=device, capacity=max(len(meta["ids"]), 1), collection=meta["collection"], path=path)
+        st = cls(meta["dim"], device=device, capacity=max(len(meta["ids"]), 1), collection=meta["collection"], path=None)
         if len(meta["ids"]):
-            st.gallery.add(torch.from_numpy(vec), normalize=False)     # stored rows are already normalised
+            st.gallery.add(torch.from_numpy(vec), normalize=False)
         st.ids, st.payloads = list(meta["ids"]), list(meta["payloads"])
+        st.complete = True
         return st
 
     def close(self):
@@ -106,31 +226,7 @@ class GalleryStore:
         self.gallery.close()
 
 
-# -- checkpoint / resume of a gallery build (core_system.py:474-489, :524-538) ----
-def save_checkpoint(ckpt_base, processed_files, embeddings, metadata, database_name, folder_path):
-    """embeddings: list of fp32 CPU tensors [D]."""
-    from datetime import datetime
-    os.makedirs(os.path.dirname(ckpt_base), exist_ok=True)
-    arr = torch.stack(embeddings).numpy() if embeddings else np.zeros((0, 0), np.float32)
-    np.save(ckpt_base + ".npy.tmp.npy", arr)
-    os.replace(ckpt_base + ".npy.tmp.npy", ckpt_base + ".npy")
-    with open(ckpt_base + ".json.tmp", "w") as f:
-        json.dump({"processed_files": sorted(processed_files), "timestamp": datetime.now().isoformat(),
-                   "database_name": database_name, "folder_path": folder_path, "partial_metadata": metadata,
-                   "n_embeddings": len(embeddings)}, f, indent=2)
-    os.replace(ckpt_base + ".json.tmp", ckpt_base + ".json")
-
-
-def load_checkpoint(ckpt_base):
-    with open(ckpt_base + ".json") as f:
-        data = json.load(f)
-    arr = np.load(ckpt_base + ".npy")
-    if arr.shape[0] != data["n_embeddings"] or arr.shape[0] != len(data["partial_metadata"]):
-        raise ValueError("checkpoint vectors and metadata disagree")
-    embs = [torch.from_numpy(arr[i].copy()) for i in range(arr.shape[0])]
-    return set(data["processed_files"]), embs, data["partial_metadata"]
-
-
+# -- the small JSON at the reference's checkpoint path (core_system.py:474-476); the vectors live in the build's shards
 def remove_checkpoint(ckpt_base):
     for ext in (".json", ".npy"):
         try:

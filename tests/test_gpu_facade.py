@@ -2,6 +2,7 @@
 (PE-Core-B16-224 on 32 local JPEGs, brute-force cosine top-5) against the CPU oracle
 run on the same decoded pixels; persistence, resume and the reference's result
 formatting."""
+import json
 import os
 
 import numpy as np
@@ -224,9 +225,9 @@ def test_device_resize_ingest_equals_host_resize(system):
 
 
 def test_resume_after_stop_in_storage_phase_builds_the_database(system, tmp_path):
-    """A stop (or crash) after the last embed batch but before the collection was written leaves a checkpoint
-    that marks every file processed and no meta.json.  Resuming must store the checkpointed vectors instead of
-    answering "already complete", and a later create_database for another name must not inherit those vectors."""
+    """A stop (or crash) after the last embed batch but before the collection was completed leaves a build directory whose
+    shards cover every file, and no database.  Resuming must complete it from those shards instead of answering "already
+    complete", and a later create_database for another name must not inherit those vectors."""
     r, folder, paths, root = system
     sub = tmp_path / "imgs"
     sub.mkdir()
@@ -238,11 +239,13 @@ def test_resume_after_stop_in_storage_phase_builds_the_database(system, tmp_path
             r.request_stop()
     out = r.create_database(str(sub), "stopped", use_direct_pe=True, progress_callback=stop_at_storage)
     assert "Processing stopped" in out
-    assert not os.path.exists(os.path.join(r.db_root, "stopped", "meta.json"))
-    assert r._partial_embeddings == [] and r._partial_metadata == []
+    assert not os.path.isdir(os.path.join(r.db_root, "stopped"))                      # nothing is visible as a database yet
+    assert os.path.exists(os.path.join(r.db_root, "stopped.building", "manifest.jsonl")) and "stopped.building" not in r.list_databases()
+    assert r._partial_embeddings == [] and r._partial_metadata == [] and r._build_store is None
     out = r.create_database(str(sub), "stopped", use_direct_pe=True, resume_from_checkpoint=True)
     assert "All files already embedded" in out and "ready for searching" in out, out
-    assert os.path.exists(os.path.join(r.db_root, "stopped", "meta.json")) and len(r.vector_db) == 6
+    assert os.path.exists(os.path.join(r.db_root, "stopped", "manifest.jsonl")) and len(r.vector_db) == 6
+    assert not os.path.isdir(os.path.join(r.db_root, "stopped.building"))
     # complete now: a second resume has nothing to do
     out = r.create_database(str(sub), "stopped", use_direct_pe=True, resume_from_checkpoint=True)
     assert "ready for searching" in out or "already processed" in out
@@ -252,3 +255,57 @@ def test_resume_after_stop_in_storage_phase_builds_the_database(system, tmp_path
     (other / "a.jpg").write_bytes(open(paths[10], "rb").read())
     out = r.create_database(str(other), "fresh", use_direct_pe=True)
     assert "Total embeddings stored: 1" in out and len(r.vector_db) == 1
+
+
+def test_killed_build_resumes_from_its_delta_shards(tmp_path, dev):
+    """Persistence that scales: a build writes its collection as delta shards (one .npy + one manifest
+    line per checkpoint, never the whole set).  A build of 6 batches is killed after its third shard -- an exception out
+    of the progress callback, nothing gets to clean up; a stray, half-written shard file is left behind as a crash would
+    -- and a NEW process-equivalent (fresh SimpleReverso) resumes it: the finished gallery holds exactly the bytes, ids
+    aside, of an uninterrupted build, in the same order; what was on disk before the kill was not rewritten."""
+    folder = str(tmp_path / "images")
+    paths = _make_jpegs(folder, n=24, seed=21)
+    ref = SimpleReverso(model_name="PE-Tiny-T14-56", db_root=str(tmp_path / "db_ref"), max_batch=4)
+    assert "✅" in ref.create_database(folder, "g", use_direct_pe=True)
+    want = ref.vector_db.gallery.read().cpu()
+    want_names = [p["filename"] for p in ref.vector_db.payloads]
+
+    class Kill(BaseException):
+        pass
+
+    def killer(msg, v=None):
+        if msg.startswith("💾 Checkpoint: shard 2 "):
+            raise Kill()
+    root = str(tmp_path / "db")
+    r = SimpleReverso(model_name="PE-Tiny-T14-56", db_root=root, max_batch=4, checkpoint_interval_s=0.0)
+    with pytest.raises(Kill):
+        r.create_database(folder, "g", use_direct_pe=True, progress_callback=killer)
+    build = os.path.join(root, "g.building")
+    lines = [json.loads(x) for x in open(os.path.join(build, "manifest.jsonl")).read().splitlines()]
+    assert [x.get("shard") for x in lines[1:]] == [0, 1, 2] and sum(x["rows"] for x in lines[1:]) == 12
+    before = {f: os.path.getmtime(os.path.join(build, f)) for f in os.listdir(build) if f.startswith("vectors.")}
+    assert sorted(before) == ["vectors.00000.f32.npy", "vectors.00001.f32.npy", "vectors.00002.f32.npy"]
+    open(os.path.join(build, "vectors.00003.f32.npy.tmp.npy"), "wb").write(b"torn")         # what a crash mid-write leaves
+    open(os.path.join(build, "manifest.jsonl"), "a").write('{"shard": 3, "file": "vectors.0')  # and a torn manifest line
+    del r
+    r2 = SimpleReverso(model_name="PE-Tiny-T14-56", db_root=root, max_batch=4, checkpoint_interval_s=0.0)
+    assert "g" not in r2.list_databases() and r2.load_database("g").startswith("❌")
+    msg = r2.create_database(folder, "g", use_direct_pe=True, resume_from_checkpoint=True)
+    assert "📋 Resuming from checkpoint: 12 files already processed" in msg and "ready for searching" in msg, msg[-600:]
+    assert "🔄 Processing 12/12" in msg and "Processing 13/" not in msg                    # only the other 12 files were embedded
+    got = r2.vector_db.gallery.read().cpu()
+    assert [p["filename"] for p in r2.vector_db.payloads] == want_names
+    assert torch.equal(got, want)
+    done = os.path.join(root, "g")
+    for f, t in before.items():
+        assert os.path.getmtime(os.path.join(done, f)) == t                                # the first three shards were not rewritten
+    # reload from disk: the same bytes; and the store keeps appending deltas after a save
+    r3 = SimpleReverso(model_name="PE-Tiny-T14-56", db_root=root, max_batch=4)
+    assert r3.load_database("g").startswith("✅")
+    assert torch.equal(r3.vector_db.gallery.read().cpu(), want) and len(r3.vector_db.payloads) == 24
+    n_files = len(os.listdir(done))
+    r3.vector_db.upsert(want[:2], ["x", "y"], [{"filename": "x"}, {"filename": "y"}])
+    r3.vector_db.save()
+    assert len(os.listdir(done)) == n_files + 1
+    r4 = SimpleReverso(model_name="PE-Tiny-T14-56", db_root=root, max_batch=4)
+    assert r4.load_database("g").startswith("✅") and len(r4.vector_db) == 26

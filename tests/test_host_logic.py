@@ -1,6 +1,7 @@
 """CPU: host-side logic above the C ABI (no device calls): database admin strings,
 checkpoint round trip, region metadata, preprocessing, the sharded-search protocol
 on gloo with world_size 2 (the oracle is injected as the compute step)."""
+import json
 import os
 import sys
 
@@ -52,18 +53,38 @@ def test_database_admin_strings(tmp_path):
     assert r._stop_requested
 
 
-def test_checkpoint_round_trip(tmp_path):
+def test_manifest_of_delta_shards_parsing(tmp_path):
+    """The append-only manifest of a collection (revers-o_amd/store.py): header, shard lines, the "complete" marker, rows
+    appended after a save, and a torn last line (a crash while appending) that ends the parse without losing what stands."""
+    man = str(tmp_path / "manifest.jsonl")
+    lines = [{"format": 2, "collection": "c", "dim": 16},
+             {"shard": 0, "file": "vectors.00000.f32.npy", "rows": 3, "ids": ["a", "b", "c"], "payloads": [{}, {}, {}], "files_done": ["x.jpg"]},
+             {"shard": 1, "file": None, "rows": 0, "ids": [], "payloads": [], "files_done": ["broken.jpg"]}]
+    with open(man, "w") as f:
+        f.write("".join(json.dumps(x) + "\n" for x in lines))
+    header, shards, complete, good = st.read_manifest(man)
+    assert header["dim"] == 16 and [x["shard"] for x in shards] == [0, 1] and not complete and good == os.path.getsize(man)
+    with open(man, "a") as f:
+        f.write(json.dumps({"complete": True, "rows": 3}) + "\n")
+    assert st.read_manifest(man)[2] is True
+    whole = os.path.getsize(man)
+    with open(man, "a") as f:
+        f.write('{"shard": 2, "file": "vectors.0')                      # torn: no newline, not JSON
+    header, shards, complete, good = st.read_manifest(man)
+    assert complete and len(shards) == 2 and good == whole
+    with open(man, "r+b") as f:
+        f.truncate(good)
+    with open(man, "a") as f:                                          # rows appended after a save: not complete until the next save
+        f.write(json.dumps({"shard": 2, "file": "vectors.00002.f32.npy", "rows": 1, "ids": ["d"], "payloads": [{}], "files_done": []}) + "\n")
+    assert st.read_manifest(man)[2] is False and len(st.read_manifest(man)[1]) == 3
+    open(str(tmp_path / "empty.jsonl"), "w").close()
+    with pytest.raises(ValueError):
+        st.read_manifest(str(tmp_path / "empty.jsonl"))
     base = str(tmp_path / "checkpoints" / "db_checkpoint")
-    embs = [torch.randn(16) for _ in range(5)]
-    metas = [{"region_id": str(i), "bbox": [0, 0, i, i], "filename": f"{i}.jpg"} for i in range(5)]
-    st.save_checkpoint(base, {"a.jpg", "b.jpg"}, embs, metas, "db", "/tmp/x")
-    files, e2, m2 = st.load_checkpoint(base)
-    assert files == {"a.jpg", "b.jpg"} and m2 == metas
-    assert all(torch.equal(a, b) for a, b in zip(embs, e2))
+    os.makedirs(os.path.dirname(base))
+    open(base + ".json", "w").write("{}")
     st.remove_checkpoint(base)
-    assert not os.path.exists(base + ".json") and not os.path.exists(base + ".npy")
-    st.save_checkpoint(base, set(), [], [], "db", "/tmp/x")       # empty checkpoint is valid
-    assert st.load_checkpoint(base) == (set(), [], [])
+    assert not os.path.exists(base + ".json")
 
 
 def test_region_metadata_rules(tmp_path):
