@@ -218,7 +218,9 @@ int32_t revo_prof_report(char* buf, int32_t capacity);
  * Bit-identical to PIL's  Image.crop(box).resize((S, S), Image.BILINEAR).
  * `jobs` is a HOST array; src pointers are device memory, interleaved RGB (H x W x 3).
  * out: device uint8 [n][3][out_size][out_size], ready for revo_vit_forward(image_dtype = 1).
- * The call returns after the work has completed on `stream`. */
+ * Asynchronous on `stream` like everything else (`jobs` is read before the call returns; the source frames and `out`
+ * must stay valid until the stream has run the work).  Calls on one device share a workspace: calls on one stream
+ * are ordered by it, a call on another stream first waits for the previous call's stream. */
 typedef struct revo_crop_job {
     const uint8_t* src;      /* device pointer to the top-left pixel of the source image */
     int32_t height, width;   /* source image size in pixels */

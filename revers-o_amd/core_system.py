@@ -69,7 +69,7 @@ class SimpleReverso:
     """Simplified visual investigation system (MI355X-native hot path)."""
 
     def __init__(self, model_name=DEFAULT_VARIANT, checkpoint=None, device=0, db_root=DB_ROOT, max_batch=64,
-                 detector=None, decode_workers=8, synthetic_seed=0, region_mode="global", device_resize=False,
+                 detector=None, decode_workers=None, synthetic_seed=0, region_mode="global", device_resize=False,
                  checkpoint_interval_s=30.0):
         print("🚀 Initializing Simple Revers-o...")
         if region_mode not in ("global", "crop"):
@@ -84,7 +84,12 @@ class SimpleReverso:
         self.db_root = db_root
         self.max_batch = int(max_batch)
         self.detector = detector
-        self._decode_pool = ThreadPoolExecutor(max_workers=int(decode_workers))
+        # decode threads of a gallery build.  None = by mode (create_database): MORE threads are not better -- PIL's
+        # RGBX -> RGB packing of a decoded frame runs under the GIL (0.35 ms per 640 x 480 frame), and the ingest thread,
+        # which has to keep the device's queue full, waits its turn behind every thread that wants it: measured on
+        # 3 000 JPEGs with device resize 1 950 images/s with 8 threads, 1 620 with 16, 1 720 with 32
+        self.decode_workers = None if decode_workers is None else int(decode_workers)
+        self._decode_pool = ThreadPoolExecutor(max_workers=self.decode_workers or 8)
         self._lock = threading.RLock()      # ui.py drives one shared instance from worker threads
         self.device = self.setup_device(device)
         self.pe_model, self.preprocess = self.load_pe_model(model_name, checkpoint, synthetic_seed)
@@ -99,6 +104,7 @@ class SimpleReverso:
         self._partial_embeddings = []
         self._partial_metadata = []
         self._build_store = None        # the collection a create_database call is building (closed when the call returns)
+        self.last_ingest_stats = None   # wall-clock stage times of the last create_database call
         print("✅ Simple Revers-o ready!")
 
     # ------------------------------------------------------------- DB admin --
@@ -251,18 +257,21 @@ class SimpleReverso:
             emb = self.pe_model.embed(u8.to(self.device, non_blocking=True))
         return emb.cpu()
 
-    def _embed_regions_batch(self, items, to_host=True):
+    def _embed_regions_batch(self, items, to_host=True, device_frames=None):
         """items: [(pil, metas)].  One vector per region of every image: the frames go to the device once,
         every region's bbox is cropped + squash-resized there in one launch (bit-identical to PIL
         crop().resize()), then forwards of max_batch crops.  Mask-derived boxes are inclusive
         (core_system.py:411).  Returns fp32 [n_regions, D] in item order: a CPU tensor, or with
         to_host=False the device tensor (the launches are asynchronous)."""
         frames, boxes = [], []
-        for pil, metas in items:
+        for n_item, (pil, metas) in enumerate(items):
             if not metas:
                 continue
             fi = len(frames)
-            frames.append(torch.from_numpy(np.array(pil, dtype=np.uint8)).to(self.device, non_blocking=True))
+            if device_frames is not None:
+                frames.append(device_frames[n_item])                    # already uploaded (create_database: one copy per batch)
+            else:
+                frames.append(torch.from_numpy(np.array(pil, dtype=np.uint8)).to(self.device, non_blocking=True))
             for m in metas:
                 x0, y0, x1, y1 = m["bbox"]
                 if m.get("mask_status") == "processed":
@@ -408,7 +417,9 @@ class SimpleReverso:
             """the rows and finished files since the last one, as a delta shard of the collection being built; the small
             JSON next to the reference's checkpoint path only says where the build lives"""
             try:
+                t_f = time.perf_counter()
                 rows = store_db.flush()
+                stats["flush_s"] += time.perf_counter() - t_f
                 os.makedirs(os.path.dirname(ckpt_base), exist_ok=True)
                 with open(ckpt_base + ".json.tmp", "w") as f:
                     json.dump({"database_name": database_name, "folder_path": folder_path, "build_path": build_path,
@@ -423,13 +434,27 @@ class SimpleReverso:
         host_resize = not self.device_resize and not (self.region_mode == "crop" and not use_direct_pe)
         model_size = self.pe_model.cfg.image_size
 
+        stats = {"images": len(image_files), "decode_thread_s": 0.0, "wait_decode_s": 0.0, "launch_s": 0.0,
+                 "bookkeeping_s": 0.0, "flush_s": 0.0}
+        self.last_ingest_stats = stats
+        t_start = time.perf_counter()
+
         def open_rgb(path, slot=None):
             """pool task: decode (and, on the host-resize path, squash-resize) one file; with `slot` (a row of the
             pinned staging batch) the resized image is written there instead of being returned"""
+            t_dec = time.perf_counter()
+            try:
+                return open_rgb_inner(path, slot)
+            finally:
+                stats["decode_thread_s"] += time.perf_counter() - t_dec      # (summed over the pool's threads; a float += under the GIL)
+
+        def open_rgb_inner(path, slot):
             try:
                 im = Image.open(path).convert("RGB")
                 if not host_resize:
-                    return im, None
+                    # the decoded frame goes to the device as it is (resized / cropped there): this thread leaves it in
+                    # a pinned buffer of its batch slot, so that the upload is one asynchronous copy
+                    return im, frame_to_pinned(im, slot)
                 u8 = pp.resize_u8(im, model_size)
                 if slot is None:
                     return im, u8
@@ -438,12 +463,79 @@ class SimpleReverso:
             except Exception as e:           # per-image failure: logged and skipped (core_system.py:585-591)
                 return e, None
 
+        class FrameSlab:
+            """Pinned host memory for the decoded frames of ONE batch: the decode threads reserve ranges (a bump counter
+            under a lock) and copy their frames in; the ingest thread uploads the used prefix with one asynchronous
+            copy.  A frame that does not fit goes up from pageable memory and the slab is enlarged for the next round."""
+
+            def __init__(self):
+                # no memory yet: the first batch of a slab goes up from pageable memory (a blocking copy, but the device
+                # is idle then) and tells how much the slab needs; pinning it (tens of ms) happens when the slab comes
+                # round again, by which time the device has batches queued
+                self.buf = torch.empty(0, dtype=torch.uint8)
+                self.lock = threading.Lock()
+                self.used = 0
+                self.wanted = 0
+
+            def reset(self):
+                if self.wanted > self.buf.numel():
+                    self.buf = torch.empty(int(self.wanted * 1.25), dtype=torch.uint8).pin_memory()
+                self.used = self.wanted = 0
+
+            def put(self, arr):
+                size = (arr.size + 255) & ~255
+                with self.lock:
+                    off = self.used
+                    self.wanted += size
+                    if off + size > self.buf.numel():
+                        return None, torch.from_numpy(np.array(arr, dtype=np.uint8))
+                    self.used = off + size
+                np.copyto(self.buf[off:off + arr.size].view(arr.shape).numpy(), arr)
+                return off, arr.shape
+
+        def frame_to_pinned(im, slot):
+            arr = np.asarray(im)
+            if slot is None:
+                return None, torch.from_numpy(np.array(arr, dtype=np.uint8))
+            return slot.put(arr)
+
+        def upload_frames(slab, handles):
+            """handles: what frame_to_pinned returned for the batch's good files.  One asynchronous copy of the slab's
+            used prefix; returns the device frames (views into it), in order."""
+            dev_slab = slab.buf[:slab.used].to(self.device, non_blocking=True) if slab.used else None
+            out = []
+            for off, x in handles:
+                if off is None:
+                    out.append(x.to(self.device, non_blocking=True))            # did not fit: pageable upload
+                else:
+                    n = x[0] * x[1] * x[2]
+                    out.append(dev_slab[off:off + n].view(x))
+            return out
+
         B = self.max_batch
+        # enough decode threads to feed the device in this mode and no more (see __init__): host resize costs 9 ms of
+        # thread time per 640 x 480 JPEG, decode alone 4 ms; crops are embedded three to an image
+        want_threads = self.decode_workers or (16 if host_resize else (6 if self.region_mode == "crop" and not use_direct_pe else 8))
+        if want_threads != self._decode_pool._max_workers:
+            self._decode_pool.shutdown(wait=True)
+            self._decode_pool = ThreadPoolExecutor(max_workers=want_threads)
+
+        # The pool works DEPTH batches ahead of the one being embedded (one batch ahead left it idle between
+        # submissions: 1 650 decoded images/s in the loop against 3 700 for the pool alone).  Batch n's host buffer --
+        # staging rows or frame slab -- is number n % NSLOT: decoding (DEPTH of them) / waiting / being uploaded.
+        DEPTH = 2
+        NSLOT = DEPTH + 2
+        slabs = [FrameSlab() for _ in range(NSLOT)] if not host_resize else None
+        frames_done = [None] * NSLOT         # event behind the upload that read a slab
 
         def submit(s0):
             if stage is not None:            # batch s0 // B fills staging buffer (s0 // B) & 1, one row per file
-                buf = stage[(s0 // B) & 1]
+                buf = stage[(s0 // B) % NSLOT]
                 return [self._decode_pool.submit(open_rgb, p, buf[j]) for j, p in enumerate(image_files[s0:s0 + B])]
+            if not host_resize:
+                slab = slabs[(s0 // B) % NSLOT]
+                slab.reset()
+                return [self._decode_pool.submit(open_rgb, p, slab) for p in image_files[s0:s0 + B]]
             return [self._decode_pool.submit(open_rgb, p) for p in image_files[s0:s0 + B]]
 
         # Three things overlap: the pool decodes batch i+1, the device embeds batch i (its vectors come back through a
@@ -453,14 +545,27 @@ class SimpleReverso:
         pipelined = host_resize and not crop_mode
         stage = None
         if pipelined:
-            stage = [torch.zeros((B, 3, model_size, model_size), dtype=torch.uint8).pin_memory() for _ in range(2)]
-        pending = submit(0)
+            stage = [torch.zeros((B, 3, model_size, model_size), dtype=torch.uint8).pin_memory() for _ in range(NSLOT)]
+        h2d_done = [None] * NSLOT
+        pending = []                         # futures of the batches being decoded, oldest first
+        submitted = [0]
+
+        def top_up(it):
+            """keep the pool DEPTH batches ahead of batch `it`; a buffer is handed out again only after the upload that
+            read it (NSLOT batches ago) has left the host"""
+            while submitted[0] <= it + DEPTH and submitted[0] * B < len(image_files):
+                bn = submitted[0]
+                for ev in (h2d_done[bn % NSLOT], frames_done[bn % NSLOT]):
+                    if ev is not None:
+                        ev.synchronize()
+                pending.append(submit(bn * B))
+                submitted[0] += 1
 
         def finalize(item):
             """bookkeeping of one embedded batch: metadata per image, then the batch's vectors -- still on the device --
             go straight into the collection being built (device-to-device append; nothing visits the host)"""
             nonlocal failed
-            s, paths, pils, dev_emb, by_file, last = item
+            s, paths, pils, hosts, dev_emb, by_file, last = item
             gi = 0
             batch_items = []                       # (path, pil, metas, row of dev_emb or None)
             for j, (path, im) in enumerate(zip(paths, pils)):
@@ -494,12 +599,16 @@ class SimpleReverso:
                     m["filename"] = filename
                     m["original_region_id"] = m.get("region_id", _uuid4())
                     m["region_id"] = _uuid4()
-                batch_items.append((path, im, metas, row))
+                batch_items.append((path, im, metas, row, hosts[j]))
             if crop_mode:
-                # region crops of the whole batch: frames go to the device once, one crop + resize launch, forwards of
-                # max_batch crops; the vectors stay on the device
+                # region crops of the whole batch: the frames go up from their pinned buffers (asynchronous copies), one
+                # crop + resize launch, forwards of max_batch crops -- nothing here waits for the device; the vectors stay there
                 with torch.cuda.device(self.device):
-                    dev = self._embed_regions_batch([(im, metas) for _, im, metas, _ in batch_items], to_host=False)
+                    dev = self._embed_regions_batch([(im, metas) for _, im, metas, _, _ in batch_items], to_host=False,
+                                                    device_frames=upload_frames(slabs[(s // B) % NSLOT],
+                                                                                [h for _, _, _, _, h in batch_items]))
+                    frames_done[(s // B) % NSLOT] = torch.cuda.Event()
+                    frames_done[(s // B) % NSLOT].record()
                 store(batch_items, dev, None, last)
                 return
             store(batch_items, None, dev_emb, last)
@@ -511,7 +620,7 @@ class SimpleReverso:
             whose vectors it does not hold)"""
             nonlocal processed, last_ckpt
             metas_all, rows = [], []
-            for path, im, metas, row in batch_items:
+            for path, im, metas, row, _ in batch_items:
                 metas_all.extend(metas)
                 if region_vecs is None:
                     rows.extend([row] * len(metas))            # every region of an image stores its global vector (core_system.py:406-408)
@@ -531,13 +640,12 @@ class SimpleReverso:
                 store_db.upsert(torch.zeros((0, store_db.dim)), [], [], files=list(done_files))
             processed_files.update(done_files)
             done_files.clear()
-            # a checkpoint writes only what is new: at most one per interval, and one at the end
-            if time.monotonic() - last_ckpt >= self.checkpoint_interval_s or last:
+            # a checkpoint writes only what is new: at most one per interval (the end of the build writes the last shard itself)
+            if time.monotonic() - last_ckpt >= self.checkpoint_interval_s and not last:
                 checkpoint()
                 last_ckpt = time.monotonic()
 
         inflight = None
-        h2d_done = [None, None]
         for it, s in enumerate(range(0, len(image_files), B)):
             if self._stop_requested:
                 if inflight is not None:
@@ -547,11 +655,14 @@ class SimpleReverso:
                 checkpoint()
                 return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
             paths = image_files[s:s + B]
-            if h2d_done[(it + 1) & 1] is not None:
-                h2d_done[(it + 1) & 1].synchronize()      # the staging buffer the next batch's decode fills has left the host
-            futures, pending = pending, (submit(s + B) if s + B < len(image_files) else [])
+            top_up(it)
+            futures = pending.pop(0)
+            t_w = time.perf_counter()
             results = [f.result() for f in futures]
+            stats["wait_decode_s"] += time.perf_counter() - t_w
+            t_l = time.perf_counter()
             pils = [r[0] for r in results]
+            hosts = [r[1] for r in results]
             good = [r for r in results if not isinstance(r[0], Exception)]
             # global vectors of the whole batch in one forward (not needed when every region is cropped)
             dev_emb = None
@@ -559,24 +670,30 @@ class SimpleReverso:
                 if pipelined:
                     # every file of the batch has its row in the staging buffer (a failed file's row keeps whatever it
                     # held: embedded and never looked at)
-                    buf = stage[it & 1][:len(paths)]
+                    buf = stage[it % NSLOT][:len(paths)]
                     with self._lock, torch.cuda.device(self.device):
                         dev_in = buf.to(self.device, non_blocking=True)
-                        h2d_done[it & 1] = torch.cuda.Event()
-                        h2d_done[it & 1].record()
+                        h2d_done[it % NSLOT] = torch.cuda.Event()
+                        h2d_done[it % NSLOT].record()
                         dev_emb = self.pe_model.embed(dev_in)
                 else:
                     # device resize: the decoded frames go up as they are, one crop + resize launch, one forward
                     with self._lock, torch.cuda.device(self.device):
-                        frames = [torch.from_numpy(np.array(pp.to_pil(im), dtype=np.uint8)).to(self.device, non_blocking=True)
-                                  for im, _ in good]
+                        frames = upload_frames(slabs[it % NSLOT], [h for _, h in good])
+                        frames_done[it % NSLOT] = torch.cuda.Event()
+                        frames_done[it % NSLOT].record()
                         dev_emb = self.pe_model.embed(pp.crop_resize_device(frames, None, model_size))
-            cur = (s, paths, pils, dev_emb, pipelined, s + B >= len(image_files))
+            stats["launch_s"] += time.perf_counter() - t_l
+            cur = (s, paths, pils, hosts, dev_emb, pipelined, s + B >= len(image_files))
             if inflight is not None:
+                t_b = time.perf_counter()
                 finalize(inflight)
+                stats["bookkeeping_s"] += time.perf_counter() - t_b
             inflight = cur
         if inflight is not None:
+            t_b = time.perf_counter()
             finalize(inflight)
+            stats["bookkeeping_s"] += time.perf_counter() - t_b
 
         if len(store_db) == 0:
             return str(log_status("❌ No embeddings extracted from any images"))
@@ -588,7 +705,9 @@ class SimpleReverso:
             checkpoint()
             return "\n".join(status_messages) + "\n\n⏸️ Processing stopped. You can resume later."
         with self._lock:
+            t_f = time.perf_counter()
             store_db.save()                                     # the last delta shard + the "complete" line
+            stats["flush_s"] += time.perf_counter() - t_f
             log_status(f"💾 Stored {len(store_db)} points in {store_db._shards} shards", 0.9)
             if self.vector_db is not None:
                 self.vector_db.close()
@@ -602,6 +721,8 @@ class SimpleReverso:
         if os.path.exists(ckpt_base + ".json"):
             st.remove_checkpoint(ckpt_base)
             log_status("🧹 Cleaned up checkpoint file")
+        stats["total_s"] = time.perf_counter() - t_start
+        stats["vectors"] = len(self.vector_db)
         log_status("\n📊 Final Summary:", 0.9)
         log_status(f"✅ Successfully processed: {processed} images")
         if failed > 0:

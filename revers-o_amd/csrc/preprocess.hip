@@ -10,6 +10,7 @@
 // coefficient kernel therefore runs in fp64 with contraction off.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -134,6 +135,15 @@ struct PreWorkspace {
     long coeffs_cap = 0;
     uint8_t* tmp = nullptr;
     long tmp_cap = 0;
+    // the job table travels through a ring of pinned host buffers (the call does not wait for its copy: a buffer is
+    // reused only after the copy that read it has run), and calls are ordered by the stream they are enqueued on
+    static constexpr int RING = 8;
+    CropJobDev* pin[RING] = {};
+    int pin_cap[RING] = {};
+    hipEvent_t pin_ev[RING] = {};
+    int ring = 0;
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
 };
 static PreWorkspace g_ws[16];
 static std::mutex g_ws_mutex;
@@ -173,8 +183,12 @@ static int crop_resize(const revo_crop_job* jobs, int n, int S, uint8_t* out, hi
     }
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     PreWorkspace& w = g_ws[dev];
+    // The device workspace (job table, filter tables, the intermediate rows) is shared by the calls on this device:
+    // calls on ONE stream are ordered by it; a call on another stream first waits for the previous one's.
+    if (w.has_last && w.last_stream != st) REVO_HIP_CHECK(hipStreamSynchronize(w.last_stream));
+    w.last_stream = st; w.has_last = true;
     if (n > w.jobs_cap) {
-        if (w.jobs) REVO_HIP_CHECK(hipFree(w.jobs));
+        if (w.jobs) REVO_HIP_CHECK(hipFree(w.jobs));          // (hipFree waits for the device: nothing still reads it)
         w.jobs = nullptr;
         w.jobs_cap = 0;
         REVO_HIP_CHECK(hipMalloc((void**)&w.jobs, sizeof(CropJobDev) * (size_t)(n + 64)));
@@ -184,7 +198,18 @@ static int crop_resize(const revo_crop_job* jobs, int n, int S, uint8_t* out, hi
     if (int rc = grow(w.bounds, w.bounds_cap, (long)n * 2 * S * 2)) return rc;
     if (int rc = grow(w.coeffs, w.coeffs_cap, (long)n * 2 * S * KS)) return rc;
     if (int rc = grow(w.tmp, w.tmp_cap, (long)n * tmp_job_stride)) return rc;
-    REVO_HIP_CHECK(hipMemcpyAsync(w.jobs, host.data(), sizeof(CropJobDev) * (size_t)n, hipMemcpyHostToDevice, st));
+    const int slot = w.ring++ % PreWorkspace::RING;
+    if (w.pin_ev[slot]) REVO_HIP_CHECK(hipEventSynchronize(w.pin_ev[slot]));     // eight calls back: long done
+    else REVO_HIP_CHECK(hipEventCreateWithFlags(&w.pin_ev[slot], hipEventDisableTiming));
+    if (n > w.pin_cap[slot]) {
+        if (w.pin[slot]) REVO_HIP_CHECK(hipHostFree(w.pin[slot]));
+        w.pin[slot] = nullptr; w.pin_cap[slot] = 0;
+        REVO_HIP_CHECK(hipHostMalloc((void**)&w.pin[slot], sizeof(CropJobDev) * (size_t)(n + 64), hipHostMallocDefault));
+        w.pin_cap[slot] = n + 64;
+    }
+    memcpy(w.pin[slot], host.data(), sizeof(CropJobDev) * (size_t)n);
+    REVO_HIP_CHECK(hipMemcpyAsync(w.jobs, w.pin[slot], sizeof(CropJobDev) * (size_t)n, hipMemcpyHostToDevice, st));
+    REVO_HIP_CHECK(hipEventRecord(w.pin_ev[slot], st));
     hipLaunchKernelGGL(resize_coeffs_kernel, dim3(n * 2), dim3(256), 0, st, w.jobs, S, KS, w.bounds, w.coeffs);
     REVO_HIP_CHECK(hipGetLastError());
     const int bx = (S + 255) / 256;
@@ -194,9 +219,7 @@ static int crop_resize(const revo_crop_job* jobs, int n, int S, uint8_t* out, hi
     hipLaunchKernelGGL(resize_v_kernel, dim3(bx, S, n), dim3(256), 0, st, w.jobs, S, KS, w.bounds, w.coeffs, w.tmp,
                        tmp_job_stride, out);
     REVO_HIP_CHECK(hipGetLastError());
-    // the workspace is reused by the next call: keep calls on one device ordered
-    REVO_HIP_CHECK(hipStreamSynchronize(st));
-    return 0;
+    return 0;                       // asynchronous: an ingest queues batch after batch without waiting for the device
 }
 
 }  // namespace revo
