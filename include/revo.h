@@ -181,7 +181,8 @@ int32_t revo_op_set_gemm_tile(int32_t tile);
 /* bits 4-7 = force the XCD arrangement (N-stripes 1, 2, 4 or 8; 0 = heuristic), bits 8-11 = force the attention
  * waves per workgroup, bit 12 = disable the GEMM tail split, bit 16 = one workgroup per tile instead of the persistent
  * 256 x 256 GEMM, bit 17 = no split-K for the leftover rows of a residual GEMM, bit 18 = 256 x 256 tiles also for
- * problems with fewer than 100 of them; 0 = normal */
+ * problems with fewer than 100 of them, bit 19 = the two-buffer 128 x 64 kernel instead of its six-deep-ring form;
+ * 0 = normal */
 int32_t revo_op_set_variant(int32_t flags);
 /* Timing experiments.  The variant bits above plus: bit 0 = skip the GEMM epilogue stores, bit 1 = skip the GEMM main loop,
  * bit 13 = skip the scan's selection, bit 15 = skip the scan's slow path (all four: WRONG RESULTS),

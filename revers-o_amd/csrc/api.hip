@@ -550,9 +550,11 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
 
     // ln_post (fp32, in place) -> attention pool -> proj -> normalise: all fp32 (head.hip says why)
     { ProfScope ps("layernorm", st);
-      CHECK_RC(launch_layernorm(v->x, W, v->lnpost_w, v->lnpost_b, c.ln_eps, rows, W, v->x, W, 0, st)); }
+      // (the pool's logits come out of the same kernel: the normalised row is in registers there)
+      const LnLogits lg{v->qk, v->ck, v->pool_logits, PH, S};
+      CHECK_RC(launch_layernorm(v->x, W, v->lnpost_w, v->lnpost_b, c.ln_eps, rows, W, v->x, W, 0, st, &lg)); }
     { ProfScope ps("pool_attention", st);
-      CHECK_RC(launch_pool_head_rows(v->x, W, v->qk, v->ck, B, S, W, PH, v->pool_logits, v->pool_u, st)); }
+      CHECK_RC(launch_pool_head_rows(v->x, W, nullptr, nullptr, B, S, W, PH, v->pool_logits, v->pool_u, st)); }
     { ProfScope ps("gemm_pool", st);
       // values: head h's output columns from head h's pooled row
       CHECK_RC(launch_gemm_f32_skinny(0, v->pool_u, (long)PH * W, W, v->phd, v->w_v, W, v->b_v, B, W, W, v->pool_att, W, st));
@@ -1049,6 +1051,7 @@ extern "C" int32_t revo_op_set_variant(int32_t flags) {
     revo::gemm_set_persistent(((flags >> 16) & 1) ? 0 : 1);
     revo::gemm_set_splitk(((flags >> 17) & 1) ? 0 : 1);
     revo::gemm_set_min_tiles256(((flags >> 18) & 1) ? 0 : 100);
+    revo::gemm_set_ring(((flags >> 19) & 1) ? 0 : 1, 0);
     return 0;
 }
 extern "C" int32_t revo_op_set_gemm_tile(int32_t tile) {

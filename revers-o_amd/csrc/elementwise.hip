@@ -9,10 +9,14 @@ namespace revo {
 // ------------------------------------------------------------ LayerNorm ----
 // One wave per row; the row lives in registers (W <= 64*4*MAXC), two-pass fp32
 // statistics exactly as torch.nn.functional.layer_norm computes them.
+// lg (optional, fp32 output only): the attention-pool logits of the normalised row against the H probe-key vectors
+// (head.hip): logits[(row / S * H + h) * S + row % S] = y . qk_h + ck_h, computed from the registers that hold the row
+// (ln_post feeds nothing but the pool: its rows are read once more instead of twice)
 template <int MAXC, bool OUT_BF16>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx,
                                                         const float* __restrict__ w, const float* __restrict__ b,
-                                                        float eps, int rows, int W, void* __restrict__ out, long ldo) {
+                                                        float eps, int rows, int W, void* __restrict__ out, long ldo,
+                                                        LnLogits lg) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -44,6 +48,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
+    float lacc[LN_MAXH];
+#pragma unroll
+    for (int h = 0; h < LN_MAXH; ++h) lacc[h] = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
@@ -53,6 +60,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             f32x4 y;
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = fmaf((v[i][j] - mean) * rstd, g[j], be[j]);
+            if (!OUT_BF16 && lg.qk) {
+#pragma unroll
+                for (int h = 0; h < LN_MAXH; ++h)
+                    if (h < lg.H) {
+                        const f32x4 k4 = *(const f32x4*)(lg.qk + (long)h * W + c * 4);
+                        lacc[h] = fmaf(y[0], k4[0], lacc[h]);
+                        lacc[h] = fmaf(y[1], k4[1], lacc[h]);
+                        lacc[h] = fmaf(y[2], k4[2], lacc[h]);
+                        lacc[h] = fmaf(y[3], k4[3], lacc[h]);
+                    }
+            }
             if (OUT_BF16) {
                 uint2 o;
                 o.x = pack_bf16x2(y[0], y[1]);
@@ -62,6 +80,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 *(f32x4*)((float*)out + (long)row * ldo + c * 4) = y;
             }
         }
+    }
+    if (!OUT_BF16 && lg.qk) {
+        const long bb = row / lg.S, ss = row - bb * lg.S;
+#pragma unroll
+        for (int h = 0; h < LN_MAXH; ++h)
+            if (h < lg.H) {
+                const float t = wave_sum(lacc[h]);
+                if (lane == 0) lg.logits[(bb * lg.H + h) * lg.S + ss] = t + lg.ck[h];
+            }
     }
 }
 
@@ -128,7 +155,12 @@ __global__ __launch_bounds__(256) void layernorm8_kernel(const float* __restrict
 }
 
 int launch_layernorm(const float* x, long ldx, const float* w, const float* b, float eps, int rows, int W, void* out,
-                     long ldo, int out_is_bf16, hipStream_t st) {
+                     long ldo, int out_is_bf16, hipStream_t st, const LnLogits* logits) {
+    LnLogits lg{};
+    if (logits) {
+        REVO_REQUIRE(!out_is_bf16 && logits->H >= 1 && logits->H <= LN_MAXH && logits->S >= 1, "layernorm: pool logits need fp32 output and at most 16 heads");
+        lg = *logits;
+    }
     REVO_REQUIRE(W % 4 == 0 && W <= 2048, "layernorm: W must be a multiple of 4 and <= 2048");
     REVO_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0, "layernorm: row strides must be multiples of 4");
     if (rows <= 0) return 0;
@@ -146,9 +178,9 @@ int launch_layernorm(const float* x, long ldx, const float* w, const float* b, f
     const int chunks = (W / 4 + 63) / 64;
 #define LN_LAUNCH(MC)                                                                                              \
     if (out_is_bf16)                                                                                               \
-        hipLaunchKernelGGL((layernorm_kernel<MC, true>), grid, block, 0, st, x, ldx, w, b, eps, rows, W, out, ldo); \
+        hipLaunchKernelGGL((layernorm_kernel<MC, true>), grid, block, 0, st, x, ldx, w, b, eps, rows, W, out, ldo, lg); \
     else                                                                                                           \
-        hipLaunchKernelGGL((layernorm_kernel<MC, false>), grid, block, 0, st, x, ldx, w, b, eps, rows, W, out, ldo);
+        hipLaunchKernelGGL((layernorm_kernel<MC, false>), grid, block, 0, st, x, ldx, w, b, eps, rows, W, out, ldo, lg);
     if (chunks <= 1) { LN_LAUNCH(1) }
     else if (chunks <= 3) { LN_LAUNCH(3) }
     else if (chunks <= 4) { LN_LAUNCH(4) }

@@ -290,6 +290,44 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm128_kernel(GemmArgs p) {
     gemm_epilogue<EPI, MF, NF>(p, m0 + wr * 64, n0 + wc * (BN / 2), lane, acc);
 }
 
+// The 128 x 64 tile with a six-deep DMA ring (gemm_core.h gemm_mainloop_ring), 144 KiB LDS: one workgroup per CU with
+// five K-steps of loads in flight.  For problems of about one tile per CU: one image (577 rows), the leftover rows of
+// the residual GEMMs at large batch.
+constexpr int G128R_NST = 6;
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm128r_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 128, BN = 64, MF = 4, NF = BN / 32;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int s = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = s / tiles_n, tn = s - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    if (EPI == EPI_F32 && p.ksplit > 1) {
+        // split-K partial (one image's fc2: 80 tiles with 64 K-steps each): blockIdx.y owns K-tiles [y nt / S, (y+1) nt / S) and
+        // writes plain fp32 sums to its own output plane; splitk_reduce_resid_kernel adds the planes in a fixed order
+        const int nt = p.K >> 6, t0 = (int)blockIdx.y * nt / p.ksplit, t1 = ((int)blockIdx.y + 1) * nt / p.ksplit;
+        p.A += t0 * 64;
+        p.B += t0 * 64;
+        p.K = (t1 - t0) * 64;
+        p.C = (float*)p.C + (long)blockIdx.y * p.c_split_stride;
+    }
+    TileLoader<BM> la;
+    TileLoader<BN> lb;
+    la.init(p.A, p.lda, m0, p.M, wave, lane);
+    lb.init(p.B, p.ldb, n0, p.N, wave, lane);
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gemm_mainloop_ring<BM, BN, MF, NF, G128R_NST>(la, lb, smem, p.K, wave, lane, wr * 64, wc * (BN / 2), acc);
+    gemm_epilogue<EPI, MF, NF>(p, m0 + wr * 64, n0 + wc * (BN / 2), lane, acc);
+}
+
 // 256 x 256 x 64 tile, 8 waves as 2 (M) x 4 (N), each 128 x 64; see gemm256_core.h.
 // DBG (compile time, scripts/gemm_ksweep.py only): 1 = no epilogue stores, 2 = no main loop.
 template <int EPI, int DBG>
@@ -580,6 +618,8 @@ bool gemm_uses_wide_epilogue(int M, int N, long lda, long ldb, long ldc) {
 template <int EPI>
 static int launch_128(const GemmArgs& a, hipStream_t st);
 
+static int g_ring = 1, g_ring_max_tiles = 256;     // the ring kernel on (timing experiments: off) / its largest problem: one tile per CU
+void gemm_set_ring(int on, int max_tiles) { g_ring = on; if (max_tiles > 0) g_ring_max_tiles = max_tiles; }
 static int g_tail_split = 1;   // timing experiments only: 0 disables the tail split below
 void gemm_set_tail_split(int on) { g_tail_split = on; }
 
@@ -609,6 +649,28 @@ void gemm_set_splitk(int on) { g_splitk = on; }
 static int try_splitk_tail(const GemmArgs& a, hipStream_t st) {
     if (!g_splitk || !a.ws || a.N % 4 || a.K < 2048) return 0;
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256, nt = a.K / 64;
+    {
+        // one image: so few tiles that even 128 x 64 ones leave most CUs idle -- the ring kernel on K thirds (80 tiles x 3)
+        const int tiles64 = ((a.M + 127) / 128) * ((a.N + 63) / 64);
+        int S = g_ring && a.N % 64 == 0 ? 256 / tiles64 : 0;
+        S = S > 8 ? 8 : S;
+        while (S > 1 && nt / S < 8) --S;
+        const long plane = (long)a.M * a.N;
+        if (S >= 2 && plane * S <= a.ws_elems) {
+            constexpr int LDS = G128R_NST * (128 + 64) * 128;
+            REVO_FUNC_LDS((gemm128r_kernel<EPI_F32>), LDS);
+            GemmArgs b = a;
+            b.C = a.ws; b.ldc = a.N; b.bias = nullptr; b.gamma = nullptr;
+            b.ksplit = S; b.c_split_stride = plane;
+            hipLaunchKernelGGL((gemm128r_kernel<EPI_F32>), dim3(tiles64, S), dim3(GEMM_THREADS), LDS, st, b);
+            REVO_HIP_CHECK(hipGetLastError());
+            const long quads = plane / 4;
+            hipLaunchKernelGGL(splitk_reduce_resid_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a.ws, S, plane,
+                               a.M, a.N, a.bias, a.gamma, (float*)a.C, a.ldc);
+            REVO_HIP_CHECK(hipGetLastError());
+            return 1;
+        }
+    }
     // XCD arrangement that spreads these few tiles most evenly (an XCD has 32 CUs: its tiles x S must fit)
     int gy = 1, per = 1 << 30;
     for (int g : {1, 2, 4, 8}) {
@@ -702,6 +764,14 @@ static int launch_128(const GemmArgs& a, hipStream_t st) {
     // K step of a workgroup and put two or three of them on a CU
     if (g_force_tile == 0 && tiles <= 384 && a.K >= 512 && a.N % 64 == 0) {
         const int tiles64 = ((a.M + 127) / 128) * ((a.N + 63) / 64);
+        if (g_ring && tiles64 <= g_ring_max_tiles) {
+            // about one tile per CU: the K loop is a chain of DMA latencies -- six-deep ring, one workgroup per CU
+            constexpr int LDS = G128R_NST * (128 + 64) * 128;
+            REVO_FUNC_LDS((gemm128r_kernel<EPI>), LDS);
+            hipLaunchKernelGGL((gemm128r_kernel<EPI>), dim3(tiles64), dim3(GEMM_THREADS), LDS, st, a);
+            REVO_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         hipLaunchKernelGGL((gemm128_kernel<EPI, 64>), dim3(tiles64), dim3(GEMM_THREADS), 2 * (128 + 64) * 128, st, a);
     } else {
         hipLaunchKernelGGL((gemm128_kernel<EPI, 128>), dim3(tiles), dim3(GEMM_THREADS), 2 * (128 + 128) * 128, st, a);

@@ -101,4 +101,50 @@ __device__ __forceinline__ void gemm_mainloop(const TileLoader<BM>& la, const Ti
     }
 }
 
+// The same K loop with an NST-deep ring of stages instead of two: NST - 1 K-steps of DMA are in flight while one is
+// multiplied.  For problems with about one tile per CU (one image: 577 rows; the leftover rows of a big GEMM) the K loop
+// is a chain of DMA latencies (~1.1 us per step with two buffers: 18 us for K = 1024 whatever the tile computes); five
+// loads in flight turn it into ~0.25 us per step.  The wait is a COUNTED vmcnt (a wave's DMA loads retire in order):
+// step t may start when at most `ahead` later stages are still outstanding; the barrier is a raw s_barrier
+// (__syncthreads() would drain every outstanding load).  smem: NST x (BM + BN) x 128 bytes.  K % 64 == 0.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int MF, int NF, int NST>
+__device__ __forceinline__ void gemm_mainloop_ring(const TileLoader<BM>& la, const TileLoader<BN>& lb, char* smem, int K,
+                                                   int wave, int lane, int rowA0, int rowB0, f32x4 (&acc)[MF][NF]) {
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+    constexpr int NLD = TileLoader<BM>::NI + TileLoader<BN>::NI;      // DMA instructions per wave and stage
+    static_assert(NST >= 3 && NST <= 6 && (NST - 2) * NLD <= 63, "vmcnt holds 6 bits");
+    const int nt = K / GEMM_BK;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nt) {
+            la.issue(smem + s * STAGE, s * GEMM_BK, wave);
+            lb.issue(smem + s * STAGE + A_BYTES, s * GEMM_BK, wave);
+        }
+    int buf = 0;                                                      // stage that holds K-step t
+    for (int t = 0; t < nt; ++t) {
+        const int left = nt - 1 - t;
+        const int ahead = left < NST - 2 ? left : NST - 2;             // later stages that may still be in flight
+        switch (ahead) {
+            case 0: wait_vmcnt_n<0>(); break;
+            case 1: wait_vmcnt_n<NLD>(); break;
+            case 2: wait_vmcnt_n<(NST > 3 ? 2 : 0) * NLD>(); break;
+            case 3: wait_vmcnt_n<(NST > 4 ? 3 : 0) * NLD>(); break;
+            default: wait_vmcnt_n<(NST > 5 ? 4 : 0) * NLD>(); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // everybody's share of stage t has landed; everybody is done reading stage t - 1
+        const int tn = t + NST - 1;
+        if (tn < nt) {                          // refill the stage that was read in step t - 1
+            const int nb = buf == 0 ? NST - 1 : buf - 1;
+            la.issue(smem + nb * STAGE, tn * GEMM_BK, wave);
+            lb.issue(smem + nb * STAGE + A_BYTES, tn * GEMM_BK, wave);
+        }
+        mma_kstep<MF, NF>(smem + buf * STAGE, smem + buf * STAGE + A_BYTES, rowA0, rowB0, lane, acc);
+        buf = buf + 1 == NST ? 0 : buf + 1;
+    }
+}
+
 }  // namespace revo

@@ -81,17 +81,19 @@ __global__ __launch_bounds__(256) void pool_logits_kernel(const float* __restric
 
 // --------------------------------------------------------------- pooled rows ----
 // u[(b * H + h) * W + c] = sum_s softmax_s(logits[b, h, :])[s] * x[b * S + s][c]
-// grid (W / 64, B): a workgroup owns 64 columns of one image; its four waves take the token rows s = w, w + 4, ...
-// (every element of x is read once, by one lane), each thread carries all H heads; the four partial sums meet in LDS
-// in a fixed order.  The softmax of the image's H x S logits is recomputed by every workgroup (a few thousand exps).
-__global__ __launch_bounds__(256) void pool_accumulate_kernel(const float* __restrict__ x, long ldx,
+// grid (W / 64, B): a workgroup owns 64 columns of one image; its sixteen waves take the token rows s = w, w + 16, ...
+// (every element of x is read once, by one lane; eight rows in flight per lane -- with four waves and four rows one
+// image took 94 us), each thread carries all H heads; the partial sums meet in LDS in a fixed order.  The softmax of the
+// image's H x S logits is recomputed by every workgroup (a few thousand exps).
+constexpr int PA_WAVES = 16;
+__global__ __launch_bounds__(PA_WAVES * 64) void pool_accumulate_kernel(const float* __restrict__ x, long ldx,
                                                               const float* __restrict__ logits, int S, int W, int H,
                                                               float* __restrict__ u) {
-    extern __shared__ float psm[];                    // [H][S] probabilities, then [4][H][64] partial sums
+    extern __shared__ float psm[];                    // [H][S] probabilities, then [PA_WAVES][H][64] partial sums
     float* red = psm + (long)H * S;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.y, c = blockIdx.x * 64 + lane;
-    for (int h = w; h < H; h += 4) {
+    for (int h = w; h < H; h += PA_WAVES) {
         const float* lg = logits + ((long)b * H + h) * S;
         float m = -INFINITY;
         for (int s = lane; s < S; s += 64) m = fmaxf(m, lg[s]);
@@ -112,8 +114,18 @@ __global__ __launch_bounds__(256) void pool_accumulate_kernel(const float* __res
     for (int h = 0; h < PL_MAXH; ++h) acc[h] = 0.f;
     if (c < W) {
         const float* xc = x + (long)b * S * ldx + c;
-#pragma unroll 4
-        for (int s = w; s < S; s += 4) {
+        int s = w;
+        for (; s + 7 * PA_WAVES < S; s += 8 * PA_WAVES) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = xc[(long)(s + u * PA_WAVES) * ldx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int h = 0; h < PL_MAXH; ++h)
+                    if (h < H) acc[h] = fmaf(psm[(long)h * S + s + u * PA_WAVES], v[u], acc[h]);
+        }
+        for (; s < S; s += PA_WAVES) {
             const float v = xc[(long)s * ldx];
 #pragma unroll
             for (int h = 0; h < PL_MAXH; ++h)
@@ -125,9 +137,10 @@ __global__ __launch_bounds__(256) void pool_accumulate_kernel(const float* __res
         if (h < H) red[((long)w * H + h) * 64 + lane] = acc[h];
     __syncthreads();
     if (c < W)
-        for (int h = w; h < H; h += 4) {
-            const float t = ((red[((long)0 * H + h) * 64 + lane] + red[((long)1 * H + h) * 64 + lane]) +
-                             red[((long)2 * H + h) * 64 + lane]) + red[((long)3 * H + h) * 64 + lane];
+        for (int h = w; h < H; h += PA_WAVES) {
+            float t = red[((long)0 * H + h) * 64 + lane];
+#pragma unroll
+            for (int o = 1; o < PA_WAVES; ++o) t += red[((long)o * H + h) * 64 + lane];
             u[((long)b * H + h) * W + c] = t;
         }
 }
@@ -136,12 +149,13 @@ int launch_pool_head_rows(const float* x, long ldx, const float* qk, const float
     REVO_REQUIRE(H >= 1 && H <= PL_MAXH && W % 4 == 0 && ldx % 4 == 0, "pool head: at most 16 heads, width a multiple of 4");
     const long rows = (long)B * S;
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(pool_logits_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, qk, ck, (int)rows, S, W, H,
-                       logits);
-    const size_t lds = ((size_t)H * S + 4 * (size_t)H * 64) * 4;
+    if (qk)
+        hipLaunchKernelGGL(pool_logits_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, qk, ck, (int)rows, S, W, H,
+                           logits);
+    const size_t lds = ((size_t)H * S + PA_WAVES * (size_t)H * 64) * 4;
     REVO_REQUIRE(lds <= 160 * 1024, "pool head: sequence too long for the probability table in LDS");
     REVO_FUNC_LDS(pool_accumulate_kernel, (int)lds);
-    hipLaunchKernelGGL(pool_accumulate_kernel, dim3((W + 63) / 64, B), dim3(256), lds, st, x, ldx, logits, S, W, H, u);
+    hipLaunchKernelGGL(pool_accumulate_kernel, dim3((W + 63) / 64, B), dim3(PA_WAVES * 64), lds, st, x, ldx, logits, S, W, H, u);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -154,53 +168,71 @@ int launch_pool_head_rows(const float* x, long ldx, const float* qk, const float
 // LDS and are added in a fixed order (deterministic).  Rows are taken 64 at a time.
 // Grouped A (the value projection of the pool): output columns [g * group_cols, (g + 1) * group_cols) read their A rows
 // at A + g * a_group_stride (one pooled row per head).
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-template <int EPI>   // 0: C = acc + bias, 1: C = gelu_erf(acc + bias), 2: C += acc + bias
-__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const float* __restrict__ A, long lda, long a_group_stride,
-                                                              int group_cols, const float* __restrict__ Wt, long ldw,
-                                                              const float* __restrict__ bias, int M, int N, int K,
-                                                              float* __restrict__ C, long ldc) {
-    __shared__ float part[4][64][17];
+template <int EPI, int MB, int NW>   // EPI 0: C = acc + bias, 1: C = gelu_erf(acc + bias), 2: C += acc + bias; MB 16-row blocks; NW waves
+__global__ __launch_bounds__(NW * 64) void gemm_f32_skinny_kernel(const float* __restrict__ A, long lda, long a_group_stride,
+                                                                  int group_cols, const float* __restrict__ Wt, long ldw,
+                                                                  const float* __restrict__ bias, int M, int N, int K,
+                                                                  float* __restrict__ C, long ldc) {
+    __shared__ float part[NW][MB * 16][17];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const float* Ab = A + (group_cols > 0 ? (long)(n0 / group_cols) * a_group_stride : 0);
     const int nr = n0 + r < N ? n0 + r : N - 1;                      // a ragged last column block re-reads a valid row
     const float* wrow = Wt + (long)nr * ldw + kq * 4;
-    const int kper = ((K / 16 + 3) / 4) * 16;                        // k range of a wave, a multiple of 16
+    const int kper = ((K / 16 + NW - 1) / NW) * 16;                  // k range of a wave, a multiple of 16
     const int k0 = w * kper, k1 = (k0 + kper) < K ? (k0 + kper) : K;
-    for (int m0 = 0; m0 < M; m0 += 64) {
-        f32x4 acc[4];
+    for (int m0 = 0; m0 < M; m0 += MB * 16) {
+        f32x4 acc[MB];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* arow[4];
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* arow[MB];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
+        for (int mb = 0; mb < MB; ++mb) {
             const int m = m0 + mb * 16 + r;
             arow[mb] = Ab + (long)(m < M ? m : M - 1) * lda + kq * 4;
         }
-        for (int k = k0; k < k1; k += 16) {
-            const f32x4 wv = *(const f32x4*)(wrow + k);
-            f32x4 av[4];
+        int k = k0;
+        for (; k + 16 < k1; k += 32) {                                // two 16-k chunks per trip: their loads are all issued first
+            const f32x4 wv0 = *(const f32x4*)(wrow + k), wv1 = *(const f32x4*)(wrow + k + 16);
+            f32x4 av0[MB], av1[MB];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) av[mb] = *(const f32x4*)(arow[mb] + k);
+            for (int mb = 0; mb < MB; ++mb) { av0[mb] = *(const f32x4*)(arow[mb] + k); av1[mb] = *(const f32x4*)(arow[mb] + k + 16); }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
+                for (int mb = 0; mb < MB; ++mb)
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv0[j], av0[mb][j], acc[mb], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv1[j], av1[mb][j], acc[mb], 0, 0, 0);
+        }
+        for (; k < k1; k += 16) {
+            const f32x4 wv = *(const f32x4*)(wrow + k);
+            f32x4 av[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[mb] = *(const f32x4*)(arow[mb] + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
                     acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], av[mb][j], acc[mb], 0, 0, 0);
         }
         // lane holds C[row mb*16 + (lane & 15)][cols (lane >> 4) * 4 + 0..3] of its K share
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int v = 0; v < 4; ++v) part[w][mb * 16 + r][kq * 4 + v] = acc[mb][v];
         __syncthreads();
-        for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+        for (int e = threadIdx.x; e < MB * 16 * 16; e += NW * 64) {
             const int row = e >> 4, col = e & 15;
             const int m = m0 + row, n = n0 + col;
             if (m < M && n < N) {
-                float t = ((part[0][row][col] + part[1][row][col]) + part[2][row][col]) + part[3][row][col];
+                float t = part[0][row][col];
+#pragma unroll
+                for (int o = 1; o < NW; ++o) t += part[o][row][col];     // fixed order: deterministic
                 if (bias) t += bias[n];
                 float* cp = C + (long)m * ldc + n;
                 if (EPI == 1) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));
@@ -211,16 +243,25 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(const float* __res
         __syncthreads();
     }
 }
+template <int EPI>
+static void launch_skinny_f32(const float* A, long lda, long a_group_stride, int group_cols, const float* Wt, long ldw,
+                              const float* bias, int M, int N, int K, float* C, long ldc, hipStream_t st) {
+    const dim3 grid((unsigned)((N + 15) / 16));
+    // up to 16 rows (one to a few images: the weights' latency chain is what costs): 16 waves split K; else 8 waves, 64 rows at a time
+    if (M <= 16)
+        hipLaunchKernelGGL((gemm_f32_skinny_kernel<EPI, 1, 16>), grid, dim3(1024), 0, st, A, lda, a_group_stride, group_cols, Wt, ldw, bias, M, N, K, C, ldc);
+    else
+        hipLaunchKernelGGL((gemm_f32_skinny_kernel<EPI, 4, 8>), grid, dim3(512), 0, st, A, lda, a_group_stride, group_cols, Wt, ldw, bias, M, N, K, C, ldc);
+}
 int launch_gemm_f32_skinny(int epi, const float* A, long lda, long a_group_stride, int group_cols, const float* Wt, long ldw,
                            const float* bias, int M, int N, int K, float* C, long ldc, hipStream_t st) {
     REVO_REQUIRE(epi >= 0 && epi <= 2, "fp32 gemm: epilogue 0..2");
     REVO_REQUIRE(K % 16 == 0 && lda % 4 == 0 && ldw % 4 == 0, "fp32 gemm: K must be a multiple of 16, rows 16-byte aligned");
     REVO_REQUIRE(group_cols == 0 || (group_cols % 16 == 0 && a_group_stride % 4 == 0), "fp32 gemm: bad A grouping");
     if (M <= 0 || N <= 0) return 0;
-    const dim3 grid((unsigned)((N + 15) / 16)), block(256);
-    if (epi == 0) hipLaunchKernelGGL((gemm_f32_skinny_kernel<0>), grid, block, 0, st, A, lda, a_group_stride, group_cols, Wt, ldw, bias, M, N, K, C, ldc);
-    else if (epi == 1) hipLaunchKernelGGL((gemm_f32_skinny_kernel<1>), grid, block, 0, st, A, lda, a_group_stride, group_cols, Wt, ldw, bias, M, N, K, C, ldc);
-    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<2>), grid, block, 0, st, A, lda, a_group_stride, group_cols, Wt, ldw, bias, M, N, K, C, ldc);
+    if (epi == 0) launch_skinny_f32<0>(A, lda, a_group_stride, group_cols, Wt, ldw, bias, M, N, K, C, ldc, st);
+    else if (epi == 1) launch_skinny_f32<1>(A, lda, a_group_stride, group_cols, Wt, ldw, bias, M, N, K, C, ldc, st);
+    else launch_skinny_f32<2>(A, lda, a_group_stride, group_cols, Wt, ldw, bias, M, N, K, C, ldc, st);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

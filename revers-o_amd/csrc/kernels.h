@@ -46,15 +46,20 @@ void gemm_force_tile(int t);   // 0 = heuristic, 128 or 256 = forced
 
 // --------------------------------------------------------- elementwise -----
 // out = LayerNorm(x) * w + b over rows of width W (fp32 statistics, two-pass).
+// logits (optional, fp32 output): also the attention-pool logits of every normalised row (head.hip): row r = token r % S of
+// image r / S; logits[(image * H + h) * S + token] = y . qk[h] + ck[h]
+constexpr int LN_MAXH = 16;
+struct LnLogits { const float* qk; const float* ck; float* logits; int H, S; };
 int launch_layernorm(const float* x, long ldx, const float* w, const float* b, float eps, int rows, int W,
-                     void* out, long ldo, int out_is_bf16, hipStream_t st);
+                     void* out, long ldo, int out_is_bf16, hipStream_t st, const LnLogits* logits = nullptr);
 // images NCHW (u8 pixel values; f32: already normalised to [-1, 1]) -> im2col matrix for the split-precision patch GEMM:
 // rows [B*G*G][parts * Kp] bf16, k = c*P*P + py*P + px zero padded to Kp, parts = 2 (u8: the exact integers 2v - 255,
 // twice) or 3 (f32: hi | hi | lo of 255 x); the weights carry the 1/255 (elementwise.hip, head.hip split_hi_lo_hi)
 int launch_patchify(const void* images, int is_u8, int B, int img, int P, bf16_t* out, long Kp, hipStream_t st);
 // ---- the attention-pool head in fp32 (head.hip)
 int launch_probe_qk(const float* q, const float* Wk, const float* bk, int W, int heads, float* qk, float* ck, hipStream_t st);
-// logits [B][H][S] of the probe against the fp32 ln_post rows x, then u [B][H][W] = softmax-weighted sums of the rows
+// u [B][H][W] = softmax-weighted sums of the fp32 ln_post rows x; logits [B][H][S] of the probe come from the ln_post
+// kernel (launch_layernorm's LnLogits), or, with qk != null, from a kernel of their own first
 int launch_pool_head_rows(const float* x, long ldx, const float* qk, const float* ck, int B, int S, int W, int H,
                           float* logits, float* u, hipStream_t st);
 // C[M][N] (+)= epi(A . Wt^T + bias) in fp32, M small; epi 0 plain, 1 exact-erf GELU, 2 C += ; group_cols > 0: output
@@ -86,6 +91,7 @@ int launch_attention(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, i
 int launch_attention_ex(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, int hd, int has_cls,
                         hipStream_t st);
 void gemm_set_min_tiles256(int n);  // timing experiments only (default 100)
+void gemm_set_ring(int on, int max_tiles);   // timing experiments only (default on, 256 tiles)
 void gemm_set_splitk(int on);       // timing experiments only (1 = default)
 void gemm_set_persistent(int on);   // timing experiments only (1 = default)
 void attention_force_nw(int nw);   // timing experiments only (0 = heuristic)
