@@ -36,7 +36,9 @@ if len(sys.argv) > 2:
             tot += (2 * sum(fe[k].get("FETCH_SIZE", [])) + sum(wr[k].get("WRITE_SIZE", []))) * 1024
         if main:
             n += len(fe[k].get("FETCH_SIZE", []))
+    import os
     json.dump({"variant": "PE-Core-L14-336", "batch": 64, "gemm_bytes_per_launch": tot / max(n, 1), "dispatches": n,
+               "taken": os.environ.get("PROFILE_TAKEN", "an unrecorded commit"),
                "source": "scripts/pmc_summary.py over gpurun_out/prof_<tag> (scripts/collect_profiles.sh): (2*FETCH_SIZE + WRITE_SIZE) "
                          "summed over the body-GEMM kernels of bench.py (gemm256*_kernel with the GELU / residual / RoPE epilogues and the kernels that take their leftover rows) and divided by the number of linear-layer launches; "
                          "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md HBM section; "
