@@ -103,6 +103,47 @@ def cpu_baseline(cfg, gallery_rows, dim, k, n_images, search_rows):
     }
 
 
+def ingest_leg(variant, n_images, device_index):
+    """SURVEY 8(f) row 1 next to the headline: n JPEGs (640 x 480, written to a temporary folder) -> decode pool -> H2D ->
+    device resize -> embed -> device gallery append -> delta-shard flush, through SimpleReverso.create_database.  Reported,
+    not part of `value` (it includes JPEG decoding on the host's cores and the file system)."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    from reverso_amd.core_system import SimpleReverso
+    root = tempfile.mkdtemp(prefix="revo_ingest_")
+    try:
+        folder = os.path.join(root, "images")
+        os.makedirs(folder)
+        rng = np.random.default_rng(0)
+        yy, xx = np.mgrid[0:480, 0:640]
+        for i in range(n_images):
+            base = np.stack([(xx * (i % 7 + 1) + yy) % 256, (yy * 2 + i) % 256, (xx + yy * (i % 5)) % 256], -1).astype(np.float32)
+            img = np.clip(base + rng.normal(0, 12, base.shape), 0, 255).astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(folder, f"img_{i:05d}.jpg"), quality=90)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):            # the facade prints like the reference does
+            r = SimpleReverso(model_name=variant, db_root=os.path.join(root, "db"), max_batch=64, device=device_index,
+                              device_resize=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            msg = r.create_database(folder, "bench", use_direct_pe=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        ok = "ready for searching" in msg and len(r.vector_db) == n_images
+        st = dict(r.last_ingest_stats or {})
+        r.vector_db.close()
+        return {"images": n_images, "images_per_s": n_images / dt, "seconds": dt, "ok": ok, "mode": "direct PE, device resize",
+                "stage_s": {k: round(v, 3) for k, v in st.items() if k.endswith("_s")},
+                "note": "JPEG decode on the host's cores + device resize + embed + device-side gallery append + delta-shard flush; "
+                        f"{n_images} images are {n_images // 64} batches: the first decode and the last embed overlap with nothing "
+                        "(profiles/r03_ingest.json: 1 950 images/s at 4 000 images)"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +163,9 @@ def main():
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--debug-flags", type=int, default=0, help="A/B experiments: revo_op_set_gemm_debug flags (0 = product path); "
                                                                "needs REVO_EXPERIMENTS=1 (librevo_exp.so, `make -C revers-o_amd/csrc exp`)")
+    ap.add_argument("--ingest-images", type=int, default=512,
+                    help="extra, untimed-by-the-headline leg on rank 0 at --gpus 1: build a gallery from this many JPEGs through "
+                         "SimpleReverso.create_database (SURVEY 8(f) row 1); 0 disables it")
     ap.add_argument("--search-dim", type=int, default=0,
                     help="dimension of the gallery of the --search-queries leg (0 = the tower's output dimension, the headline "
                          "gallery itself).  BASELINE.json configs[4] writes its gallery as 10M x 1536 while PE-Core-G14-448 "
@@ -367,6 +411,13 @@ def main():
                             "note": "every query's top-k is certified equal to an exhaustive fp32 scoring or re-done exactly "
                                     "(include/revo.h EXACTNESS); the fallback's time is inside ms_per_step"},
         }
+        if world == 1 and args.ingest_images > 0:
+            eng.close()
+            gal.close()
+            try:
+                res["ingest"] = ingest_leg(args.variant, args.ingest_images, local_rank)
+            except Exception as e:                                  # a reported extra: never takes the headline line down
+                res["ingest"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, args.gallery, D, args.k, args.cpu_images, min(args.gallery, 250_000))
         print(json.dumps(res), flush=True)

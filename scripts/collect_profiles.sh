@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"      # includes the 10 000-query batch of configs[3] after the timed steps
+ARGS="$REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --ingest-images 0"      # includes the 10 000-query batch of configs[3] after the timed steps
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $ARGS > $OUT/trace.log 2>&1
 echo "trace done"
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/sq -o sq -- python3 $ARGS > $OUT/sq.log 2>&1

@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--variant", "PE-Tiny-T14-56", "--batch", "8", "--gallery", "60000", "--steps", "2", "--warmup", "1",
-         "--search-queries", "600", "--no-cpu-baseline"]
+         "--search-queries", "600", "--no-cpu-baseline", "--ingest-images", "24"]
 
 
 def _json_line(out):
@@ -42,7 +42,10 @@ def test_bench_contract_one_gpu(dev):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, cwd=ROOT, capture_output=True, text=True,
                        timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
-    _check_contract(_json_line(p.stdout), 1)
+    d = _json_line(p.stdout)
+    _check_contract(d, 1)
+    assert d["ingest"]["ok"] and d["ingest"]["images"] == 24 and d["ingest"]["images_per_s"] > 0, d["ingest"]     # the reported ingest leg
+    assert d["certificate"]["uncertified_queries_last_step"] >= 0 and "uncertified_queries" in d["search_query_batch"]
 
 
 def test_bench_contract_two_ranks_on_one_gpu(dev):
@@ -55,4 +58,4 @@ def test_bench_contract_two_ranks_on_one_gpu(dev):
     _check_contract(d, 2)
     sq = d["search_query_batch"]
     assert sq["one_gpu_ms_same_process"] > 0 and sq["speedup_vs_1gpu_model"] > 0      # rank 0's 1-GPU run of the same search
-    assert "cpu_baseline" not in d                                                       # N = 1 only
+    assert "cpu_baseline" not in d and "ingest" not in d                                 # N = 1 only
