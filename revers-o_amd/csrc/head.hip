@@ -168,12 +168,17 @@ int launch_pool_head_rows(const float* x, long ldx, const float* qk, const float
 // LDS and are added in a fixed order (deterministic).  Rows are taken 64 at a time.
 // Grouped A (the value projection of the pool): output columns [g * group_cols, (g + 1) * group_cols) read their A rows
 // at A + g * a_group_stride (one pooled row per head).
-template <int EPI, int MB, int NW>   // EPI 0: C = acc + bias, 1: C = gelu_erf(acc + bias), 2: C += acc + bias; MB 16-row blocks; NW waves
-__global__ __launch_bounds__(NW * 64) void gemm_f32_skinny_kernel(const float* __restrict__ A, long lda, long a_group_stride,
+// (K is always cut into the same NW = 16 ranges, summed in the same order, whatever M is: a row's result does not
+//  depend on how many other rows -- images -- are in the batch, bit for bit.)
+constexpr int SK_NW = 16;
+template <int EPI, int MB>   // EPI 0: C = acc + bias, 1: C = gelu_erf(acc + bias), 2: C += acc + bias; MB 16-row blocks per pass
+__global__ __launch_bounds__(SK_NW * 64) void gemm_f32_skinny_kernel(const float* __restrict__ A, long lda, long a_group_stride,
                                                                   int group_cols, const float* __restrict__ Wt, long ldw,
                                                                   const float* __restrict__ bias, int M, int N, int K,
                                                                   float* __restrict__ C, long ldc) {
-    __shared__ float part[NW][MB * 16][17];
+    constexpr int NW = SK_NW;
+    extern __shared__ float part_raw[];
+    float (*part)[MB * 16][17] = (float (*)[MB * 16][17])part_raw;           // [NW][MB * 16][17]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16;
@@ -247,11 +252,21 @@ template <int EPI>
 static void launch_skinny_f32(const float* A, long lda, long a_group_stride, int group_cols, const float* Wt, long ldw,
                               const float* bias, int M, int N, int K, float* C, long ldc, hipStream_t st) {
     const dim3 grid((unsigned)((N + 15) / 16));
-    // up to 16 rows (one to a few images: the weights' latency chain is what costs): 16 waves split K; else 8 waves, 64 rows at a time
-    if (M <= 16)
-        hipLaunchKernelGGL((gemm_f32_skinny_kernel<EPI, 1, 16>), grid, dim3(1024), 0, st, A, lda, a_group_stride, group_cols, Wt, ldw, bias, M, N, K, C, ldc);
-    else
-        hipLaunchKernelGGL((gemm_f32_skinny_kernel<EPI, 4, 8>), grid, dim3(512), 0, st, A, lda, a_group_stride, group_cols, Wt, ldw, bias, M, N, K, C, ldc);
+    // sixteen waves split K (the weights' latency chain is what costs); up to 16 rows in one pass, else 64 rows at a time
+    if (M <= 16) {
+        hipLaunchKernelGGL((gemm_f32_skinny_kernel<EPI, 1>), grid, dim3(SK_NW * 64), SK_NW * 16 * 17 * 4, st, A, lda, a_group_stride,
+                           group_cols, Wt, ldw, bias, M, N, K, C, ldc);
+    } else {
+        constexpr int LDS = SK_NW * 64 * 17 * 4;
+        static bool done[REVO_MAX_DEVICES] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < REVO_MAX_DEVICES && !done[dev]) {
+            (void)hipFuncSetAttribute((const void*)(gemm_f32_skinny_kernel<EPI, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            done[dev] = true;
+        }
+        hipLaunchKernelGGL((gemm_f32_skinny_kernel<EPI, 4>), grid, dim3(SK_NW * 64), LDS, st, A, lda, a_group_stride, group_cols, Wt,
+                           ldw, bias, M, N, K, C, ldc);
+    }
 }
 int launch_gemm_f32_skinny(int epi, const float* A, long lda, long a_group_stride, int group_cols, const float* Wt, long ldw,
                            const float* bias, int M, int N, int K, float* C, long ldc, hipStream_t st) {
