@@ -182,3 +182,28 @@ def test_sharded_search_protocol_gloo(tmp_path, noise):
             assert np.array_equal(got[f"{thr}_i"], ri)
             assert np.array_equal(got[f"{thr}_c"], rc)
             np.testing.assert_allclose(got[f"{thr}_s"], rs, atol=1e-6)
+
+
+@pytest.mark.parametrize("noise,shards", [(0.0, 3), (0.25, 4)])
+def test_local_shards_protocol_on_cpu(noise, shards):
+    """sharded.LocalShards -- the two-phase protocol with its certificate round over several shards held by one process
+    (one handle per GPU, or the GPU tests' eight shards on one device) -- with the numpy backend: equals the exhaustive
+    search, with and without a noisy scan stand-in, thresholds included, uneven shard sizes, k larger than a shard."""
+    from reverso_amd import sharded
+    rng = np.random.default_rng(21)
+    N, D, Q, k = 700, 32, 9, 12
+    gal = osearch.normalize_rows(rng.standard_normal((N, D), dtype=np.float32))
+    gal[40:48] = gal[40]
+    qs = osearch.normalize_rows(rng.standard_normal((Q, D), dtype=np.float32))
+    qs[0] = gal[40]
+    cuts = [0] + sorted(rng.choice(np.arange(20, N - 20), size=shards - 1, replace=False).tolist()) + [N]
+    backends = [osearch.OracleShardBackend(gal[a:b], scan_noise=noise, row_offset=a) for a, b in zip(cuts[:-1], cuts[1:])]
+    ls = sharded.LocalShards(backends, cuts[:-1])
+    second = 0
+    for thr in (None, 0.2):
+        s, i, c = ls.search(torch.from_numpy(qs), k, thr)
+        second += ls.last_uncertified
+        rs, ri, rc = osearch.search(gal, qs, k, thr, normalize=False)
+        assert np.array_equal(i.numpy(), ri) and np.array_equal(c.numpy(), rc)
+        np.testing.assert_allclose(s.numpy(), rs, atol=1e-6)
+    assert (second > 0) == (noise > 0)
