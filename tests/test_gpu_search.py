@@ -604,7 +604,7 @@ def test_config4_gallery_10m_x_1536(dev):
     ms, mi, mc = engine.merge_topk(torch.stack(parts_s), torch.stack(parts_i), k)
     assert torch.equal(mi, i) and torch.equal(ms, s) and torch.equal(mc, c)
     plan = G.search_plan(Q, k)
-    assert plan["scan256"] and plan["ksel"] == 32
+    assert plan["scan256"] and plan["ksel"] == 64          # 10 M rows: the wide candidate lists (api.hip SEARCH_WIDE_ROWS)
     G.close()
 
 
@@ -643,3 +643,24 @@ def test_sharded_two_phase_with_certificate_equals_unsharded(dev):
     for Gp in shards:
         Gp.close()
     G.close()
+
+
+def test_wide_candidate_lists_on_very_large_galleries(dev):
+    """From 2^22 rows on the unsharded search keeps 64 candidates per query whatever k is (a failed certificate costs a
+    whole pass there): same results as the brute-force mode, bit for bit, and the plan says so."""
+    N, D, Q, k = (1 << 22) + 1000, 64, 33, 10
+    g = torch.Generator(device=dev).manual_seed(4)
+    G = engine.Gallery(D, N, device=0)
+    for s0 in range(0, N, 1 << 20):
+        G.add(torch.randn(min(1 << 20, N - s0), D, generator=g, device=dev))
+    assert G.search_plan(Q, k)["ksel"] == 64
+    q = torch.cat([G.read(123456, 8) + 0.05 * torch.randn(8, D, generator=g, device=dev), torch.randn(Q - 8, D, generator=g, device=dev)])
+    out = G.search(q, k)
+    st = G.search_stats()
+    assert st["checked"] == Q
+    G.set_search_mode("bruteforce")
+    ref = G.search(q, k)
+    G.close()
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    assert out[1][:8, 0].cpu().tolist() == list(range(123456, 123464))
