@@ -87,7 +87,9 @@ class SimpleReverso:
         # decode threads of a gallery build.  None = by mode (create_database): MORE threads are not better -- PIL's
         # RGBX -> RGB packing of a decoded frame runs under the GIL (0.35 ms per 640 x 480 frame), and the ingest thread,
         # which has to keep the device's queue full, waits its turn behind every thread that wants it: measured on
-        # 3 000 JPEGs with device resize 1 950 images/s with 8 threads, 1 620 with 16, 1 720 with 32
+        # 3 000 JPEGs with device resize 1 950 images/s with 8 threads, 1 620 with 16, 1 720 with 32.  (Decode worker
+        # PROCESSES writing into pinned shared memory were built and measured too: 1 975 and 563-598 images/s against
+        # 1 950 and 602-649 with threads -- with the right thread count the build waits for the device, not for the GIL.)
         self.decode_workers = None if decode_workers is None else int(decode_workers)
         self._decode_pool = ThreadPoolExecutor(max_workers=self.decode_workers or 8)
         self._lock = threading.RLock()      # ui.py drives one shared instance from worker threads
@@ -434,7 +436,7 @@ class SimpleReverso:
         host_resize = not self.device_resize and not (self.region_mode == "crop" and not use_direct_pe)
         model_size = self.pe_model.cfg.image_size
 
-        stats = {"images": len(image_files), "decode_thread_s": 0.0, "wait_decode_s": 0.0, "launch_s": 0.0,
+        stats = {"images": len(image_files), "decode_thread_s": 0.0, "wait_decode_s": 0.0, "wait_device_s": 0.0, "launch_s": 0.0,
                  "bookkeeping_s": 0.0, "flush_s": 0.0}
         self.last_ingest_stats = stats
         t_start = time.perf_counter()
@@ -555,9 +557,11 @@ class SimpleReverso:
             read it (NSLOT batches ago) has left the host"""
             while submitted[0] <= it + DEPTH and submitted[0] * B < len(image_files):
                 bn = submitted[0]
+                t_ev = time.perf_counter()
                 for ev in (h2d_done[bn % NSLOT], frames_done[bn % NSLOT]):
                     if ev is not None:
                         ev.synchronize()
+                stats["wait_device_s"] += time.perf_counter() - t_ev        # the device is the bottleneck while this grows
                 pending.append(submit(bn * B))
                 submitted[0] += 1
 

@@ -33,3 +33,17 @@ frames = [d[j * MB:j * MB + arr.size].view(480, 640, 3) for j in range(64)]
 print("crop_resize_device 64 frames -> 336: host %.2f ms, done %.2f ms" % t(lambda: pp.crop_resize_device(frames, None, 336)))
 stage = torch.zeros((64, 3, 336, 336), dtype=torch.uint8).pin_memory()
 print("H2D 21.7 MB staged batch:            host %.2f ms, done %.2f ms" % t(lambda: stage.to(dev, non_blocking=True)))
+# the crop-mode batch of scripts/ingest_bench.py: 64 frames, three boxes each -> 192 crops of 336 x 336
+w, h = 640, 480
+boxes = []
+for i in range(64):
+    boxes += [(i, 0, 0, w // 2, h // 2), (i, w // 4, h // 4, w - 1, h - 1), (i, w // 3, 0, w - 1, h // 2)]
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+pp.crop_resize_device(frames, boxes, 336); torch.cuda.synchronize()
+e0.record()
+for _ in range(10): pp.crop_resize_device(frames, boxes, 336)
+e1.record(); torch.cuda.synchronize()
+print("crop_resize_device 192 crops of 64 frames: device %.3f ms per call" % (e0.elapsed_time(e1) / 10))
+t0 = time.perf_counter()
+for _ in range(10): pp.crop_resize_device(frames, boxes, 336)
+print("   host %.3f ms per call" % ((time.perf_counter() - t0) / 10 * 1e3)); torch.cuda.synchronize()

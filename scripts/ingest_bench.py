@@ -43,10 +43,17 @@ for mode, kw, direct in (("direct PE (one vector per image)", {}, True),
     r = SimpleReverso(model_name="PE-Core-L14-336", db_root=os.path.join(root, "db_" + str(len(mode))), max_batch=64,
                       decode_workers=int(os.environ["DECODE_WORKERS"]) if os.environ.get("DECODE_WORKERS") else None, **kw)
     torch.cuda.synchronize()
+    if os.environ.get("PROF_CLASSES"):
+        from reverso_amd import engine as _eng
+        _eng.prof_reset(); _eng.prof_enable(1)
     t0 = time.perf_counter()
     msg = r.create_database(folder, "bench", use_direct_pe=direct)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if os.environ.get("PROF_CLASSES"):
+        _eng.prof_enable(0)
+        rep = _eng.prof_report()
+        print("device ms by class:", {k2: round(v["ms"], 1) for k2, v in sorted(rep.items())}, "sum", round(sum(v["ms"] for v in rep.values()), 1))
     vecs = len(r.vector_db.payloads)
     t1 = time.perf_counter()
     r.process_image_direct_pe(os.path.join(folder, "img_00003.jpg"))
