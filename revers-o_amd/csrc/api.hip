@@ -554,7 +554,7 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
       const LnLogits lg{v->qk, v->ck, v->pool_logits, PH, S};
       CHECK_RC(launch_layernorm(v->x, W, v->lnpost_w, v->lnpost_b, c.ln_eps, rows, W, v->x, W, 0, st, &lg)); }
     { ProfScope ps("pool_attention", st);
-      CHECK_RC(launch_pool_head_rows(v->x, W, nullptr, nullptr, B, S, W, PH, v->pool_logits, v->pool_u, st)); }
+      CHECK_RC(launch_pool_head_rows(v->x, W, B, S, W, PH, v->pool_logits, v->pool_u, st)); }
     { ProfScope ps("gemm_pool", st);
       // values: head h's output columns from head h's pooled row
       CHECK_RC(launch_gemm_f32_skinny(0, v->pool_u, (long)PH * W, W, v->phd, v->w_v, W, v->b_v, B, W, W, v->pool_att, W, st));

@@ -478,87 +478,5 @@ int launch_attention(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, i
     return launch_attention_ex(qkv, ld, out, ldo, B, S, H, hd, 1, st);
 }
 
-// ------------------------------------------------------ attention pool -----
-// One workgroup per (image, pool head): scores of the single probe against all S keys, softmax,
-// weighted sum of V.  q is pre-projected and pre-scaled fp32.  GW lanes share a key row (16-byte
-// chunks, so a row is one coalesced segment); 256 / GW keys are in flight per sweep step.
-template <int GW, int MAXS>
-__global__ __launch_bounds__(256) void pool_attn_kernel(const float* __restrict__ q, const bf16_t* __restrict__ kv,
-                                                        long ld, bf16_t* __restrict__ out, long ldo, int S, int H,
-                                                        int hd) {
-    constexpr int SLOTS = 256 / GW;
-    __shared__ float sc[MAXS];
-    __shared__ float red[8];
-    __shared__ float accs[SLOTS][GW * 8];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int g = tid / GW, c = tid % GW;
-    const bool act = c * 8 < hd;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const int W = H * hd;
-    const bf16_t* kbase = kv + (long)b * S * ld + h * hd + c * 8;
-    const bf16_t* vbase = kbase + W;
-    float qv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) qv[j] = act ? q[h * hd + c * 8 + j] : 0.f;
-    for (int s0 = 0; s0 < S; s0 += SLOTS) {
-        const int s = s0 + g;
-        float acc = 0.f;
-        if (act && s < S) {
-            const s16x8 kk = *(const s16x8*)(kbase + (long)s * ld);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc = fmaf(qv[j], bf16_to_f32((bf16_t)kk[j]), acc);
-        }
-#pragma unroll
-        for (int o = GW / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (c == 0 && s < S) sc[s] = acc;
-    }
-    __syncthreads();
-    float mx = -INFINITY;
-    for (int s = tid; s < S; s += 256) mx = fmaxf(mx, sc[s]);
-    mx = wave_max(mx);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float sum = 0.f;
-    for (int s = tid; s < S; s += 256) {
-        const float p = __expf(sc[s] - mx);
-        sc[s] = p;
-        sum += p;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) red[4 + wave] = sum;
-    __syncthreads();
-    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-    float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (act) {
-        for (int s = g; s < S; s += SLOTS) {
-            const float p = sc[s];
-            const s16x8 vv = *(const s16x8*)(vbase + (long)s * ld);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o8[j] = fmaf(p, bf16_to_f32((bf16_t)vv[j]), o8[j]);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) accs[g][c * 8 + j] = o8[j];
-    __syncthreads();
-    for (int d = tid; d < hd; d += 256) {
-        float acc = 0.f;
-#pragma unroll
-        for (int gg = 0; gg < SLOTS; ++gg) acc += accs[gg][d];
-        out[(long)b * ldo + h * hd + d] = f32_to_bf16(acc * inv);
-    }
-}
-
-int launch_pool_attention(const float* q, const bf16_t* kv, long ld, bf16_t* out, long ldo, int B, int S, int H,
-                          int hd, hipStream_t st) {
-    REVO_REQUIRE(S <= 1024, "pool attention: sequence longer than 1024 tokens");
-    REVO_REQUIRE(hd % 8 == 0 && hd <= 256, "pool attention: head_dim must be a multiple of 8, at most 256");
-    REVO_REQUIRE(ld % 8 == 0, "pool attention: row stride must keep 16-byte alignment");
-    if (B <= 0) return 0;
-    if (hd <= 128) hipLaunchKernelGGL((pool_attn_kernel<16, 1024>), dim3(B * H), dim3(256), 0, st, q, kv, ld, out, ldo, S, H, hd);
-    else hipLaunchKernelGGL((pool_attn_kernel<32, 1024>), dim3(B * H), dim3(256), 0, st, q, kv, ld, out, ldo, S, H, hd);
-    REVO_HIP_CHECK(hipGetLastError());
-    return 0;
-}
 
 }  // namespace revo

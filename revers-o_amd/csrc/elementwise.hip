@@ -354,28 +354,6 @@ int launch_f32_to_bf16(const float* src, long ld_src, bf16_t* dst, long ld_dst, 
     return 0;
 }
 
-__global__ void transpose_f32_to_bf16_kernel(const float* __restrict__ src, int rows, int cols,
-                                             bf16_t* __restrict__ dst, long ld_dst) {
-    __shared__ float tile[32][33];
-    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
-    for (int j = ty; j < 32; j += 8) {
-        const int r = by + j, c = bx + tx;
-        tile[j][tx] = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
-    }
-    __syncthreads();
-    for (int j = ty; j < 32; j += 8) {
-        const int orow = bx + j, ocol = by + tx;   // dst[c][r]
-        if (orow < cols && ocol < rows) dst[(long)orow * ld_dst + ocol] = f32_to_bf16(tile[tx][j]);
-    }
-}
-int launch_transpose_f32_to_bf16(const float* src, int rows, int cols, bf16_t* dst, long ld_dst, hipStream_t st) {
-    if (rows <= 0 || cols <= 0) return 0;
-    hipLaunchKernelGGL(transpose_f32_to_bf16_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, src,
-                       rows, cols, dst, ld_dst);
-    REVO_HIP_CHECK(hipGetLastError());
-    return 0;
-}
 
 // --------------------------------------------------------- L2 normalise ----
 // e / ||e||_2 with no epsilon (core_system.py:447); an all-zero row stays zero

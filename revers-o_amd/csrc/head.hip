@@ -43,41 +43,7 @@ int launch_probe_qk(const float* q, const float* Wk, const float* bk, int W, int
     return 0;
 }
 
-// ------------------------------------------------------------------ logits ----
-// logits[(b * H + h) * S + s] = qk_h . x[b * S + s] + ck_h ; one wave per token row, the row in registers
-constexpr int PL_MAXH = 16;
-__global__ __launch_bounds__(256) void pool_logits_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ qk,
-                                                          const float* __restrict__ ck, int rows, int S, int W, int H,
-                                                          float* __restrict__ logits) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* xr = x + row * ldx;
-    float acc[PL_MAXH];
-#pragma unroll
-    for (int h = 0; h < PL_MAXH; ++h) acc[h] = 0.f;
-    for (int c = lane * 4; c < W; c += 256) {
-        const f32x4 v = *(const f32x4*)(xr + c);
-#pragma unroll
-        for (int h = 0; h < PL_MAXH; ++h) {
-            if (h < H) {
-                const f32x4 w = *(const f32x4*)(qk + (long)h * W + c);
-                acc[h] = fmaf(v[0], w[0], acc[h]);
-                acc[h] = fmaf(v[1], w[1], acc[h]);
-                acc[h] = fmaf(v[2], w[2], acc[h]);
-                acc[h] = fmaf(v[3], w[3], acc[h]);
-            }
-        }
-    }
-    const long b = row / S, s = row - b * S;
-#pragma unroll
-    for (int h = 0; h < PL_MAXH; ++h) {
-        if (h < H) {
-            const float t = wave_sum(acc[h]);
-            if (lane == 0) logits[(b * H + h) * S + s] = t + ck[h];
-        }
-    }
-}
+constexpr int PL_MAXH = LN_MAXH;        // heads a thread of the accumulation carries (the logits come from the ln_post kernel)
 
 // --------------------------------------------------------------- pooled rows ----
 // u[(b * H + h) * W + c] = sum_s softmax_s(logits[b, h, :])[s] * x[b * S + s][c]
@@ -144,14 +110,10 @@ __global__ __launch_bounds__(PA_WAVES * 64) void pool_accumulate_kernel(const fl
             u[((long)b * H + h) * W + c] = t;
         }
 }
-int launch_pool_head_rows(const float* x, long ldx, const float* qk, const float* ck, int B, int S, int W, int H,
-                          float* logits, float* u, hipStream_t st) {
+int launch_pool_head_rows(const float* x, long ldx, int B, int S, int W, int H, const float* logits, float* u, hipStream_t st) {
     REVO_REQUIRE(H >= 1 && H <= PL_MAXH && W % 4 == 0 && ldx % 4 == 0, "pool head: at most 16 heads, width a multiple of 4");
     const long rows = (long)B * S;
     if (rows <= 0) return 0;
-    if (qk)
-        hipLaunchKernelGGL(pool_logits_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, qk, ck, (int)rows, S, W, H,
-                           logits);
     const size_t lds = ((size_t)H * S + PA_WAVES * (size_t)H * 64) * 4;
     REVO_REQUIRE(lds <= 160 * 1024, "pool head: sequence too long for the probability table in LDS");
     REVO_FUNC_LDS(pool_accumulate_kernel, (int)lds);

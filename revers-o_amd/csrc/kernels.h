@@ -58,10 +58,9 @@ int launch_layernorm(const float* x, long ldx, const float* w, const float* b, f
 int launch_patchify(const void* images, int is_u8, int B, int img, int P, bf16_t* out, long Kp, hipStream_t st);
 // ---- the attention-pool head in fp32 (head.hip)
 int launch_probe_qk(const float* q, const float* Wk, const float* bk, int W, int heads, float* qk, float* ck, hipStream_t st);
-// u [B][H][W] = softmax-weighted sums of the fp32 ln_post rows x; logits [B][H][S] of the probe come from the ln_post
-// kernel (launch_layernorm's LnLogits), or, with qk != null, from a kernel of their own first
-int launch_pool_head_rows(const float* x, long ldx, const float* qk, const float* ck, int B, int S, int W, int H,
-                          float* logits, float* u, hipStream_t st);
+// u [B][H][W] = softmax-weighted sums of the fp32 ln_post rows x; the logits [B][H][S] of the probe come from the
+// ln_post kernel (launch_layernorm's LnLogits)
+int launch_pool_head_rows(const float* x, long ldx, int B, int S, int W, int H, const float* logits, float* u, hipStream_t st);
 // C[M][N] (+)= epi(A . Wt^T + bias) in fp32, M small; epi 0 plain, 1 exact-erf GELU, 2 C += ; group_cols > 0: output
 // columns [g * group_cols, ...) read A at A + g * a_group_stride
 int launch_gemm_f32_skinny(int epi, const float* A, long lda, long a_group_stride, int group_cols, const float* Wt, long ldw,
@@ -81,8 +80,6 @@ int launch_f32_to_bf16(const float* src, long ld_src, bf16_t* dst, long ld_dst, 
 int launch_l2norm_rows(const float* src, long ld_src, float* dst_f32, long ld_f32, bf16_t* dst_bf16, long ld_bf16,
                        long rows, int D, hipStream_t st, int normalize = 1, float* row_stats = nullptr,
                        uint32_t* max_stats = nullptr);
-// dst[n][k] = src[k][n]   (fp32 -> bf16 transposed copy; visual.proj is stored [W][D])
-int launch_transpose_f32_to_bf16(const float* src, int rows, int cols, bf16_t* dst, long ld_dst, hipStream_t st);
 
 // ----------------------------------------------------------- attention -----
 // qkv [B*S][ld] bf16 (q | k | v thirds, heads contiguous inside a third) -> out [B*S][ldo] bf16
@@ -95,9 +92,6 @@ void gemm_set_ring(int on, int max_tiles);   // timing experiments only (default
 void gemm_set_splitk(int on);       // timing experiments only (1 = default)
 void gemm_set_persistent(int on);   // timing experiments only (1 = default)
 void attention_force_nw(int nw);   // timing experiments only (0 = heuristic)
-// single-probe attention pool: q [W] fp32 (already projected and scaled), kv [B*S][ld] bf16 (k | v halves)
-int launch_pool_attention(const float* q, const bf16_t* kv, long ld, bf16_t* out, long ldo, int B, int S, int H,
-                          int hd, hipStream_t st);
 
 // ---------------------------------------------------------------- top-k ----
 struct ScanArgs {
