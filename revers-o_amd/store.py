@@ -128,6 +128,8 @@ class GalleryStore:
     def flush(self, path=None):
         """Write the rows (and finished source files) added since the last flush as one delta shard.  Returns the rows written."""
         path = path or self.path
+        if not path:
+            raise ValueError("this store has no directory to flush to")
         n = len(self)
         new = n - self._flushed
         if new <= 0 and not self._files_pending:
@@ -154,6 +156,9 @@ class GalleryStore:
     def save(self, path=None):
         """Flush what is new and mark the collection complete."""
         path = path or self.path
+        if not path:
+            raise ValueError("this store has no directory (created without one, or loaded from the one-file format of "
+                             "rounds 1-2): save(path=<new directory>) writes it out in the delta-shard format")
         os.makedirs(path, exist_ok=True)
         if path != self.path:                              # saving somewhere else: write everything there
             other = os.path.join(path, MANIFEST)
