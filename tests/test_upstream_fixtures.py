@@ -76,7 +76,7 @@ def test_engine_matches_upstream(path, dev):
     eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=2)
     emb = eng.embed(torch.from_numpy(gold["preprocessed"]).to(dev)).cpu()
     ref = torch.from_numpy(gold["embedding"])
-    assert ((emb * ref).sum(-1) >= 0.999).all()
+    assert ((emb * ref).sum(-1) >= 0.9999).all()          # the bound every end-to-end test holds (tests/_parity.py)
     g = torch.Generator().manual_seed(1)
     gal = torch.nn.functional.normalize(torch.randn(2000, cfg.out_dim, generator=g), dim=-1)
     assert ((emb @ gal.T) - (ref @ gal.T)).abs().max().item() <= 1e-3
