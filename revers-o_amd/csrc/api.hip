@@ -456,11 +456,15 @@ extern "C" int32_t revo_vit_read_tap(revo_vit* vit, int32_t which, int32_t batch
 }
 
 namespace {
+// ln (optional, residual epilogue): the LayerNorm that follows; *ln_fused = 1 if the GEMM's launch form did it (kernels.h)
+struct LnAfter { const float* w; const float* b; float eps; bf16_t* out; long ldo; int* fused; };
 int gemm(const char* cls, int epi, const bf16_t* A, long lda, const bf16_t* B, long ldb, int M, int N, int K, void* C,
-         long ldc, const float* bias, const float* gamma, hipStream_t st, float* ws = nullptr, long ws_elems = 0) {
+         long ldc, const float* bias, const float* gamma, hipStream_t st, float* ws = nullptr, long ws_elems = 0,
+         const LnAfter* ln = nullptr) {
     revo::GemmArgs a{};
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
     a.bias = bias; a.gamma = gamma; a.ws = ws; a.ws_elems = ws_elems;
+    if (ln) { a.ln_w = ln->w; a.ln_b = ln->b; a.ln_eps = ln->eps; a.ln_out = ln->out; a.ln_ldo = ln->ldo; a.ln_fused = ln->fused; }
     ProfScope ps(cls, st);
     return revo::launch_gemm(epi, a, st);
 }
@@ -523,10 +527,15 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
       CHECK_RC(launch_layernorm(v->x, W, v->lnpre_w, v->lnpre_b, c.ln_eps, rows, W, v->x, W, 0, st)); }
 
     const int nl = v->debug_layers < 0 ? c.layers : std::min(v->debug_layers, c.layers);
+    // One-image forwards: the residual GEMMs run as K parts + one reduce, and that reduce also does the LayerNorm that
+    // follows (ln_2 after out-proj, the next block's ln_1 after fc2): h_ready says the rows in h are already normalised.
+    int h_ready = 0;
     for (int i = 0; i < nl; ++i) {
         const LayerW& L = v->layers[i];
-        { ProfScope ps("layernorm", st);
-          CHECK_RC(launch_layernorm(v->x, W, L.ln1w, L.ln1b, c.ln_eps, rows, W, v->h, W, 1, st)); }
+        if (!h_ready) {
+            ProfScope ps("layernorm", st);
+            CHECK_RC(launch_layernorm(v->x, W, L.ln1w, L.ln1b, c.ln_eps, rows, W, v->h, W, 1, st));
+        }
         {
             // K4 + K5: bias and the 2-D rotary embedding of q and k in the GEMM epilogue (every tile shape)
             GemmArgs a{};
@@ -538,13 +547,21 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
         }
         { ProfScope ps("attention", st);
           CHECK_RC(launch_attention_ex(v->qkv, 3 * W, v->att, W, B, S, c.heads, v->hd, c.use_cls, st)); }
-        CHECK_RC(gemm("gemm_out", EPI_RESID_F32, v->att, W, L.w_o, W, rows, W, W, v->x, W, L.b_o, L.ls1, st));
-        { ProfScope ps("layernorm", st);
-          CHECK_RC(launch_layernorm(v->x, W, L.ln2w, L.ln2b, c.ln_eps, rows, W, v->h, W, 1, st)); }
+        int fused = 0;
+        const LnAfter ln2{L.ln2w, L.ln2b, c.ln_eps, v->h, W, &fused};
+        CHECK_RC(gemm("gemm_out", EPI_RESID_F32, v->att, W, L.w_o, W, rows, W, W, v->x, W, L.b_o, L.ls1, st, vv->splitk_ws,
+                      (long)SPLITK_WS_ELEMS, &ln2));
+        if (!fused) {
+            ProfScope ps("layernorm", st);
+            CHECK_RC(launch_layernorm(v->x, W, L.ln2w, L.ln2b, c.ln_eps, rows, W, v->h, W, 1, st));
+        }
         CHECK_RC(gemm("gemm_fc1", EPI_BF16_GELU, v->h, W, L.w_fc1, W, rows, Md, W, v->mlp, Md, L.b_fc1, nullptr, st));
         // scratch for the split-K forms of fc2 (leftover rows at large batch, the whole GEMM at small batch)
+        h_ready = 0;
+        LnAfter ln1n{nullptr, nullptr, c.ln_eps, v->h, W, &h_ready};
+        if (i + 1 < nl) { ln1n.w = v->layers[i + 1].ln1w; ln1n.b = v->layers[i + 1].ln1b; }
         CHECK_RC(gemm("gemm_fc2", EPI_RESID_F32, v->mlp, Md, L.w_fc2, Md, rows, W, Md, v->x, W, L.b_fc2, L.ls2, st,
-                      vv->splitk_ws, (long)SPLITK_WS_ELEMS));
+                      vv->splitk_ws, (long)SPLITK_WS_ELEMS, i + 1 < nl ? &ln1n : nullptr));
     }
     if (v->debug_layers >= 0) return 0;   // parity hook: residual stream only
 

@@ -643,18 +643,94 @@ __global__ __launch_bounds__(256) void splitk_reduce_resid_kernel(const float* _
     float* dst = x + (long)r * ldc + c;
     *(f32x4*)dst = *(const f32x4*)dst + v;
 }
+// The same reduction, one wave per row, followed by the LayerNorm of the updated row (elementwise.hip layernorm8_kernel's
+// arithmetic: 8 consecutive elements per lane and step, two-pass fp32 statistics): x_new = x + gamma * (sum_s ws_s + bias)
+// is stored AND normalised into h (bf16) from the registers that hold it.  One-image forwards only (a few hundred rows).
+template <int MAXG>
+__global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float* __restrict__ ws, int S, long plane, int rows, int N,
+                                                                     const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                                     float* __restrict__ x, long ldc, const float* __restrict__ lw,
+                                                                     const float* __restrict__ lb, float eps,
+                                                                     bf16_t* __restrict__ h, long ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int ngroup = N >> 3;
+    f32x4 v[MAXG][2];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+        const int g = lane + 64 * i;
+        if (g < ngroup) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const long e = (long)row * N + g * 8 + hh * 4;
+                f32x4 t = *(const f32x4*)(ws + e);
+                for (int p2 = 1; p2 < S; ++p2) t += *(const f32x4*)(ws + (long)p2 * plane + e);
+                if (bias) t += *(const f32x4*)(bias + g * 8 + hh * 4);
+                if (gamma) t *= *(const f32x4*)(gamma + g * 8 + hh * 4);
+                float* dst = x + (long)row * ldc + g * 8 + hh * 4;
+                t = *(const f32x4*)dst + t;
+                *(f32x4*)dst = t;
+                v[i][hh] = t;
+            }
+            s += ((v[i][0][0] + v[i][0][1]) + (v[i][0][2] + v[i][0][3])) + ((v[i][1][0] + v[i][1][1]) + (v[i][1][2] + v[i][1][3]));
+        } else {
+            v[i][0] = v[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+        const int g = lane + 64 * i;
+        if (g < ngroup) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[i][hh][j] - mean;
+                    q = fmaf(d, d, q);
+                }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)N + eps);
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+        const int g = lane + 64 * i;
+        if (g < ngroup) {
+            float y[8];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x4 gm = *(const f32x4*)(lw + g * 8 + hh * 4);
+                const f32x4 be = *(const f32x4*)(lb + g * 8 + hh * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[hh * 4 + j] = fmaf((v[i][hh][j] - mean) * rstd, gm[j], be[j]);
+            }
+            uint4 o;
+            o.x = pack_bf16x2(y[0], y[1]);
+            o.y = pack_bf16x2(y[2], y[3]);
+            o.z = pack_bf16x2(y[4], y[5]);
+            o.w = pack_bf16x2(y[6], y[7]);
+            *(uint4*)(h + (long)row * ldo + g * 8) = o;
+        }
+    }
+}
 static int g_splitk = 1;     // timing experiments only: 0 disables the split-K tail
 void gemm_set_splitk(int on) { g_splitk = on; }
 // returns 1 when it took the problem, 0 when the caller should use the ordinary path
 static int try_splitk_tail(const GemmArgs& a, hipStream_t st) {
-    if (!g_splitk || !a.ws || a.N % 4 || a.K < 2048) return 0;
+    if (!g_splitk || !a.ws || a.N % 4 || a.K < 1024) return 0;
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256, nt = a.K / 64;
     {
-        // one image: so few tiles that even 128 x 64 ones leave most CUs idle -- the ring kernel on K thirds (80 tiles x 3)
+        // one image: so few tiles that even 128 x 64 ones leave most CUs idle -- the ring kernel on K thirds (80 tiles x 3);
+        // with the LayerNorm that follows folded into the reduce this also pays at K = 1024 (out-proj: 5 K-steps per part)
         const int tiles64 = ((a.M + 127) / 128) * ((a.N + 63) / 64);
+        const bool with_ln = a.ln_w && a.ln_b && a.ln_out && a.ln_fused && a.N % 8 == 0 && a.N <= 2048 && a.ln_ldo % 8 == 0;
         int S = g_ring && a.N % 64 == 0 ? 256 / tiles64 : 0;
         S = S > 8 ? 8 : S;
-        while (S > 1 && nt / S < 8) --S;
+        while (S > 1 && nt / S < (with_ln ? 4 : 8)) --S;
+        if (a.K < 2048 && !with_ln) S = 0;
         const long plane = (long)a.M * a.N;
         if (S >= 2 && plane * S <= a.ws_elems) {
             constexpr int LDS = G128R_NST * (128 + 64) * 128;
@@ -664,6 +740,20 @@ static int try_splitk_tail(const GemmArgs& a, hipStream_t st) {
             b.ksplit = S; b.c_split_stride = plane;
             hipLaunchKernelGGL((gemm128r_kernel<EPI_F32>), dim3(tiles64, S), dim3(GEMM_THREADS), LDS, st, b);
             REVO_HIP_CHECK(hipGetLastError());
+            if (with_ln) {
+                const dim3 grid((unsigned)((a.M + 3) / 4));
+                const int groups = (a.N / 8 + 63) / 64;
+#define RLN_LAUNCH(G) hipLaunchKernelGGL((splitk_reduce_resid_ln_kernel<G>), grid, dim3(256), 0, st, a.ws, S, plane, a.M, a.N, a.bias, \
+                                         a.gamma, (float*)a.C, a.ldc, a.ln_w, a.ln_b, a.ln_eps, a.ln_out, a.ln_ldo)
+                if (groups <= 1) RLN_LAUNCH(1);
+                else if (groups <= 2) RLN_LAUNCH(2);
+                else if (groups <= 3) RLN_LAUNCH(3);
+                else RLN_LAUNCH(4);
+#undef RLN_LAUNCH
+                REVO_HIP_CHECK(hipGetLastError());
+                *a.ln_fused = 1;
+                return 1;
+            }
             const long quads = plane / 4;
             hipLaunchKernelGGL(splitk_reduce_resid_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a.ws, S, plane,
                                a.M, a.N, a.bias, a.gamma, (float*)a.C, a.ldc);
@@ -671,6 +761,7 @@ static int try_splitk_tail(const GemmArgs& a, hipStream_t st) {
             return 1;
         }
     }
+    if (a.K < 2048) return 0;
     // XCD arrangement that spreads these few tiles most evenly (an XCD has 32 CUs: its tiles x S must fit)
     int gy = 1, per = 1 << 30;
     for (int g : {1, 2, 4, 8}) {
@@ -711,7 +802,7 @@ static int launch_t(const GemmArgs& a, hipStream_t st) {
         return launch_256<EPI>(a, st);
     if constexpr (EPI == EPI_RESID_F32) {
         // a few tiles with a long K (fc2 of one to a few images): the K loop is a latency chain, cut it across CUs
-        if (g_force_tile == 0 && a.M > 64 && a.K >= 2048 && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) <= 96 &&
+        if (g_force_tile == 0 && a.M > 64 && (a.K >= 2048 || (a.K >= 1024 && a.ln_w)) && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) <= 96 &&
             256l * a.lda * 2 < (1l << 31) && 256l * a.ldb * 2 < (1l << 31)) {
             const int rc2 = try_splitk_tail(a, st);
             if (rc2 < 0) return rc2;
@@ -735,6 +826,7 @@ static int launch_t(const GemmArgs& a, hipStream_t st) {
             if (m_tiles_main >= 1 && m_tiles_main < tm) {
                 const int m_main = (int)(m_tiles_main * 256);
                 GemmArgs a1 = a, a2 = a;
+                a1.ln_w = a2.ln_w = nullptr;          // a LayerNorm can only be folded into a launch form that covers ALL rows
                 a1.M = m_main;
                 a2.M = a.M - m_main;
                 a2.A = a.A + (long)m_main * a.lda;

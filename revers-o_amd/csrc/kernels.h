@@ -29,6 +29,11 @@ struct GemmArgs {
     int prefer256;               // caller's hint: few rows but very many columns (search pre-pass) -> 256 x 256 tiles
     float* ws; long ws_elems;    // optional scratch for the split-K tail of EPI_RESID_F32 (null = never split K)
     int ksplit; long c_split_stride;   // set by the launcher: K ranges per tile, fp32 elements between partial outputs
+    // EPI_RESID_F32 only, optional: the LayerNorm that reads the updated residual rows next (ln_w != null).  If the
+    // launcher takes the one-image form -- ring kernel on K parts + one reduce -- the reduce also normalises its rows
+    // into ln_out (bf16) and *ln_fused is set to 1: the caller then skips that LayerNorm launch (a 577-row LayerNorm is
+    // nothing but its launch: 5 us of a 90-us block).  Any other form leaves *ln_fused alone.
+    const float* ln_w; const float* ln_b; float ln_eps; bf16_t* ln_out; long ln_ldo; int* ln_fused;
 #ifdef REVO_EXPERIMENTS
     int stagger_cycles, stagger_groups;   // timing experiment (persistent kernel): phase groups, see gemm256p_kernel
 #endif
