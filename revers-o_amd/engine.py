@@ -392,9 +392,15 @@ def set_default(engine=None, gallery=None):
 
 
 def embed(images, engine=None):
+    """images: uint8 / float32 ``[B,3,H,W]`` device tensor at the model resolution, or a list of PIL images / arrays /
+    paths (squash-resized on the host like ``self.preprocess`` at core_system.py:439, uploaded as uint8).
+    Returns fp32 ``[B, D]`` on the device, L2-normalised."""
     eng = engine or _default_engine
     if eng is None:
         raise _lib.RevoError("embed(): no engine; create a VitEngine and call set_default(engine=...)")
+    if isinstance(images, (list, tuple)):
+        from . import preprocess as pp
+        images = pp.batch_u8(list(images), eng.cfg.image_size, pin=True).to(eng.device, non_blocking=True)
     return eng.embed(images)
 
 

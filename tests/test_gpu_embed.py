@@ -252,3 +252,18 @@ def test_l14_every_batch_size_family_agrees(dev):
         cos = (a * full[:B]).sum(-1)
         assert float(cos.min()) >= 0.99995, (B, float(cos.min()))
     eng.close()
+
+
+def test_module_level_embed_accepts_pil_images(dev):
+    """engine.embed() -- the core API named by north_star -- takes what the reference's process_image_direct_pe takes:
+    PIL images (any size: squash-resized like self.preprocess, core_system.py:439), arrays, or a ready device batch."""
+    from PIL import Image
+    from reverso_amd import preprocess as pp
+    cfg, sd, _ = make_golden.tiny_case()
+    eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=4)
+    rng = np.random.default_rng(0)
+    pils = [Image.fromarray(rng.integers(0, 256, (40 + 9 * i, 70 - 5 * i, 3), dtype=np.uint8)) for i in range(3)]
+    a = engine.embed(pils, engine=eng)
+    b = eng.embed(pp.batch_u8(pils, cfg.image_size).to(dev))
+    assert torch.equal(a, b) and a.shape == (3, cfg.out_dim)
+    eng.close()
