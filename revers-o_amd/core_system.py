@@ -517,7 +517,8 @@ class SimpleReverso:
         B = self.max_batch
         # enough decode threads to feed the device in this mode and no more (see __init__): host resize costs 9 ms of
         # thread time per 640 x 480 JPEG, decode alone 4 ms; crops are embedded three to an image
-        want_threads = self.decode_workers or (16 if host_resize else (6 if self.region_mode == "crop" and not use_direct_pe else 8))
+        want_threads = self.decode_workers or min(os.cpu_count() or 8,
+                                                  16 if host_resize else (6 if self.region_mode == "crop" and not use_direct_pe else 8))
         if want_threads != self._decode_pool._max_workers:
             self._decode_pool.shutdown(wait=True)
             self._decode_pool = ThreadPoolExecutor(max_workers=want_threads)
