@@ -1073,6 +1073,7 @@ extern "C" int32_t revo_op_set_variant(int32_t flags) {
     revo::gemm_set_splitk(((flags >> 17) & 1) ? 0 : 1);
     revo::gemm_set_min_tiles256(((flags >> 18) & 1) ? 0 : 100);
     revo::gemm_set_ring(((flags >> 19) & 1) ? 0 : 1, 0);
+    revo::gemm_set_rows192(((flags >> 3) & 1) ? 0 : 1);
     return 0;
 }
 extern "C" int32_t revo_op_set_gemm_tile(int32_t tile) {

@@ -162,7 +162,9 @@ __device__ __forceinline__ void gemm256_epilogue_f32_quarter(const GemmArgs& p, 
 // reads/writes global memory in whole 128-byte (bf16) or 256-byte (fp32) row segments,
 // 16 bytes per lane.  Bias, GELU and LayerScale are applied before the transpose, the
 // residual add after it (on the coalesced rows).
-template <int EPI>
+// SKIP_DEAD (192-row tiles): a wave whose second 64 rows lie past p.M (the caller passes the tile's row limit as p.M)
+// skips them altogether instead of masking their stores.
+template <int EPI, bool SKIP_DEAD = false>
 __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, int m_base, int n_base, int lane,
                                                  f32x4 (&acc)[8][4]) {
     static_assert(EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_F32 || EPI == EPI_RESID_F32 ||
@@ -183,6 +185,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
         constexpr int RS = 144;   // 64 bf16 + 16 bytes of padding per slab row
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+            if (SKIP_DEAD && m_base + half * 64 >= p.M) break;          // wave-uniform
             asm volatile("" : "+v"(lane) :: "memory");
             const int lr = lane & 15, lq = lane >> 4;
             // RoPE table entries of this half's 8 store steps, requested before the LDS transpose so that
@@ -252,6 +255,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
         if (EPI == EPI_RESID_F32) gemm256_load_resid<1>(p, m_base, n_base, lane, rb);
         gemm256_epilogue_f32_quarter<EPI, 0>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, ra);
         gemm256_epilogue_f32_quarter<EPI, 1>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, rb);
+        if (SKIP_DEAD && m_base + 64 >= p.M) return;                    // wave-uniform
         if (EPI == EPI_RESID_F32) gemm256_load_resid<2>(p, m_base, n_base, lane, ra);
         if (EPI == EPI_RESID_F32) gemm256_load_resid<3>(p, m_base, n_base, lane, rb);
         gemm256_epilogue_f32_quarter<EPI, 2>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, ra);
@@ -397,12 +401,16 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256_kernel(GemmArgs p) {
 // last store and the next tile's first MFMA.  LDS while an epilogue runs: A stage 0 and B stage 0
 // are being filled; the wave-private transpose slabs live in A stage 1 (waves 0-2) and in B stage
 // 1 plus the 32 KiB above the main-loop image (waves 3-7).
+// BMR = 192: 192-row tiles (gemm256_mainloop<192>), chosen by the launcher where they make whole rounds.
 constexpr int G256P_LDS = 163840;
-template <int EPI>
+template <int EPI, int BMR = 256>
 __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, int nslot) {
+    static_assert(BMR == 256 || BMR == 192, "");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = (p.N + 255) / 256;
-    const int tiles_m = (p.M + 255) / 256;
+    // 192-row form: p.t192_tiles tile rows, the last p.t192_tall of them 208 rows tall (set by the launcher)
+    const int tiles_m = BMR == 256 ? (p.M + 255) / 256 : p.t192_tiles;
+    const int tall0 = tiles_m - p.t192_tall;
     const int gy = p.gy, gx = 8 / gy;
     const int xcd = blockIdx.x & 7;
     const int xi = xcd / gy, xj = xcd - xi * gy;
@@ -426,9 +434,13 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
     }
 #endif
 
-    int m0 = (m_lo + slot / n_cnt) * 256, n0 = (n_lo + slot % n_cnt) * 256;
+    // row origin / height of tile row mi
+    auto tile_row0 = [&](int mi) { return BMR == 256 ? mi * 256 : mi * 192 + (mi > tall0 ? (mi - tall0) * 16 : 0); };
+    int mi = m_lo + slot / n_cnt;
+    int m0 = tile_row0(mi), n0 = (n_lo + slot % n_cnt) * 256;
+    bool tall = BMR != 256 && mi >= tall0;
     G256Operand A, B;
-    g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane);
+    g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane, BMR == 256 ? 256 : (tall ? 208 : 192));
     g256_operand_init(B, p.B, p.ldb, p.N, n0, wave, lane);
     g256_issue_half(A, 0, 0, G256_A(smem, 0), wave);
     g256_issue_half(A, 1, 0, G256_A(smem, 0), wave);
@@ -444,15 +456,23 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
         for (int m = 0; m < 8; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        gemm256_mainloop(A, B, smem, p.K, wave, lane, acc);
+        if constexpr (BMR == 256) gemm256_mainloop(A, B, smem, p.K, wave, lane, acc);
+        else gemm256_mainloop<192>(A, B, smem, p.K, wave, lane, acc, tall);
 
         const int mb = m0 + (wave >> 2) * 128, nb = n0 + (wave & 3) * 64;
+        GemmArgs pe = p;                                   // the epilogue's row limit: the end of this tile
+        if (BMR != 256) {
+            const int mend = m0 + (tall ? 208 : 192);
+            pe.M = mend < p.M ? mend : p.M;
+        }
         slot += nslot;
         const bool more = slot < total;
         if (more) {
-            m0 = (m_lo + slot / n_cnt) * 256;
+            mi = m_lo + slot / n_cnt;
+            m0 = tile_row0(mi);
             n0 = (n_lo + slot % n_cnt) * 256;
-            g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane);
+            tall = BMR != 256 && mi >= tall0;
+            g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane, BMR == 256 ? 256 : (tall ? 208 : 192));
             g256_operand_init(B, p.B, p.ldb, p.N, n0, wave, lane);
             g256_issue_half(A, 0, 0, G256_A(smem, 0), wave);
             g256_issue_half(A, 1, 0, G256_A(smem, 0), wave);
@@ -460,11 +480,11 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
             g256_issue_half(B, 1, 0, G256_B(smem, 0), wave);
         }
         if constexpr (EPI == EPI_PATCH) {
-            gemm_epilogue<EPI, 8, 4>(p, mb, nb, lane, acc);
+            gemm_epilogue<EPI, 8, 4>(pe, mb, nb, lane, acc);
         } else {
             const bool wide = (p.N & 7) == 0 && (p.ldc & 7) == 0;
-            if (wide) gemm256_epilogue<EPI>(p, slab, mb, nb, lane, acc);
-            else gemm_epilogue<EPI, 8, 4>(p, mb, nb, lane, acc);
+            if (wide) gemm256_epilogue<EPI, BMR != 256>(pe, slab, mb, nb, lane, acc);
+            else gemm_epilogue<EPI, 8, 4>(pe, mb, nb, lane, acc);
         }
         if (!more) break;
         __builtin_amdgcn_s_barrier();      // every wave is out of its slab before A stage 1 is refilled
@@ -473,52 +493,60 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
 
 // Skinny GEMM for M <= 64 (the attention-pool head at batch <= 64: four layers whose time is the
 // streaming of 2-8 MB of weights).  The tiled kernels give such a problem N/128 workgroups and a
-// serial K loop; here a workgroup owns 16 output columns, its 4 waves split K, operands go
+// serial K loop; here a workgroup owns 16 output columns, its NW (4 or 16) waves split K, operands go
 // global -> registers in MFMA fragment layout with eight k-steps of loads in flight, and the
 // partial accumulators meet in LDS.
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
-    __shared__ f32x4 red[3][4][64];
+// MY = 1: a workgroup covers all (up to 64) rows, four accumulator fragments per wave.  MY = 4: blockIdx.y picks one
+// 16-row fragment -- four times the workgroups, each reading a quarter of A: the leftover rows of a batch-64 layer (64 x
+// 1024..4096 x 1024..4096) are bound by what ONE CU can pull through its L2 port (every workgroup of the MY = 1 form
+// reads all of A: 640 KB at K = 4096, 20 us), not by the chip.
+template <int EPI, int NW, int DEPTH, int MY>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p) {
+    constexpr int MFR = MY == 1 ? 4 : 1;
+    __shared__ f32x4 red[NW - 1][MFR][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    const int kw = p.K >> 2;                       // this wave's K range
+    const int m0 = MY == 1 ? 0 : (int)blockIdx.y * 16;
+    const int kw = p.K / NW;                       // this wave's K range
     const int nrow = n0 + lr < p.N ? n0 + lr : p.N - 1;
     const bf16_t* bp = p.B + (long)nrow * p.ldb + wave * kw + lq * 8;
-    const bf16_t* ap[4];
+    const bf16_t* ap[MFR];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int row = m * 16 + lr < p.M ? m * 16 + lr : p.M - 1;
+    for (int m = 0; m < MFR; ++m) {
+        const int row = m0 + m * 16 + lr < p.M ? m0 + m * 16 + lr : p.M - 1;
         ap[m] = p.A + (long)row * p.lda + wave * kw + lq * 8;
     }
-    f32x4 acc[4][1];
+    f32x4 acc[MFR][1];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < kw; k += 64) {             // kw % 64 == 0 (launcher checks K % 256 == 0)
-        bf16x8 b[2], a[2][4];
+    for (int m = 0; m < MFR; ++m) acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // DEPTH x 64 k per trip, every load of a trip requested before its first MFMA: the K loop is a chain of global-load
+    // latencies (the launcher checks K % (64 NW DEPTH) == 0)
+    for (int k = 0; k < kw; k += 64 * DEPTH) {
+        bf16x8 b[2 * DEPTH], a[2 * DEPTH][MFR];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 2 * DEPTH; ++u) {
             b[u] = *(const bf16x8*)(bp + k + u * 32);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[u][m] = *(const bf16x8*)(ap[m] + k + u * 32);
+            for (int m = 0; m < MFR; ++m) a[u][m] = *(const bf16x8*)(ap[m] + k + u * 32);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2 * DEPTH; ++u)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MFR; ++m)
                 acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u], a[u][m], acc[m][0], 0, 0, 0);
     }
     if (wave > 0) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) red[wave - 1][m][lane] = acc[m][0];
+        for (int m = 0; m < MFR; ++m) red[wave - 1][m][lane] = acc[m][0];
     }
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int w = 0; w < 3; ++w)
+        for (int w = 0; w < NW - 1; ++w)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m][0] += red[w][m][lane];
-        gemm_epilogue<EPI, 4, 1>(p, 0, n0, lane, acc);
+            for (int m = 0; m < MFR; ++m) acc[m][0] += red[w][m][lane];
+        gemm_epilogue<EPI, MFR, 1>(p, m0, n0, lane, acc);
     }
 }
 
@@ -558,21 +586,21 @@ void gemm_set_stagger(int cycles, int groups) { g_stagger_cycles = cycles; g_sta
 #endif
 static int g_persistent = 1;   // timing experiments only: 0 = one workgroup per tile
 void gemm_set_persistent(int on) { g_persistent = on; }
-template <int EPI>
+template <int EPI, int BMR = 256>
 static int launch_256p(const GemmArgs& a, hipStream_t st) {
-    REVO_FUNC_LDS(gemm256p_kernel<EPI>, G256P_LDS);
+    REVO_FUNC_LDS((gemm256p_kernel<EPI, BMR>), G256P_LDS);
     GemmArgs b = a;
 #ifdef REVO_EXPERIMENTS
     b.stagger_cycles = g_stagger_cycles; b.stagger_groups = g_stagger_groups;
 #endif
-    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
+    const int tiles_m = BMR == 256 ? (a.M + 255) / 256 : a.t192_tiles, tiles_n = (a.N + 255) / 256;
     int gy = tiles_n >= 12 ? 4 : (tiles_n >= 8 ? 2 : 1);
     if (g_force_gy) gy = g_force_gy;
     b.gy = gy;
     const int gx = 8 / gy;
     const int region = ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
     const int nslot = region < 32 ? region : 32;          // 32 CUs per XCD
-    hipLaunchKernelGGL((gemm256p_kernel<EPI>), dim3(8 * nslot), dim3(G256_THREADS), G256P_LDS, st, b, nslot);
+    hipLaunchKernelGGL((gemm256p_kernel<EPI, BMR>), dim3(8 * nslot), dim3(G256_THREADS), G256P_LDS, st, b, nslot);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -789,9 +817,41 @@ static int try_splitk_tail(const GemmArgs& a, hipStream_t st) {
 }
 
 static bool use_skinny(const GemmArgs& a) { return g_force_tile == 0 && a.M <= 64 && a.K % 256 == 0 && a.N >= 256; }
+
+// 192-row tiles.  The 256 x 256 kernel's tiles go in rounds of 256 (one workgroup per CU); PE-L14 at batch 64 has
+// 36 928 rows = 144.25 tile rows, which for the two residual GEMMs (four tile columns) is 2.27 rounds: two whole ones
+// and leftover rows that cost small-tile kernels more than half a round.  With 192-row tiles the same rows are
+// 192 tile rows x 4 = exactly three rounds of 3/4 the work each (gemm256_mainloop<192>); the 64 rows that are still
+// left make the last four tile rows 208 rows tall (1/16 of a tile's work more for 16 of the 768 workgroup-tiles: a
+// launch of their own cost 10-17 us).  Returns the number of tile rows (and how many are tall), or 0 when the 256-row
+// plan is no worse.
+static int g_rows192 = 1;      // timing experiments only: 0 disables the 192-row form
+void gemm_set_rows192(int on) { g_rows192 = on; }
+static int plan_rows192(const GemmArgs& a, bool can_split_tail, int* tall) {
+    if (!g_rows192 || g_force_tile || a.K < 128 || a.M % 16) return 0;
+    // T tile rows of 192, the last e of them 16 rows taller: M = 192 T + 16 e
+    const long tn = (a.N + 255) / 256, T = a.M / 192, e = (a.M - T * 192) / 16;
+    if (e > T || e > 8) return 0;
+    const long tiles192 = T * tn, rounds192 = (tiles192 + 255) / 256;
+    if (tiles192 <= 256 || rounds192 * 256 - tiles192 > tiles192 / 32) return 0;      // whole rounds only
+    // the 256-row plan in tile times: its whole rounds, plus a last round or what the tail split makes of it
+    const long tiles = ((a.M + 255) / 256) * tn, full = tiles / 256, rem = tiles % 256;
+    double cost256 = (double)full;
+    if (rem) cost256 += (can_split_tail && g_tail_split && full > 0 && rem <= 160) ? (rem > 77 ? rem / 128.0 : 0.6) : 1.0;
+    const double cost192 = rounds192 * 0.75 * 1.06 + (e ? 0.0625 : 0.0);
+    if (cost192 >= cost256) return 0;
+    *tall = (int)e;
+    return (int)T;
+}
 template <int EPI>
 static int launch_skinny(const GemmArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(gemm_skinny_kernel<EPI>, dim3((a.N + 15) / 16), dim3(256), 0, st, a);
+    // few output columns (N / 16 workgroups would leave most CUs idle, each pulling all of A through one L2 port): one
+    // workgroup per 16 x 16 fragment, all loads of 256 k per wave in flight -- 64 x 1024 x 4096: 21 -> 9 us, x 1024: 8 -> 6
+    // (same bits: per element the same K order and the same fixed-order sum of the waves' parts)
+    if (a.K % 1024 == 0 && a.N <= 2048)
+        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 4, 4, 4>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 4, 1, 1>), dim3((a.N + 15) / 16), dim3(256), 0, st, a);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -818,6 +878,15 @@ static int launch_t(const GemmArgs& a, hipStream_t st) {
         // and fc2 have 580 tiles = 2.27 rounds, fc1 2320 = 9.06).  When the last round would be
         // less than ~60 % full, the 256 x 256 kernel takes the M rows that make whole rounds and
         // the remaining rows go to the 128 x 128 kernel (two workgroups per CU, 4x shorter tiles).
+        if constexpr (EPI == EPI_RESID_F32) {
+            int tall = 0;
+            if (const int t192 = plan_rows192(a, true, &tall)) {
+                GemmArgs a1 = a;
+                a1.ln_w = nullptr;
+                a1.t192_tiles = t192; a1.t192_tall = tall;
+                return launch_256p<EPI, 192>(a1, st);
+            }
+        }
         const long tm = (a.M + 255) / 256, tn = (a.N + 255) / 256;
         const long tiles = tm * tn, full = tiles / 256 * 256, rem = tiles - full;
         if (g_tail_split && g_force_tile == 0 && EPI != EPI_PATCH && EPI != EPI_BF16_ROPE && full > 0 && rem > 0 &&

@@ -40,12 +40,14 @@ struct G256Operand {
 // Block j's descriptor covers rows [row0 + 64 j, min(row0 + 64 j + 64, rows)): a lane whose
 // row lies past the matrix edge addresses beyond num_records and the DMA writes zeros.
 // One VGPR of addressing per operand; every window is < 4 GiB whatever the operand size.
+// tile_rows < 256 (a 192- or 208-row tile): the rows past it get empty windows -- their DMA moves no data and writes zeros.
 __device__ __forceinline__ void g256_operand_init(G256Operand& op, const bf16_t* base, long ld, long rows, int row0,
-                                                  int wave, int lane) {
+                                                  int wave, int lane, int tile_rows = 256) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         long left = rows - (row0 + 64 * j);
         left = left < 0 ? 0 : (left > 64 ? 64 : left);
+        if (left > tile_rows - 64 * j) left = tile_rows - 64 * j < 0 ? 0 : tile_rows - 64 * j;
         op.rsrc[j] = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)(row0 + 64 * j) * ld), 0,
                                                        (int)(left * ld * 2), 0x00020000);
     }
@@ -120,6 +122,21 @@ __device__ __forceinline__ void g256_cluster(const bf16x8 (&a)[4][2], const bf16
     __builtin_amdgcn_s_setprio(0);
 }
 
+// first fragment only (the 16 extra rows of a 208-row tile)
+template <int ROWS, int STAGE>
+__device__ __forceinline__ void g256_read_a1(bf16x8 (&dst)[4][2], const uint32_t (&base)[2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) dst[0][kk] = *(lds_frag_ptr)(uintptr_t)(base[kk] + STAGE * 32768 + ROWS * 128);
+}
+template <int M0, int N0>
+__device__ __forceinline__ void g256_cluster1(const bf16x8 (&a)[4][2], const bf16x8 (&b)[2][2], f32x4 (&acc)[8][4]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            acc[M0][N0 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[n][kk], a[0][kk], acc[M0][N0 + n], 0, 0, 0);
+}
+
 #define G256_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // DMA for the first 1.5 K-tiles of an output tile (tile 0 complete, A of tile 1).  May be
@@ -144,13 +161,19 @@ __device__ __forceinline__ void g256_issue_prologue(const G256Operand& A, const 
 // waves of the second wave-row (and, at 64, the A-hi halves of the first) skip their LDS reads and
 // MFMAs (their accumulators stay 0) but keep issuing DMA and meeting the barriers, so the loop runs
 // at the DMA / HBM rate instead of the MFMA rate.
+// ROWS = 192: a 192-row output tile (the linear layers use it where 192-row tiles make whole rounds of workgroups and
+// 256-row ones do not): the second wave-row skips its A-hi halves only.  Waves w and w + 4 share a SIMD, so every SIMD
+// carries one full and one half wave tile: 3/4 of the MFMA work of a 256-row tile, evenly spread.  With `tall` (wave
+// uniform) the tile has 208 rows: the second wave-row also takes the first fragment of its A-hi half (rows 192..207),
+// 1/16 of a tile's work more -- how the launcher places a few leftover rows without a launch of their own.
 template <int ROWS = 0>
 __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G256Operand& B, char* smem, int K,
-                                                 int wave, int lane, f32x4 (&acc)[8][4]) {
-    static_assert(ROWS == 0 || ROWS == 64 || ROWS == 128, "");
+                                                 int wave, int lane, f32x4 (&acc)[8][4], bool tall = false) {
+    static_assert(ROWS == 0 || ROWS == 64 || ROWS == 128 || ROWS == 192, "");
     const bool wact = wave < 4;
-#define G256_LO(...) do { if (ROWS == 0 || wact) { __VA_ARGS__; } } while (0)
-#define G256_HI(...) do { if (ROWS == 0 || (ROWS == 128 && wact)) { __VA_ARGS__; } } while (0)
+#define G256_LO(...) do { if (ROWS == 0 || ROWS == 192 || wact) { __VA_ARGS__; } } while (0)
+#define G256_HI(...) do { if (ROWS == 0 || ((ROWS == 128 || ROWS == 192) && wact)) { __VA_ARGS__; } } while (0)
+#define G256_HT(...) do { if (ROWS == 192 && !wact && tall) { __VA_ARGS__; } } while (0)
     const int nt = K >> 6;
     G256Frags f;
     G256Addr ad;
@@ -174,6 +197,7 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             const bool n1 = t + 1 < nt, n2 = t + 2 < nt;
             // P0
             G256_HI(g256_read_a<64, 0>(f.ahi, ad.a););
+            G256_HT(g256_read_a1<64, 0>(f.ahi, ad.a););
             if (n1) g256_issue_half(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_LO(g256_cluster<0, 0>(f.alo, f.blo, acc););
@@ -183,6 +207,7 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             if (n1) g256_issue_half(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
+            G256_HT(g256_cluster1<4, 0>(f.ahi, f.blo, acc););
             G256_FENCE();
             // P2: every wave has retired its A reads of this stage -> refill its A halves
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -190,6 +215,7 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             if (n2) g256_issue_half(A, 0, (t + 2) * 128, G256_A(smem, 0), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 2>(f.ahi, f.bhi, acc););
+            G256_HT(g256_cluster1<4, 2>(f.ahi, f.bhi, acc););
             G256_FENCE();
             // P3: publish tile t+1, start reading it
             if (n2) g256_issue_half(A, 1, (t + 2) * 128, G256_A(smem, 0), wave);
@@ -198,6 +224,7 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 G256_HI(g256_read_a<64, 1>(f.ahi, ad.a););          // odd tiles start with A-hi
+                G256_HT(g256_read_a1<64, 1>(f.ahi, ad.a););
                 G256_LO(g256_read_b<0, 1>(f.blo, ad.b););
             }
             G256_FENCE();
@@ -213,6 +240,7 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             if (n1) g256_issue_half(B, 0, (u + 1) * 128, G256_B(smem, 0), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
+            G256_HT(g256_cluster1<4, 0>(f.ahi, f.blo, acc););
             G256_FENCE();
             // P1'
             G256_LO(g256_read_b<32, 1>(f.bhi, ad.b););
@@ -238,6 +266,7 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             }
             G256_FENCE();
             G256_HI(g256_cluster<4, 2>(f.ahi, f.bhi, acc););
+            G256_HT(g256_cluster1<4, 2>(f.ahi, f.bhi, acc););
             G256_FENCE();
         }
     }
@@ -247,6 +276,7 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             const bool n1 = t + 1 < nt, n2 = t + 2 < nt;
             // P0
             G256_HI(g256_read_a<64, 0>(f.ahi, ad.a););
+            G256_HT(g256_read_a1<64, 0>(f.ahi, ad.a););
             if (n1) g256_issue_half(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_LO(g256_cluster<0, 0>(f.alo, f.blo, acc););
@@ -256,6 +286,7 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             if (n1) g256_issue_half(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
+            G256_HT(g256_cluster1<4, 0>(f.ahi, f.blo, acc););
             G256_FENCE();
             // P2: every wave has retired its A reads of this stage -> refill its A halves
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -263,6 +294,7 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             if (n2) g256_issue_half(A, 0, (t + 2) * 128, G256_A(smem, 0), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 2>(f.ahi, f.bhi, acc););
+            G256_HT(g256_cluster1<4, 2>(f.ahi, f.bhi, acc););
             G256_FENCE();
             // P3: publish tile t+1, start reading it
             if (n2) g256_issue_half(A, 1, (t + 2) * 128, G256_A(smem, 0), wave);
@@ -271,6 +303,7 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 G256_HI(g256_read_a<64, 1>(f.ahi, ad.a););          // odd tiles start with A-hi
+                G256_HT(g256_read_a1<64, 1>(f.ahi, ad.a););
                 G256_LO(g256_read_b<0, 1>(f.blo, ad.b););
             }
             G256_FENCE();
@@ -283,6 +316,7 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
     __builtin_amdgcn_s_barrier();
 #undef G256_LO
 #undef G256_HI
+#undef G256_HT
 }
 
 }  // namespace revo

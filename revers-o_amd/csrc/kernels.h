@@ -28,6 +28,7 @@ struct GemmArgs {
     int rope_S, rope_hd, rope_cols;
     int prefer256;               // caller's hint: few rows but very many columns (search pre-pass) -> 256 x 256 tiles
     float* ws; long ws_elems;    // optional scratch for the split-K tail of EPI_RESID_F32 (null = never split K)
+    int t192_tiles, t192_tall;         // set by the launcher (192-row form): tile rows, how many of the last are 208 rows tall
     int ksplit; long c_split_stride;   // set by the launcher: K ranges per tile, fp32 elements between partial outputs
     // EPI_RESID_F32 only, optional: the LayerNorm that reads the updated residual rows next (ln_w != null).  If the
     // launcher takes the one-image form -- ring kernel on K parts + one reduce -- the reduce also normalises its rows
@@ -96,6 +97,7 @@ void gemm_set_min_tiles256(int n);  // timing experiments only (default 100)
 void gemm_set_ring(int on, int max_tiles);   // timing experiments only (default on, 256 tiles)
 void gemm_set_splitk(int on);       // timing experiments only (1 = default)
 void gemm_set_persistent(int on);   // timing experiments only (1 = default)
+void gemm_set_rows192(int on);      // timing experiments only (1 = default)
 void attention_force_nw(int nw);   // timing experiments only (0 = heuristic)
 
 // ---------------------------------------------------------------- top-k ----

@@ -325,6 +325,53 @@ def test_gemm_splitk_tail_residual(lib, dev, gemm_tile, M, N, K):
     assert (outs[0][rows] - ref).abs().max().item() <= 3e-3 * math.sqrt(K / 64)
 
 
+@pytest.mark.parametrize("M,N,K", [(36928, 1024, 1024), (36928, 1024, 4096), (36864, 1024, 1024), (12288 + 32, 4096, 512),
+                                   (49152 + 128, 1536, 1536)])
+def test_gemm_192_row_tiles_residual(lib, dev, gemm_tile, M, N, K):
+    """Residual GEMMs whose rows make whole rounds of 192-row tiles but not of 256-row ones (PE-L14 at batch 64: 192 tile
+    rows x 4 = three rounds; the 64 rows left over make the last four tile rows 208 rows tall): same bits as the 256-row
+    plan wherever that plan runs its 256 x 256 kernel (same MFMA order along K, same epilogue arithmetic),
+    summation-order differences in the rows the 256-row plan gives to its tail kernels, deterministic, and right
+    against fp32 on rows around every kind of edge (192-row tile edges, the first tall tile, the last rows)."""
+    if gemm_tile != 128:
+        pytest.skip("heuristic path with variant switches: one run on the experiment library is enough")
+    _lib.check(lib.revo_op_set_gemm_tile(0))
+    g = torch.Generator(device=dev).manual_seed(M + K + 1)
+    a = torch.randn(M, K, generator=g, device=dev).bfloat16()
+    b = (torch.randn(N, K, generator=g, device=dev) * 0.05).bfloat16()
+    bias = torch.randn(N, generator=g, device=dev)
+    gamma = torch.rand(N, generator=g, device=dev) + 0.5
+    x0 = torch.randn(M, N, generator=g, device=dev)
+    outs = []
+    try:
+        for flag in (0, 0, 1 << 3):
+            _lib.check(lib.revo_op_set_variant(flag))
+            x = x0.clone()
+            _gemm(lib, EPI_RESID_F32, a, b, x, bias, gamma)
+            outs.append(x)
+    finally:
+        _lib.check(lib.revo_op_set_variant(0))
+    assert torch.equal(outs[0], outs[1])                                   # deterministic
+    tn = (N + 255) // 256
+    tiles = ((M + 255) // 256) * tn
+    same = (tiles // 256 * 256) // tn * 256 if tiles % 256 else M          # rows of the 256-row plan's whole rounds
+    assert same >= 8192
+    assert torch.equal(outs[0][:same], outs[2][:same])
+    assert (outs[0] - outs[2]).abs().max().item() <= 1e-3                  # summation order only
+    T, e = M // 192, (M % 192) // 16
+    first_tall = (T - e) * 192
+    edges = [0, 190, 382, 192 * 64 - 2, same - 3, first_tall - 3, first_tall + 190, first_tall + 205, first_tall + 208 + 205, M - 210]
+    rows = torch.cat([torch.arange(max(x_, 0), min(x_ + 6, M), device=dev) for x_ in edges if x_ < M] + [torch.arange(M - 70, M, device=dev)]).unique()
+    ref = x0[rows] + gamma * (a[rows].float() @ b.float().T + bias)
+    assert (outs[0][rows] - ref).abs().max().item() <= 3e-3 * math.sqrt(K / 64)
+    # every row was written exactly once: against the 256-row plan no row differs by more than summation order, and
+    # the rows outside [0, M) of a padded buffer are untouched
+    xp = torch.full((M + 256, N), 7.0, device=dev)
+    xp[:M] = x0
+    _gemm(lib, EPI_RESID_F32, a, b, xp[:M], bias, gamma)
+    assert torch.equal(xp[:M], outs[0]) and bool((xp[M:] == 7.0).all())
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 4096, 512), (900, 2368, 1024), (640, 3008, 576)])
 def test_gemm_128x64_variant_all_epilogues(lib, dev, gemm_tile, M, N, K):
     """Between 128 and 384 tiles of 128 x 128 (about one per CU) the heuristic takes 128 x 64 tiles so that
