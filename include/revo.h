@@ -190,6 +190,10 @@ int32_t revo_op_set_variant(int32_t flags);
 int32_t revo_op_set_gemm_debug(int32_t flags);
 /* copies bytes of the handle's search workspace to host_dst (host_dst NULL: returns the workspace size) */
 int64_t revo_debug_read_workspace(revo_gallery* g, int64_t offset, int64_t bytes, void* host_dst);
+/* experiment: bounds = device array [Q] of order-preserving u32 scan scores (the format revo_search_candidates publishes)
+ * that the next searches on this handle take as lower limits of their admission bounds (NULL: off).  Stands in for a
+ * bound exchanged between the shards before the scan; the caller guarantees each is <= the query's true ksel-th score. */
+int32_t revo_debug_seed_bounds(revo_gallery* g, const uint32_t* bounds);
 /* counters of the fused scan when debug bit 14 is set */
 int32_t revo_debug_scan_stats(int64_t* out8);
 #endif

@@ -79,6 +79,7 @@ EXPERIMENT_SIGNATURES = {
     "revo_op_set_variant": (_i32, [_i32]),
     "revo_op_set_gemm_debug": (_i32, [_i32]),
     "revo_debug_scan_stats": (_i32, [C.POINTER(C.c_int64)]),
+    "revo_debug_seed_bounds": (_i32, [_p, _p]),
     "revo_debug_read_workspace": (_i64, [_p, _i64, _i64, _p]),
 }
 BASE_SIGNATURES = dict(SIGNATURES)

@@ -619,6 +619,7 @@ struct revo_gallery {
     float* qstat = nullptr; uint32_t* gstat = nullptr;
     char* xbuf = nullptr; revo::ExactWs xw{};
     int mode = 0;
+    const uint32_t* seed_bounds = nullptr;   // experiment build only (revo_debug_seed_bounds): admission bounds from outside
     ~revo_gallery() {
         (void)hipFree(gb); (void)hipFree(gf); (void)hipFree(qf); (void)hipFree(qb); (void)hipFree(part);
         (void)hipFree(tau0);
@@ -714,6 +715,13 @@ extern "C" int32_t revo_gallery_read(revo_gallery* g, int64_t start, int64_t n, 
     API_END
 }
 
+#ifdef REVO_EXPERIMENTS
+// experiment (bound exchange between shards): raise the scan's admission bounds to values handed in
+__global__ void seed_bounds_kernel(uint32_t* tau, const uint32_t* seed, int Q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < Q && seed[i] > tau[i]) tau[i] = seed[i];
+}
+#endif
 // Rows of the pre-pass of the 256 x 256 scan: about one round of GEMM tiles, at most a quarter of the gallery
 static long search_prepass_rows(int Q, long N) {
 #ifdef REVO_EXPERIMENTS
@@ -817,6 +825,9 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
             REVO_HIP_CHECK(hipMemsetAsync(hist, 0, hist_bytes, st));
             CHECK_RC(launch_topk_select_rows(pre_scores, n_pre, (int)n_pre, Q, prelist, ksel, 0, tau_base, ksel, hist, NB,
                                              topk_scan256_hist_shift(), st, tau_live));
+#ifdef REVO_EXPERIMENTS
+            if (g->seed_bounds) hipLaunchKernelGGL(seed_bounds_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, tau_live, g->seed_bounds, Q);
+#endif
         }
         { ProfScope ps("topk_scan", st);
           for (int i = 0; i < nparts; ++i) {
@@ -1096,6 +1107,11 @@ extern "C" int64_t revo_debug_read_workspace(revo_gallery* g, int64_t offset, in
     if (hipDeviceSynchronize() != hipSuccess) return -3;
     if (hipMemcpy(host_dst, (const char*)g->part + offset, (size_t)bytes, hipMemcpyDeviceToHost) != hipSuccess) return -3;
     return bytes;
+}
+extern "C" int32_t revo_debug_seed_bounds(revo_gallery* g, const uint32_t* bounds) {
+    if (!g) return -1;
+    g->seed_bounds = bounds;
+    return 0;
 }
 extern "C" int32_t revo_debug_scan_stats(int64_t* out4) {
     REVO_HIP_CHECK(hipDeviceSynchronize());
