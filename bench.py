@@ -139,7 +139,7 @@ def ingest_leg(variant, n_images, device_index):
                 "stage_s": {k: round(v, 3) for k, v in st.items() if k.endswith("_s")},
                 "note": "JPEG decode on the host's cores + device resize + embed + device-side gallery append + delta-shard flush; "
                         f"{n_images} images are {n_images // 64} batches: the first decode and the last embed overlap with nothing "
-                        "(profiles/r03_ingest.json: 1 950 images/s at 4 000 images)"}
+                        "(profiles/r03_ingest.json: 2 020 images/s at 4 000 images)"}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 

@@ -566,11 +566,24 @@ class SimpleReverso:
                 pending.append(submit(bn * B))
                 submitted[0] += 1
 
+        def detect_batch(pils):
+            """crop mode, as soon as a batch is decoded: detector boxes and region metadata per image (None for a file
+            that failed to decode), so that the batch's crops can be queued on the device before the bookkeeping of the
+            batch in front of it"""
+            det = []
+            for im in pils:
+                if isinstance(im, Exception):
+                    det.append(None)
+                    continue
+                n_reg = self.detect_regions(im, text_prompt)
+                det.append((n_reg, self._region_metadata(im, self.detected_regions)[1] if n_reg else []))
+            return det
+
         def finalize(item):
             """bookkeeping of one embedded batch: metadata per image, then the batch's vectors -- still on the device --
             go straight into the collection being built (device-to-device append; nothing visits the host)"""
             nonlocal failed
-            s, paths, pils, hosts, dev_emb, by_file, last = item
+            s, paths, pils, hosts, dev_emb, by_file, last, det = item
             gi = 0
             batch_items = []                       # (path, pil, metas, row of dev_emb or None)
             for j, (path, im) in enumerate(zip(paths, pils)):
@@ -583,7 +596,7 @@ class SimpleReverso:
                     failed += 1
                     continue
                 row = None
-                if dev_emb is not None:
+                if dev_emb is not None and not crop_mode:
                     row = j if by_file else gi                # staged batches have one row per file, the others one per decoded file
                     gi += 1
                 if use_direct_pe:
@@ -591,13 +604,16 @@ class SimpleReverso:
                               "detection_index": 0, "confidence": 1.0, "detected_class": "full_image"}]
                     log_status(f"✅ Extracted global embedding for {filename}")
                 else:
-                    n_reg = self.detect_regions(im, text_prompt)
+                    if det is not None:
+                        n_reg, metas = det[j]                 # crop mode: detected when the batch was queued
+                    else:
+                        n_reg = self.detect_regions(im, text_prompt)
+                        metas = self._region_metadata(im, self.detected_regions)[1] if n_reg else []
                     if n_reg == 0:
                         log_status(f"⚠️ No regions found in {filename}, skipping")
                         done_files.append(path)
                         failed += 1
                         continue
-                    _, metas = self._region_metadata(im, self.detected_regions)
                     log_status(f"✅ Found {n_reg} regions, extracted {len(metas)} embeddings in {filename}")
                 for m in metas:
                     m["image_source"] = path
@@ -606,15 +622,7 @@ class SimpleReverso:
                     m["region_id"] = _uuid4()
                 batch_items.append((path, im, metas, row, hosts[j]))
             if crop_mode:
-                # region crops of the whole batch: the frames go up from their pinned buffers (asynchronous copies), one
-                # crop + resize launch, forwards of max_batch crops -- nothing here waits for the device; the vectors stay there
-                with torch.cuda.device(self.device):
-                    dev = self._embed_regions_batch([(im, metas) for _, im, metas, _, _ in batch_items], to_host=False,
-                                                    device_frames=upload_frames(slabs[(s // B) % NSLOT],
-                                                                                [h for _, _, _, _, h in batch_items]))
-                    frames_done[(s // B) % NSLOT] = torch.cuda.Event()
-                    frames_done[(s // B) % NSLOT].record()
-                store(batch_items, dev, None, last)
+                store(batch_items, dev_emb, None, last)       # one vector per region, in item order (queued with the batch)
                 return
             store(batch_items, None, dev_emb, last)
 
@@ -669,9 +677,23 @@ class SimpleReverso:
             pils = [r[0] for r in results]
             hosts = [r[1] for r in results]
             good = [r for r in results if not isinstance(r[0], Exception)]
-            # global vectors of the whole batch in one forward (not needed when every region is cropped)
+            # global vectors of the whole batch in one forward -- or, when every region is cropped, the regions' vectors
             dev_emb = None
-            if good and not crop_mode:
+            det = None
+            if crop_mode:
+                # region crops of the whole batch: boxes from the detector, the frames go up from their pinned slab (one
+                # asynchronous copy), one crop + resize launch, forwards of max_batch crops -- queued NOW, so that the
+                # device holds this batch while the thread does the bookkeeping of the one before; the vectors stay there
+                det = detect_batch(pils)
+                with_regions = [j for j, d in enumerate(det) if d is not None and d[1]]
+                if with_regions:
+                    with torch.cuda.device(self.device):
+                        dev_emb = self._embed_regions_batch([(pils[j], det[j][1]) for j in with_regions], to_host=False,
+                                                            device_frames=upload_frames(slabs[it % NSLOT],
+                                                                                        [hosts[j] for j in with_regions]))
+                        frames_done[it % NSLOT] = torch.cuda.Event()
+                        frames_done[it % NSLOT].record()
+            elif good:
                 if pipelined:
                     # every file of the batch has its row in the staging buffer (a failed file's row keeps whatever it
                     # held: embedded and never looked at)
@@ -689,7 +711,7 @@ class SimpleReverso:
                         frames_done[it % NSLOT].record()
                         dev_emb = self.pe_model.embed(pp.crop_resize_device(frames, None, model_size))
             stats["launch_s"] += time.perf_counter() - t_l
-            cur = (s, paths, pils, hosts, dev_emb, pipelined, s + B >= len(image_files))
+            cur = (s, paths, pils, hosts, dev_emb, pipelined, s + B >= len(image_files), det)
             if inflight is not None:
                 t_b = time.perf_counter()
                 finalize(inflight)
