@@ -729,9 +729,11 @@ static long search_prepass_rows(int Q, long N) {
     //  3.50 ms per search of a 125 k-row shard: 8192 it is)
     if (const char* e = getenv("REVO_NPRE")) { const long v = atol(e) / 256 * 256; if (v >= 1024 && v <= N / 4) return v; }
 #endif
+    // (few queries, 1 M rows, whole search in ms at 1 / 64 queries: 8192 rows 0.557 / 0.600, 16 384 0.555 / 0.596, 32 768
+    //  0.529 / 0.566, 65 536 0.564 / 0.596: a weaker seed costs the HBM-rate scan more survivors than the rows save)
     const long qtiles = (Q + 255) / 256;
     long n_pre = (65536 / qtiles) / 256 * 256;
-    n_pre = n_pre > 65536 ? 65536 : (n_pre < 8192 ? 8192 : n_pre);
+    n_pre = n_pre > 32768 ? 32768 : (n_pre < 8192 ? 8192 : n_pre);
     if (n_pre > N / 4) n_pre = (N / 4) / 256 * 256;
     const long cap_pre = ((512l << 20) / (4l * Q)) / 256 * 256;
     if (n_pre > cap_pre) n_pre = cap_pre;
@@ -789,7 +791,7 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
         // ---- 256 x 256 scan.  Pre-pass: a plain GEMM of the queries against the first n_pre rows and a
         // per-row selection seed the admission scores; the fused scan covers rows [n_pre, N).
         // Pre-pass size: about one round of 256 x 256 GEMM tiles; with few queries (short gallery slices
-        // per CU) up to 64 k rows, which seed the 0.05 % quantile.
+        // per CU) up to 32 k rows, which seed the 0.1 % quantile.
         const long n_pre = search_prepass_rows(Q, N);
         // the scan runs as one launch, or as a main launch of whole query tiles plus one for a ragged tail of queries
         const int q_main = topk_scan256_main_queries(Q, N - n_pre);

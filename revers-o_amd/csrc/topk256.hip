@@ -351,7 +351,7 @@ struct Scan256Args {
     unsigned long long* stats;    // optional counters (REVO_EXPERIMENTS): [0] drains, [1] queued entries, [2] retry passes, [3] fragments scanned slowly, [4] appended entries, [5] refreshes
 };
 
-// ROWS: 0 = all 256 query rows of a tile may be valid; 64 / 128 = the whole search has at most that many
+// ROWS: 0 = all 256 query rows of a tile may be valid; 64 / 128 / 192 = the whole search has at most that many
 // queries (one query tile), and the main loop skips the MFMA work of the rows that cannot be valid.
 template <int KSEL, int ROWS>
 __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Args p) {
@@ -730,14 +730,16 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
         REVO_FUNC_LDS((topk_scan256_kernel<KS, RW>), S256_LDS);                                                  \
         hipLaunchKernelGGL((topk_scan256_kernel<KS, RW>), grid, block, S256_LDS, st, a);                       \
     } while (0)
-    const int rows_mode = Q <= 64 ? 64 : (Q <= 128 ? 128 : 0);
+    const int rows_mode = Q <= 64 ? 64 : (Q <= 128 ? 128 : (Q <= 192 ? 192 : 0));
     if (ksel == 32) {
         if (rows_mode == 64) S256_LAUNCH(32, 64);
         else if (rows_mode == 128) S256_LAUNCH(32, 128);
+        else if (rows_mode == 192) S256_LAUNCH(32, 192);
         else S256_LAUNCH(32, 0);
     } else {
         if (rows_mode == 64) S256_LAUNCH(64, 64);
         else if (rows_mode == 128) S256_LAUNCH(64, 128);
+        else if (rows_mode == 192) S256_LAUNCH(64, 192);
         else S256_LAUNCH(64, 0);
     }
 #undef S256_LAUNCH

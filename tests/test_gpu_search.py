@@ -163,7 +163,7 @@ def test_all_rows_identical_ties_terminate(dev):
     G.close()
 
 
-@pytest.mark.parametrize("N,Q", [(16384, 1), (16385, 257), (70001, 64), (250000, 513)])
+@pytest.mark.parametrize("N,Q", [(16384, 1), (16385, 257), (70001, 64), (250000, 513), (60000, 129), (90001, 192), (50000, 100)])
 def test_large_scan_path_vs_oracle(dev, N, Q):
     D, k = 128, 10
     rng = np.random.default_rng(N + Q)
@@ -303,7 +303,7 @@ def test_properties_at_full_gallery_1m(dev):
 def test_large_scan_path_wide_k(dev, k):
     """limit 20 and 50 (the reference UI's other choices, ui.py:342) keep 64 candidates per query: the
     256 x 256 scan's 64-entry lists (128-element merges with de-duplication in the drains)."""
-    for (N, Q, D) in [(70001, 64, 128), (120000, 300, 64)]:
+    for (N, Q, D) in [(70001, 64, 128), (120000, 300, 64), (40000, 180, 64)]:       # 64-, 256- and 192-row forms of the scan
         rng = np.random.default_rng(N + Q + k)
         gal = rng.standard_normal((N, D), dtype=np.float32)
         gal[N // 3: N // 3 + 90] = gal[N // 3]             # a tie group longer than the 64-entry list
@@ -565,13 +565,13 @@ def test_config4_gallery_10m_x_1536(dev):
         pytest.skip("needs ~110 GB of free HBM")
     g = torch.Generator(device=dev).manual_seed(404)
     q = torch.randn(Q, D, generator=g, device=dev)
-    plant_rows = [0, 1, 65535, 65536, 65537, N // 2, N - 2, N - 1]
+    plant_rows = [0, 1, 32767, 32768, 32769, 65535, 65536, 65537, N // 2, N - 2, N - 1]
     G = engine.Gallery(D, N, device=0)
     chunk = 500_000
     for s0 in range(0, N, chunk):
         G.add(torch.randn(chunk, D, generator=g, device=dev))
     # the gallery is append-only: instead of planting copies of the queries, the first queries are made near-copies of
-    # gallery rows at the interesting positions (first / last rows, both sides of the 65 536-row pre-pass boundary)
+    # gallery rows at the interesting positions (first / last rows, both sides of the pre-pass boundary)
     ids = torch.tensor(plant_rows, device=dev)
     qrows = torch.cat([G.read(int(r), 1) for r in plant_rows])   # the normalised fp32 rows themselves
     q[: len(plant_rows)] = qrows + 0.01 * torch.randn(len(plant_rows), D, generator=g, device=dev)
