@@ -326,7 +326,7 @@ def test_gemm_splitk_tail_residual(lib, dev, gemm_tile, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(36928, 1024, 1024), (36928, 1024, 4096), (36864, 1024, 1024), (12288 + 32, 4096, 512),
-                                   (49152 + 128, 1536, 1536)])
+                                   (49152 + 128, 1536, 1536), (12288 + 16, 4096, 128), (12288 + 48, 4096, 192)])
 def test_gemm_192_row_tiles_residual(lib, dev, gemm_tile, M, N, K):
     """Residual GEMMs whose rows make whole rounds of 192-row tiles but not of 256-row ones (PE-L14 at batch 64: 192 tile
     rows x 4 = three rounds; the 64 rows left over make the last four tile rows 208 rows tall): same bits as the 256-row
