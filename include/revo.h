@@ -110,10 +110,12 @@ int32_t revo_search_topk(revo_gallery* g, const float* queries, int32_t n_querie
  * scale-out of that call.  Per rank:
  *   1. revo_search_candidates: scan the shard (same kernels as revo_search_topk); the query's candidates stay in the
  *      handle, and bounds [n_queries, top_m] receives the scan scores of the best top_m of them as order-preserving
- *      uint32 (0 = none).  top_m <= revo_search_ksel(k); parts * top_m >= revo_search_ksel(k) makes the bound below tight.
+ *      uint32 (0 = none).  top_m <= revo_search_ksel(k); parts * top_m >= min(64, 2 * revo_search_ksel(k)) makes the bound below tight.
  *   2. all-gather `bounds` over the ranks -> all_bounds [parts, n_queries, top_m]   (RCCL; 4 * top_m bytes per query and rank)
- *   3. revo_search_finish: only candidates that can still be among the best revo_search_ksel(k) of the WHOLE gallery
- *      (scan score at or above the ksel-th largest published score) are re-scored in fp32; results as revo_search_topk.
+ *   3. revo_search_finish: only candidates that can still be among the best j = min(64, 2 * revo_search_ksel(k)) of the
+ *      WHOLE gallery (scan score at or above the j-th largest published score) are re-scored in fp32; results as
+ *      revo_search_topk.  (Twice the unsharded search's candidates: with that margin the exactness certificate of the
+ *      merge all but never fails on ordinary data, which saves the protocol's second round.)
  *      all_bounds may be NULL (re-score every candidate).  Same queries, k and stream as step 1.
  *   4. all-gather the per-rank results and revo_topk_merge / revo_topk_merge_packed them.
  * The merged result equals the unsharded revo_search_topk of the concatenated gallery. */

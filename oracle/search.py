@@ -217,8 +217,9 @@ class OracleShardBackend:
             bound = np.uint32(0)
             if all_bounds is not None:
                 pub = np.sort(all_bounds[:, r, :].numpy().view(np.uint32).reshape(-1))[::-1]
-                if pub.shape[0] >= ksel:
-                    bound = pub[ksel - 1]
+                brank = min(64, 2 * ksel)                      # the rule of topk_finish_kernel (revers-o_amd/csrc/topk.hip)
+                if pub.shape[0] >= brank:
+                    bound = pub[brank - 1]
             nc = int(c[r])
             keep = [j for j in range(nc) if f32_orderable(s[r, j]) >= bound]
             # certificate bound: the first candidate the shard bound dropped, else the worst kept one of a full list

@@ -8,10 +8,11 @@ scale-out of that call.  A search of Q queries (identical on every rank) for the
      search) and keeps its best ``ksel`` candidates per query; it publishes the scan scores of the best
      ``top_m`` of them                                                        [Q, top_m] int32
   2. all-gather #1 of those scores (4 * top_m bytes per query and rank)        [P, Q, top_m]
-     -> the ksel-th largest is a lower bound of the ksel-th best scan score over the whole gallery
-  3. every rank re-scores in fp32 only its candidates at or above that bound (about ksel / P per query
+     -> the j-th largest, j = min(64, 2 ksel), is a lower bound of the j-th best scan score over the whole gallery
+  3. every rank re-scores in fp32 only its candidates at or above that bound (about j / P per query
      instead of ksel: the fp32 row gathers, the part of a search that does not shrink with the shard,
-     shrink with it) and takes its local top k with global row ids
+     shrink with it; j is twice what the unsharded search re-scores, so that the certificate of step 5
+     all but never fails and step 6 stays the exception) and takes its local top k with global row ids
   4. all-gather #2 of the packed per-rank results (12 * k bytes per query and rank, one buffer)
   5. the same merge on every rank (score descending, global row id ascending), which also checks every query's
      exactness certificate over all shards (include/revo.h, "EXACTNESS": each shard ships, next to its results, the
@@ -149,11 +150,12 @@ class ShardedSearch:
         return out
 
     def top_m(self, k):
-        """Scores published per query and rank: world * top_m >= ksel makes the bound the exact global ksel-th
-        best whenever no shard holds more than top_m of the global best ksel; at least 8 so that an uneven
-        spread of the best rows over the shards rarely loosens it."""
+        """Scores published per query and rank.  The finish step re-scores what reaches the min(64, 2 ksel)-th largest
+        of all published scores: world * top_m >= that many makes it the exact global order statistic whenever no
+        shard holds more than top_m of those rows; at least 8 so that an uneven spread of the best rows over the
+        shards rarely loosens it."""
         ksel = self.backend.ksel(k)
-        return min(ksel, max(8, -(-ksel // self.world)))
+        return min(ksel, max(8, -(-min(64, 2 * ksel) // self.world)))
 
     def search(self, queries, k, threshold=None):
         """queries: identical [Q, D] on every rank.  Returns the global top-k triple on every rank."""
@@ -206,7 +208,7 @@ class LocalShards:
     def search(self, queries, k, threshold=None):
         P, Q = len(self.backends), queries.shape[0]
         ksel = self.backends[0].ksel(k)
-        top_m = min(ksel, max(8, -(-ksel // P)))
+        top_m = min(ksel, max(8, -(-min(64, 2 * ksel) // P)))
         allb = torch.stack([b.candidates(queries, k, top_m) for b in self.backends])            # [P, Q, top_m]
         allp = torch.cat([b.finish(Q, k, allb, off) for b, off in zip(self.backends, self.offsets)])
         scores, idx, counts, unc = self.backends[0].merge(allp, P, Q, k, threshold, certify=True)

@@ -26,7 +26,7 @@ for p in range(P):
     shards.append(Gp)
 q = torch.randn(Q, D, generator=g, device=dev)
 ksel = engine.search_ksel(k)
-top_m = min(ksel, max(8, -(-ksel // P)))
+top_m = min(ksel, max(8, -(-min(64, 2 * ksel) // P)))
 n_pre = shards[0].search_plan(Q, k)["prepass_rows"]
 
 def union_bound(rows):

@@ -23,7 +23,7 @@ for p in range(P):
     shards.append(Gp)
 q = torch.randn(Q, D, generator=g, device=dev)
 ksel = engine.search_ksel(k)
-top_m = min(ksel, max(8, -(-ksel // P)))
+top_m = min(ksel, max(8, -(-min(64, 2 * ksel) // P)))
 pb = engine.packed_bytes(Q, k)
 
 def timed(fn, reps=5):

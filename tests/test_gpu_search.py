@@ -283,14 +283,13 @@ def test_properties_at_full_gallery_1m(dev):
     # (each shard's candidates stay in its handle between the two phases)
     pb = engine.packed_bytes(big.shape[0], k)
     packed = torch.empty((8 * pb,), dtype=torch.uint8, device=dev)
-    kept = 0
     for p, Gp in enumerate(shards):
-        _, pi, _ = Gp.search_finish(big.shape[0], k, allb, None, p * 125_000, out_packed=packed[p * pb:(p + 1) * pb])
-        kept += int((pi >= 0).sum())
-    ts, ti, tc = engine.merge_topk_packed(packed, 8, big.shape[0], k)
+        Gp.search_finish(big.shape[0], k, allb, None, p * 125_000, out_packed=packed[p * pb:(p + 1) * pb])
+    ts, ti, tc, unc = engine.merge_topk_packed(packed, 8, big.shape[0], k, certify=True)
     assert torch.equal(ti, bi) and torch.equal(ts, bs) and torch.equal(tc, bc)
-    # the bound did its job: far fewer than 8 x k results per query survive the cut (about ksel = 32 per query in all)
-    assert kept <= big.shape[0] * 40, kept
+    # the shards together re-score what reaches the 64th-best published score (2 x ksel): with that margin the
+    # cross-shard certificate holds for (nearly) every query of a random gallery -- no second round
+    assert int(unc[0].item()) <= 2
     for Gp in shards:
         Gp.close()
     # a large query batch takes the MFMA-bound regime of the same scan: same answers on the shared queries
@@ -636,7 +635,7 @@ def test_sharded_two_phase_with_certificate_equals_unsharded(dev):
         ref = G.search(qd, k, thr)
         assert G.search_stats()["uncertified"] >= Q // 2
         out = ls.search(qd, k, thr)
-        assert ls.last_uncertified >= Q // 2 and ls.last_uncertified < Q
+        assert Q // 4 <= ls.last_uncertified < Q          # (the shards together re-score 64 rows per query: a few clusters certify)
         for a, b in zip(out, ref):
             assert torch.equal(a, b)
     _check(ref if thr is None else G.search(qd, k, None), osearch.search(gal, qr, k), atol=1e-5, near_tie=3e-7)

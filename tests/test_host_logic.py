@@ -163,7 +163,7 @@ def _shard_worker(rank, world, port, tmp, N, D, Q, k, noise=0.0):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("noise", [0.0, 0.07])
+@pytest.mark.parametrize("noise", [0.0, 0.1])
 def test_sharded_search_protocol_gloo(tmp_path, noise):
     """World-size-2 run of the sharded search's protocol (offsets, both all-gathers, the merge, the certificate check
     and -- with a noisy scan -- the second, exact round) on CPU: the result must be the exhaustive search's."""
