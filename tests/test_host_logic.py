@@ -125,6 +125,33 @@ def test_preprocess_matches_reference_transform():
     assert pp.batch_u8([arr, arr], 28).shape == (2, 3, 28, 28)
 
 
+def test_preprocess_accepts_what_the_reference_accepts(tmp_path):
+    from PIL import Image
+    """core_system.py:435-439: an ndarray goes through Image.fromarray, a path through Image.open, anything else is taken
+    as a PIL image, and every one is converted to RGB before the 336-px squash: grey, RGBA, palette and CMYK inputs end
+    up as the same uint8 tensor the reference's transform would see."""
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    grey = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (37, 53, 1), dtype=np.uint8)], -1)
+    pal = Image.fromarray(rgb).convert("P", palette=Image.ADAPTIVE, colors=16)
+    pal_path = os.path.join(str(tmp_path), "pal.png")
+    pal.save(pal_path)
+    cmyk_path = os.path.join(str(tmp_path), "cmyk.jpg")
+    Image.fromarray(rgb).convert("CMYK").save(cmyk_path, quality=95)
+
+    def want(pil):
+        return np.asarray(pil.convert("RGB").resize((28, 28), Image.BILINEAR)).transpose(2, 0, 1)
+
+    cases = [(grey, Image.fromarray(grey)), (rgba, Image.fromarray(rgba)), (pal_path, Image.open(pal_path)),
+             (cmyk_path, Image.open(cmyk_path)), (Image.fromarray(rgb), Image.fromarray(rgb)), (pal, pal)]
+    for given, ref in cases:
+        got = pp.resize_u8(given, 28)
+        assert got.dtype == torch.uint8 and tuple(got.shape) == (3, 28, 28)
+        assert np.array_equal(got.numpy(), want(ref))
+    assert pp.to_pil(grey).mode == "RGB" and pp.to_pil(pal_path).size == (53, 37)
+
+
 # --------------------------------------------------------------- gloo, world 2 ---
 def _shard_worker(rank, world, port, tmp, N, D, Q, k, noise=0.0):
     import torch.distributed as dist
