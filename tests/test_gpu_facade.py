@@ -185,14 +185,21 @@ def test_pipelined_ingest_equals_one_batch(tmp_path, dev):
     stores, in the same order, in every mode -- a broken file in the middle included."""
     from reverso_amd.core_system import Regions
     folder = str(tmp_path / "images")
-    _make_jpegs(folder, n=21, seed=9)
+    paths = _make_jpegs(folder, n=21, seed=9)
     (tmp_path / "images" / "img_010a_broken.jpg").write_bytes(b"not a jpeg")
+    # four of the files in other modes (core_system.py:439 converts whatever it opens to RGB): grey, RGBA and palette PNGs,
+    # a CMYK JPEG -- same names, so that the order of the collection does not change
+    for j, mode in ((2, "L"), (5, "RGBA"), (8, "P"), (13, "CMYK")):
+        im = Image.open(paths[j]).convert(mode)
+        os.remove(paths[j])
+        im.save(paths[j][:-4] + (".jpg" if mode == "CMYK" else ".png"))
 
     def detector(pil, prompt):
         w, h = pil.size
         return Regions([[0, 0, w // 2, h // 2], [w // 4, h // 4, w - 1, h - 1], [w // 3, 0, w - 1, h // 2]],
                        confidence=[0.9, 0.8, 0.7], class_id=[0, 1, 0], class_names=["person", "car"])
 
+    direct_runs = []
     for kw, direct in (({}, True), ({"device_resize": True}, True), ({"detector": detector, "region_mode": "crop"}, False),
                        ({"detector": detector}, False)):
         got = []
@@ -205,6 +212,10 @@ def test_pipelined_ingest_equals_one_batch(tmp_path, dev):
         assert got[0][1] == got[1][1]
         assert len(got[0][1]) == (21 if direct else 63)
         assert torch.equal(got[0][0], got[1][0])
+        if direct:
+            direct_runs.append(got[0])
+    # host resize and device resize store the same vectors, the odd image modes included
+    assert direct_runs[0][1] == direct_runs[1][1] and torch.equal(direct_runs[0][0], direct_runs[1][0])
 
 
 def test_device_resize_ingest_equals_host_resize(system):
