@@ -1,0 +1,56 @@
+"""CPU: bench.py's own launcher.  `python bench.py --gpus N` (N > 1) without torch.distributed.run around it must start
+the N rank processes as CHILDREN, before torch or the HIP library is imported in the parent (a process that has touched
+the GPU must never exec or fork GPU work on this pool), hand them the same arguments, and exit with their status."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run_parent(tmp_path, argv, extra_env=None):
+    """Run bench.py as __main__ with subprocess.Popen replaced by a recorder (sitecustomize in a scratch directory)."""
+    (tmp_path / "sitecustomize.py").write_text(textwrap.dedent("""
+        import json, os, subprocess, sys
+        class _P:
+            def __init__(self, cmd, **kw):
+                mods = [m for m in ("torch", "reverso_amd", "ctypes") if m in sys.modules]
+                with open(os.environ["REC"], "w") as f:
+                    json.dump({"cmd": cmd, "env": {k: kw.get("env", {}).get(k) for k in
+                               ("HSA_ENABLE_IPC_MODE_LEGACY", "WORLD_SIZE")}, "loaded": mods}, f)
+            def wait(self):
+                return 7
+        subprocess.Popen = _P
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PYTHONPATH"] = str(tmp_path)
+    env["REC"] = str(tmp_path / "rec.json")
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, BENCH] + argv, env=env, capture_output=True, text=True, timeout=300), tmp_path / "rec.json"
+
+
+def test_parent_starts_rank_processes_before_touching_torch(tmp_path):
+    import json
+    p, rec = _run_parent(tmp_path, ["--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert p.returncode == 7, p.stderr[-2000:]                      # the children's status is the parent's
+    r = json.loads(rec.read_text())
+    cmd = r["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(BENCH)
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert r["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and r["env"]["WORLD_SIZE"] is None
+    assert r["loaded"] == [], r["loaded"]                           # neither torch nor the HIP library in the parent
+
+
+def test_gpus_equals_form_and_launcher_environment(tmp_path):
+    import json
+    p, rec = _run_parent(tmp_path, ["--gpus=2"])
+    assert p.returncode == 7 and json.loads(rec.read_text())["cmd"][-1] == "--gpus=2"
+    # under a launcher (WORLD_SIZE set) the parent starts nothing: it IS a rank
+    rec.unlink()
+    p, rec = _run_parent(tmp_path, ["--gpus", "2", "--help"], {"WORLD_SIZE": "2", "RANK": "0"})
+    assert not rec.exists() and p.returncode == 0 and "--gpus" in p.stdout

@@ -59,3 +59,19 @@ def test_bench_contract_two_ranks_on_one_gpu(dev):
     sq = d["search_query_batch"]
     assert sq["one_gpu_ms_same_process"] > 0 and sq["speedup_vs_1gpu_model"] > 0      # rank 0's 1-GPU run of the same search
     assert "cpu_baseline" not in d and "ingest" not in d                                 # N = 1 only
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher(dev):
+    """`python bench.py --gpus 2 ...` with no torch.distributed.run around it (the way the driver starts N = 1): the
+    parent starts the two rank processes itself before anything touches the device, relays rank 0's line and its status."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-gpu", "--backend", "gloo"] + SMALL
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _json_line(p.stdout)
+    _check_contract(d, 2)
+    sq = d["search_query_batch"]
+    assert len(sq["sharded_ms_per_rank"]) == 2 and max(sq["sharded_ms_per_rank"]) == pytest.approx(sq["sharded_ms"], rel=1e-3)
+    assert sq["one_gpu_ms_same_process"] > 0 and sq["speedup_vs_1gpu_model"] > 0
+    c = d["collective"]
+    assert c["ranks"] == 2 and c["backend"] == "gloo" and c["rccl_ranks"] == 0 and c["devices"] == [0, 0] and c["one_gpu_rehearsal"]
