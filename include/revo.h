@@ -65,14 +65,6 @@ int32_t revo_vit_destroy(revo_vit* vit);
  * the device; normalize != 0 applies embedding / embedding.norm() (core_system.py:447). */
 int32_t revo_vit_forward(revo_vit* vit, const void* images, int32_t image_dtype, int32_t batch, float* out,
                          int32_t normalize, void* stream);
-/* parity-test hooks: run only the first n transformer blocks (n = -1: the whole forward; n = -2: stop after the
- * patch embedding, before ln_pre) and copy the fp32 residual stream [batch*seq, width] of the last forward to dst (device). */
-int32_t revo_vit_set_debug_layers(revo_vit* vit, int32_t n_layers);
-int32_t revo_vit_read_residual(revo_vit* vit, int32_t batch, float* dst, void* stream);
-/* other intermediate buffers of the last forward (device to device): which = 0 the residual stream (fp32 [batch*seq, width]),
- * 1 the ln_post output after a whole forward (fp32 [batch*seq, width]: the head works in fp32), 2 the attention-pool
- * output after its MLP residual, before proj (fp32 [batch, width]) */
-int32_t revo_vit_read_tap(revo_vit* vit, int32_t which, int32_t batch, void* dst, void* stream);
 int32_t revo_vit_seq_len(const revo_vit* vit);
 
 /* ---- gallery: replaces recreate_collection(size=D, COSINE) + upsert (core_system.py:600-622) */
@@ -141,10 +133,6 @@ int32_t revo_search_finish(revo_gallery* g, int32_t n_queries, int32_t k, int32_
 int32_t revo_search_exact(revo_gallery* g, int32_t n, const int32_t* q_idx, const float* need, int32_t k,
                           int32_t has_threshold, float threshold, int64_t index_offset, float* scores, int64_t* indices,
                           int32_t* counts, void* stream);
-/* how the certificate treats the handle's searches: 0 = certificate + fallback (default), 1 = every query takes the
- * collecting pass, 2 = every query takes the brute-force pass (1 and 2: parity tests of the fallback against the fast
- * path), 3 = certificate evaluated and counted but no fallback (what the search did before it had one; timing only) */
-int32_t revo_search_set_mode(revo_gallery* g, int32_t mode);
 /* counters of the handle's last search, read after `stream` has drained (host array): out4 = { queries the certificate
  * failed for (-1: the gallery has no fp32 rows), of those: brute-forced, queries the certificate was evaluated for,
  * rows the collecting passes re-scored } */
@@ -178,6 +166,20 @@ int32_t revo_op_gemm_rope(const void* a_bf16, int64_t lda, const void* b_bf16, i
  * with -DREVO_EXPERIMENTS; used by scripts/ and by the forced-tile runs of tests/test_gpu_kernels.py), never into
  * librevo.so, whose kernels are chosen by its size heuristics alone.  Process-global, not thread-safe.
  * Every variant computes the same result (split-K changes the fp32 summation order only). */
+/* Parity-test hooks (tests/ load librevo_exp.so for them; the product library has no way to stop a forward early, to
+ * read intermediate buffers, or to switch the exactness machinery of a search off):
+ * run only the first n transformer blocks (n = -1: the whole forward; n = -2: stop after the patch embedding, before
+ * ln_pre) and copy the fp32 residual stream [batch*seq, width] of the last forward to dst (device). */
+int32_t revo_vit_set_debug_layers(revo_vit* vit, int32_t n_layers);
+int32_t revo_vit_read_residual(revo_vit* vit, int32_t batch, float* dst, void* stream);
+/* other intermediate buffers of the last forward (device to device): which = 0 the residual stream (fp32 [batch*seq, width]),
+ * 1 the ln_post output after a whole forward (fp32 [batch*seq, width]: the head works in fp32), 2 the attention-pool
+ * output after its MLP residual, before proj (fp32 [batch, width]) */
+int32_t revo_vit_read_tap(revo_vit* vit, int32_t which, int32_t batch, void* dst, void* stream);
+/* how the certificate treats the handle's searches: 0 = certificate + fallback (the product library's only behaviour),
+ * 1 = every query takes the collecting pass, 2 = every query takes the brute-force pass (1 and 2: parity tests of the
+ * fallback against the fast path), 3 = certificate evaluated and counted but no fallback (timing only: NOT exact) */
+int32_t revo_search_set_mode(revo_gallery* g, int32_t mode);
 /* 0 = size heuristic (default), 128 or 256 = force that GEMM tile */
 int32_t revo_op_set_gemm_tile(int32_t tile);
 /* bits 4-7 = force the XCD arrangement (N-stripes 1, 2, 4 or 8; 0 = heuristic), bits 8-11 = force the attention

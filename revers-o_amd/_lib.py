@@ -40,9 +40,6 @@ SIGNATURES = {
     "revo_vit_create": (_i32, [C.POINTER(VitCfg), C.POINTER(Tensor), _i32, _i32, _i32, C.POINTER(_p)]),
     "revo_vit_destroy": (_i32, [_p]),
     "revo_vit_forward": (_i32, [_p, _p, _i32, _i32, _p, _i32, _p]),
-    "revo_vit_set_debug_layers": (_i32, [_p, _i32]),
-    "revo_vit_read_residual": (_i32, [_p, _i32, _p, _p]),
-    "revo_vit_read_tap": (_i32, [_p, _i32, _i32, _p, _p]),
     "revo_vit_seq_len": (_i32, [_p]),
     "revo_gallery_create": (_i32, [_i32, _i64, _i32, _i32, C.POINTER(_p)]),
     "revo_gallery_destroy": (_i32, [_p]),
@@ -56,7 +53,6 @@ SIGNATURES = {
     "revo_search_candidates": (_i32, [_p, _p, _i32, _i32, _i32, _p, _p]),
     "revo_search_finish": (_i32, [_p, _i32, _i32, _i32, _f32, _i64, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     "revo_search_exact": (_i32, [_p, _i32, _p, _p, _i32, _i32, _f32, _i64, _p, _p, _p, _p]),
-    "revo_search_set_mode": (_i32, [_p, _i32]),
     "revo_search_stats": (_i32, [_p, C.POINTER(C.c_int32), _p]),
     "revo_topk_merge": (_i32, [_p, _p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p]),
     "revo_topk_packed_bytes": (_i64, [_i32, _i32]),
@@ -75,6 +71,10 @@ SIGNATURES = {
 
 # only in librevo_exp.so (built by `make exp` with -DREVO_EXPERIMENTS; timing scripts under scripts/)
 EXPERIMENT_SIGNATURES = {
+    "revo_vit_set_debug_layers": (_i32, [_p, _i32]),
+    "revo_vit_read_residual": (_i32, [_p, _i32, _p, _p]),
+    "revo_vit_read_tap": (_i32, [_p, _i32, _i32, _p, _p]),
+    "revo_search_set_mode": (_i32, [_p, _i32]),
     "revo_op_set_gemm_tile": (_i32, [_i32]),
     "revo_op_set_variant": (_i32, [_i32]),
     "revo_op_set_gemm_debug": (_i32, [_i32]),
@@ -92,6 +92,11 @@ if os.environ.get("REVO_EXPERIMENTS") == "1":
 
 _lib = None
 _lib_exp = None
+
+
+def product_is_experiment_build():
+    """True when load() itself returns an experiment build (REVO_EXPERIMENTS=1: scripts/)."""
+    return os.environ.get("REVO_EXPERIMENTS") == "1"
 
 
 def load_exp():

@@ -175,27 +175,46 @@ class SimpleReverso:
         return dev
 
     def load_pe_model(self, target_model=DEFAULT_VARIANT, checkpoint=None, synthetic_seed=0):
-        """core_system.py:169-203: target model first, else the first available config."""
+        """core_system.py:169-203: the target model first; if it is not among the available configs, or if loading it
+        FAILS (:183-191 -- here: a checkpoint that does not fit the architecture, by missing, unexpected or mis-shaped
+        tensor, or an engine that cannot be created), the first available config -- whose own failure propagates, as the
+        reference's second ``from_config`` would."""
         print(f"📚 Loading {target_model}...")
         configs = available_configs()
         print(f"Available PE configs: {configs}")
-        try:
-            cfg = get_config(target_model)
-        except KeyError:
-            cfg = get_config(configs[0])
-            print(f"🔄 Using available: {configs[0]}")
         checkpoint = checkpoint or os.environ.get("REVERSO_PE_CHECKPOINT")
-        if checkpoint:
-            sd = load_state_dict(checkpoint)
-            print(f"✅ Loaded {cfg.name} weights from {checkpoint}")
-        else:
+        sd = load_state_dict(checkpoint) if checkpoint else None
+        if sd is None:
             # no network here: pretrained weights (pe.CLIP.from_config(..., pretrained=True), :181)
             # must be supplied as a file; without one the tower is random-initialised.
             print("⚠️ No checkpoint given (REVERSO_PE_CHECKPOINT): using seeded random-init weights")
-            sd = synth_weights(cfg, seed=synthetic_seed, device=self.device)
-        engine = VitEngine(cfg, sd, device=self.device.index or 0, max_batch=self.max_batch)
-        size = cfg.image_size
-        print("⚡ bf16 MFMA matmuls, fp32 residual stream")
+
+        def build(name):
+            cfg = get_config(name)
+            w = sd if sd is not None else synth_weights(cfg, seed=synthetic_seed, device=self.device)
+            # LayerScale follows the checkpoint's ls_* tensors; any other unexpected `visual.*` tensor is an error (weights.py)
+            return VitEngine(cfg, w, device=self.device.index or 0, max_batch=self.max_batch)
+
+        known = target_model in configs
+        if not known:
+            try:
+                get_config(target_model)            # the build's own test miniatures are not "available configs"
+                known = True
+            except KeyError:
+                pass
+        if known:
+            try:
+                engine = build(target_model)
+                print(f"✅ Loaded {target_model}" + (f" weights from {checkpoint}" if checkpoint else ""))
+            except Exception as e:
+                print(f"❌ Failed to load {target_model}: {e}")
+                engine = build(configs[0])
+                print(f"🔄 Using fallback: {configs[0]}")
+        else:
+            engine = build(configs[0])
+            print(f"🔄 Using available: {configs[0]}")
+        size = engine.cfg.image_size
+        print("⚡ bf16 MFMA matmuls, fp32 residual stream" + (", LayerScale from the checkpoint" if engine.cfg.use_ls else ""))
         return engine, (lambda image: pp.resize_u8(image, size))
 
     # ------------------------------------------------------------- detection --

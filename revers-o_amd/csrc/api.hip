@@ -294,6 +294,17 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
         }
         for (auto& kv : need)
             if (!wm.get(kv.first, kv.second)) return -2;
+        // ... and nothing else: a tensor the forward would not read (LayerScale gains handed to a handle created with
+        // use_ls = 0, a tensor of another architecture) means a different model, not one to run without it
+        if (wm.m.size() != need.size()) {
+            std::map<std::string, int64_t> want(need.begin(), need.end());
+            for (auto& kv : wm.m)
+                if (!want.count(kv.first)) {
+                    revo_set_error("unexpected weight tensor: " + kv.first + " (not read by this architecture" +
+                                   (c.use_ls ? ")" : "; LayerScale needs cfg.use_ls = 1)"));
+                    return -2;
+                }
+        }
     }
     REVO_ON_DEVICE(device);
 
@@ -426,6 +437,7 @@ extern "C" int32_t revo_vit_destroy(revo_vit* vit) {
     API_END
 }
 extern "C" int32_t revo_vit_seq_len(const revo_vit* vit) { return vit ? vit->S : -1; }
+#ifdef REVO_EXPERIMENTS   // parity-test hooks: librevo_exp.so only (include/revo.h)
 extern "C" int32_t revo_vit_set_debug_layers(revo_vit* vit, int32_t n) {
     REVO_REQUIRE(vit, "null handle");
     vit->debug_layers = n;
@@ -454,6 +466,7 @@ extern "C" int32_t revo_vit_read_tap(revo_vit* vit, int32_t which, int32_t batch
     REVO_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
+#endif
 
 namespace {
 // ln (optional, residual epilogue): the LayerNorm that follows; *ln_fused = 1 if the GEMM's launch form did it (kernels.h)
@@ -992,11 +1005,13 @@ extern "C" int32_t revo_search_exact(revo_gallery* g, int32_t n, const int32_t* 
     API_END
 }
 
+#ifdef REVO_EXPERIMENTS   // librevo.so cannot be put into a non-exact mode
 extern "C" int32_t revo_search_set_mode(revo_gallery* g, int32_t mode) {
     REVO_REQUIRE(g && mode >= 0 && mode <= 3, "search_set_mode: mode must be 0..3");
     g->mode = mode;
     return 0;
 }
+#endif
 extern "C" int32_t revo_search_stats(revo_gallery* g, int32_t* out4, void* stream) {
     API_BEGIN
     REVO_REQUIRE(g && out4, "search_stats: null argument");

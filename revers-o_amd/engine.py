@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from .config import PEConfig, get_config
-from .weights import check_state_dict, synth_weights
+from .weights import check_state_dict, resolve_config, strip_non_parameters, synth_weights
 
 IMAGE_F32 = 0
 IMAGE_U8 = 1
@@ -37,13 +37,19 @@ def _as_device(device):
 class VitEngine:
     """A PE vision tower resident on one GPU (weights bf16, fp32 residual stream)."""
 
-    def __init__(self, cfg: PEConfig, state_dict, device=0, max_batch=64):
+    def __init__(self, cfg: PEConfig, state_dict, device=0, max_batch=64, experiments=False):
+        # LayerScale follows the checkpoint (SURVEY.md 8(a)); unknown `visual.*` tensors are rejected by name
+        cfg = resolve_config(cfg, state_dict)
         self.cfg = cfg
         self.device = _as_device(device)
         self.max_batch = int(max_batch)
         self._lock = threading.Lock()
-        lib = _lib.load()
+        # experiments=True: the handle lives in librevo_exp.so, the only library with the parity-test hooks
+        # (residual_after / taps); the product library cannot stop a forward early or hand out intermediates
+        self.experiments = bool(experiments) or _lib.product_is_experiment_build()
+        lib = _lib.load_exp() if experiments else _lib.load()
         check_state_dict(cfg, state_dict)
+        state_dict = strip_non_parameters(state_dict)
         names = sorted(state_dict)
         keep = []          # keep converted tensors alive until create returns
         arr = (_lib.Tensor * len(names))()
@@ -64,11 +70,15 @@ class VitEngine:
         self._lib = lib
 
     @classmethod
-    def synthetic(cls, name_or_cfg="PE-Core-L14-336", seed=0, device=0, max_batch=64, **kw):
+    def synthetic(cls, name_or_cfg="PE-Core-L14-336", seed=0, device=0, max_batch=64, experiments=False, **kw):
         cfg = name_or_cfg if isinstance(name_or_cfg, PEConfig) else get_config(name_or_cfg)
         dev = torch.device("cuda", device)
         sd = synth_weights(cfg, seed=seed, device=dev, **kw)
-        return cls(cfg, sd, device=device, max_batch=max_batch)
+        return cls(cfg, sd, device=device, max_batch=max_batch, experiments=experiments)
+
+    def _need_hooks(self, what):
+        if not self.experiments:
+            raise _lib.RevoError(f"{what} is a parity-test hook of librevo_exp.so: create the engine with experiments=True")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -112,6 +122,7 @@ class VitEngine:
     # -- parity-test hook -----------------------------------------------------
     def residual_after(self, images, n_layers):
         """fp32 residual stream [B, S, W] after ln_pre and the first n blocks."""
+        self._need_hooks("residual_after")
         _require_cuda(images, "images", self.device)
         B = images.shape[0]
         assert B <= self.max_batch
@@ -134,6 +145,7 @@ class VitEngine:
         """Parity-test hook: intermediate activations of one forward as fp32 CPU-comparable tensors:
         ``embed`` [B,S,W] (patch embed + position + class token, before ln_pre), ``ln_post`` [B,S,W] (fp32: the head
         works in fp32), ``pooled`` [B,W] (attention-pool output before proj) and the ``embedding`` [B,D]."""
+        self._need_hooks("taps")
         _require_cuda(images, "images", self.device)
         B = images.shape[0]
         assert B <= self.max_batch
@@ -154,12 +166,15 @@ class Gallery:
     """Device-resident cosine gallery: normalised rows as bf16 (scan copy) plus an
     fp32 master copy used for exact re-scoring and persistence."""
 
-    def __init__(self, dim, capacity, device=0, keep_f32=True):
+    def __init__(self, dim, capacity, device=0, keep_f32=True, experiments=False):
         self.dim = int(dim)
         self.capacity = int(capacity)
         self.device = _as_device(device)
         self._lock = threading.Lock()
-        self._lib = _lib.load()
+        # experiments=True: a handle of librevo_exp.so, the only library in which a search can be forced through (or
+        # kept from) its exact fallbacks (set_search_mode: parity tests and timing scripts)
+        self.experiments = bool(experiments) or _lib.product_is_experiment_build()
+        self._lib = _lib.load_exp() if experiments else _lib.load()
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.revo_gallery_create(self.dim, self.capacity, self.device.index or 0, int(keep_f32),
@@ -237,6 +252,9 @@ class Gallery:
     def set_search_mode(self, mode="certified"):
         """``certified`` (default): every query's result is certified exact or re-done exactly; ``collect`` /
         ``bruteforce``: every query takes that fallback (parity tests); ``uncertified``: certificate counted only."""
+        if not self.experiments:
+            raise _lib.RevoError("set_search_mode is a parity-test hook of librevo_exp.so: create the gallery with "
+                                 "experiments=True (the product library's searches are always certified exact)")
         _lib.check(self._lib.revo_search_set_mode(self._h, self.MODES[mode] if isinstance(mode, str) else int(mode)),
                    "revo_search_set_mode")
 

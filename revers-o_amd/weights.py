@@ -6,6 +6,9 @@ state dict (``visual.*`` names) comes either from a file the
 user supplies (safetensors / torch) or from the seeded synthetic initialiser the
 benchmarks and tests use.
 """
+import re
+from dataclasses import replace
+
 import torch
 
 from .config import PEConfig
@@ -98,11 +101,45 @@ def load_state_dict(path: str):
     return {k: v.float() for k, v in sd.items() if k.startswith("visual.")}
 
 
+# `visual.*` entries of a checkpoint that are not parameters of the arithmetic: buffers a module registers for values
+# this build derives itself (the rotary tables come from rope_theta and the grid, csrc/api.hip).  Anything else under
+# `visual.` that the architecture table does not name is an error, by name: a tensor the forward would silently ignore
+# is a different model ("LayerScale present only if the checkpoint has ls_* tensors").
+_NON_PARAMETER = re.compile(r"^visual\.(.*\.)?rope(\.\w+)*\.(freqs?|inv_freq|t_x|t_y|freqs_cis)$|\.num_batches_tracked$")
+_LS = re.compile(r"^visual\.transformer\.resblocks\.(\d+)\.ls_([12])\.gamma$")
+
+
+def resolve_config(cfg: PEConfig, sd) -> PEConfig:
+    """The variant's config with ``use_ls`` taken from the checkpoint: LayerScale is on iff the state dict carries
+    ``visual.transformer.resblocks.{i}.ls_{1,2}.gamma`` -- for every block, or the checkpoint is rejected."""
+    have = sorted((int(m.group(1)), int(m.group(2))) for m in map(_LS.match, sd) if m)
+    if not have:
+        return replace(cfg, use_ls=False) if cfg.use_ls else cfg
+    want = [(i, j) for i in range(cfg.layers) for j in (1, 2)]
+    if have != want:
+        lacking = sorted(set(want) - set(have))
+        extra = sorted(set(have) - set(want))
+        what = (f"lacks ls_{lacking[0][1]}.gamma of block {lacking[0][0]}" if lacking
+                else f"has ls_{extra[0][1]}.gamma for block {extra[0][0]} of a {cfg.layers}-block tower")
+        raise KeyError(f"checkpoint has LayerScale tensors for {len(have)} of {len(want)} places: {what}")
+    return cfg if cfg.use_ls else replace(cfg, use_ls=True)
+
+
+def strip_non_parameters(sd):
+    """The state dict without the known non-parameter buffers (see _NON_PARAMETER)."""
+    return {k: v for k, v in sd.items() if not _NON_PARAMETER.search(k)}
+
+
 def check_state_dict(cfg: PEConfig, sd):
+    """Every tensor the architecture needs, with its shape, and NOTHING else under ``visual.``."""
     exp = expected_shapes(cfg)
     missing = [k for k in exp if k not in sd]
     if missing:
         raise KeyError(f"checkpoint lacks {len(missing)} tensors, e.g. {missing[:3]}")
+    unexpected = [k for k in sd if k not in exp and not _NON_PARAMETER.search(k)]
+    if unexpected:
+        raise KeyError(f"checkpoint has {len(unexpected)} tensors {cfg.name} does not use, e.g. {sorted(unexpected)[:3]}: "
+                       "refusing to ignore them (a tensor the forward skips is a different model)")
     for k, shp in exp.items():
         if tuple(sd[k].shape) != tuple(shp):
             raise ValueError(f"{k}: expected {shp}, got {tuple(sd[k].shape)}")

@@ -15,7 +15,7 @@ from reverso_amd import engine
 dev = torch.device("cuda", 0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 D = 1024
-G = engine.Gallery(D, N, device=0)
+G = engine.Gallery(D, N, device=0, experiments=True)    # set_search_mode lives in librevo_exp.so
 g = torch.Generator(device=dev).manual_seed(42)
 for s in range(0, N, 131072):
     G.add(torch.randn(min(131072, N - s), D, generator=g, device=dev))

@@ -104,14 +104,11 @@ int main() {
             EXPECT(revo_vit_forward(vit, nullptr, 1, 1, out, 1, nullptr) == -2);
             EXPECT(revo_vit_forward(vit, out, 2, 1, out, 1, nullptr) == -2);
             EXPECT(revo_vit_forward(vit, out, 1, 5, out, 1, nullptr) == -2 && err_has("max_batch"));
-            EXPECT(revo_vit_read_tap(vit, 7, 1, out, nullptr) == -2);
             EXPECT(revo_vit_destroy(vit) == 0);
         }
     }
     EXPECT(revo_vit_destroy(nullptr) == 0);
     EXPECT(revo_vit_seq_len(nullptr) == -1);
-    EXPECT(revo_vit_set_debug_layers(nullptr, 1) == -2);
-    EXPECT(revo_vit_read_residual(nullptr, 1, nullptr, nullptr) == -2);
 
     // ---- gallery + search
     revo_gallery* g = nullptr;
@@ -129,7 +126,6 @@ int main() {
             EXPECT(revo_search_topk(g, v, 1, 51, 0, 0.f, 0, s, i, cnt, nullptr) == -2);
             EXPECT(revo_search_finish(g, 3, 5, 0, 0.f, 0, nullptr, 0, 0, s, i, cnt, nullptr, nullptr) == -2 && err_has("no matching"));
             EXPECT(revo_gallery_read(g, 0, 1, v, 0) == -2 && err_has("outside"));
-            EXPECT(revo_search_set_mode(g, 4) == -2 && revo_search_set_mode(g, 2) == 0 && revo_search_set_mode(g, 0) == 0);
             int32_t st4[4] = {7, 7, 7, 7};
             EXPECT(revo_search_stats(g, st4, nullptr) == 0 && st4[0] == -1 && st4[1] == 0);      // no search yet
             int32_t qi[1] = {0}; float nd[1] = {0.f};
@@ -153,7 +149,6 @@ int main() {
     EXPECT(revo_topk_merge(nullptr, nullptr, 1, 1, 1, 0, 0.f, nullptr, nullptr, nullptr, nullptr) == -2);
     EXPECT(revo_topk_merge_packed(nullptr, 1, 1, 1, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == -2);
     EXPECT(revo_search_exact(nullptr, 1, nullptr, nullptr, 5, 0, 0.f, 0, nullptr, nullptr, nullptr, nullptr) == -2);
-    EXPECT(revo_search_set_mode(nullptr, 0) == -2);
     EXPECT(revo_search_stats(nullptr, nullptr, nullptr) == -2);
 
     // ---- single kernels and hooks: argument checks that do not need a device

@@ -37,6 +37,13 @@ def test_experiment_switches_are_not_in_the_product_library():
     assert "revo_op_set_gemm_debug" in exp and sorted(exp) == sorted(_lib.EXPERIMENT_SIGNATURES)
     for n in exp:
         assert not hasattr(lib, n), f"librevo.so exports the experiment switch {n}"
+    # the parity-test hooks too: the product library cannot stop a forward early, hand out intermediate buffers, or be
+    # put into a search mode that skips (or forces) the exact fallback
+    for n in ("revo_vit_set_debug_layers", "revo_vit_read_residual", "revo_vit_read_tap", "revo_search_set_mode"):
+        assert n in exp and not hasattr(lib, n), n
+    xl = _lib.load_exp()
+    for n in exp:
+        assert hasattr(xl, n), f"librevo_exp.so does not export {n}"
 
 
 def test_version_and_error_string():

@@ -35,15 +35,18 @@ def test_tiny_vit_layer_by_layer(dev, fname, cname):
     gold = _gold(fname)
     cfg, sd, images = make_golden.tiny_case(cname)
     eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=4)
+    # intermediate activations come from librevo_exp.so (the product library has no such hooks): same sources, same bits
+    engx = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=4, experiments=True)
     img = images.to(dev)
+    assert torch.equal(engx.embed(img), eng.embed(img))
     for n, tap in ((0, "ln_pre"), (1, "block0"), (2, "block1")):
-        x = eng.residual_after(img, n).cpu().numpy()
+        x = engx.residual_after(img, n).cpu().numpy()
         ref = gold["tap_" + tap]
         err = np.abs(x - ref).max()
         assert err <= 3e-2 * np.abs(ref).max(), (tap, err, np.abs(ref).max())
     # the kernels outside the transformer blocks, each against its own golden tap: patchify + patch GEMM + position
     # add + class-token rows (embed), the last LayerNorm (ln_post), the single-probe pool attention + its MLP (pooled)
-    taps = eng.taps(img)
+    taps = engx.taps(img)
     for name in ("embed", "ln_post", "pooled"):
         got, ref = taps[name].cpu().numpy(), gold["tap_" + name]
         assert got.shape == ref.shape, (name, got.shape, ref.shape)
@@ -60,6 +63,7 @@ def test_tiny_vit_layer_by_layer(dev, fname, cname):
     refun = gold["tap_proj"]
     assert np.abs(un - refun).max() <= 3e-2 * np.abs(refun).max()
     eng.close()
+    engx.close()
 
 
 def test_uint8_input_matches_float_preprocess(dev):
@@ -89,14 +93,17 @@ def test_b16_single_block_golden(dev):
     gold = _gold("b16_block.npz")
     cfg, sd, images = make_golden.b16_block_case()
     eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=1)
+    engx = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=1, experiments=True)
     rows = gold["rows"].tolist()
-    x0 = eng.residual_after(images.to(dev), 0).cpu().numpy()[0, rows]
-    x1 = eng.residual_after(images.to(dev), 1).cpu().numpy()[0, rows]
+    x0 = engx.residual_after(images.to(dev), 0).cpu().numpy()[0, rows]
+    x1 = engx.residual_after(images.to(dev), 1).cpu().numpy()[0, rows]
     assert np.abs(x0 - gold["ln_pre"]).max() <= 3e-2 * np.abs(gold["ln_pre"]).max()
     assert np.abs(x1 - gold["block0"]).max() <= 3e-2 * np.abs(gold["block0"]).max()
     emb = eng.embed(images.to(dev)).cpu().numpy()
     assert (emb * gold["embedding"]).sum() >= 0.9999
+    assert torch.equal(engx.embed(images.to(dev)), eng.embed(images.to(dev)))
     eng.close()
+    engx.close()
 
 
 def test_b16_full_depth_vs_oracle(dev):
@@ -227,13 +234,15 @@ def test_mid_size_batches_are_deterministic(dev, B):
     576-684 workgroups): repeated forwards must give the same bits, block by block and at the end."""
     cfg = reverso_amd.get_config("PE-Core-B16-224")
     eng = engine.VitEngine.synthetic(cfg, seed=2, device=0, max_batch=16)
+    engx = engine.VitEngine.synthetic(cfg, seed=2, device=0, max_batch=16, experiments=True)
     g = torch.Generator().manual_seed(9)
     u8 = torch.randint(0, 256, (B, 3, 224, 224), generator=g, dtype=torch.uint8).to(dev)
-    r = [eng.residual_after(u8, 1).cpu() for _ in range(3)]
+    r = [engx.residual_after(u8, 1).cpu() for _ in range(3)]
     assert torch.equal(r[0], r[1]) and torch.equal(r[0], r[2])
     e = [eng.embed(u8).cpu() for _ in range(3)]
-    assert torch.equal(e[0], e[1]) and torch.equal(e[0], e[2])
+    assert torch.equal(e[0], e[1]) and torch.equal(e[0], e[2]) and torch.equal(e[0], engx.embed(u8).cpu())
     eng.close()
+    engx.close()
 
 
 def test_l14_every_batch_size_family_agrees(dev):
@@ -267,3 +276,42 @@ def test_module_level_embed_accepts_pil_images(dev):
     b = eng.embed(pp.batch_u8(pils, cfg.image_size).to(dev))
     assert torch.equal(a, b) and a.shape == (3, cfg.out_dim)
     eng.close()
+
+
+def test_layerscale_checkpoint_is_auto_detected_and_matches_the_oracle(dev, lib):
+    """A checkpoint that carries ls_*.gamma tensors handed to the LayerScale-less variant name: the engine turns LayerScale
+    on from the tensors and lands on the oracle run with use_ls = True; an unexpected `visual.*` tensor
+    is refused by name, by the Python loader and by the C ABI itself."""
+    import ctypes as C
+    from reverso_amd import _lib
+    gold = _gold("tiny_vit_ls.npz")
+    cfg_ls, sd, images = make_golden.tiny_case("PE-Tiny-T14-56-LS")
+    plain = reverso_amd.get_config("PE-Tiny-T14-56")
+    assert not plain.use_ls and any(".ls_1.gamma" in k for k in sd)
+    eng = engine.VitEngine(plain, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=4)
+    assert eng.cfg.use_ls
+    emb = eng.embed(images.to(dev)).cpu()
+    assert_embeddings_match(emb.numpy(), gold["embedding"], what="auto-detected LayerScale")
+    with torch.no_grad():
+        ref = pe_vit.embed(sd, cfg_ls, images)
+        ref_off = pe_vit.embed({k: v for k, v in sd.items() if ".ls_" not in k}, plain, images)
+    assert_embeddings_match(emb, ref)
+    # ignoring the gains is a different model: the oracle without LayerScale is measurably elsewhere
+    assert float(torch.nn.functional.cosine_similarity(emb, ref_off, dim=-1).min()) < 0.9999
+    eng.close()
+    bad = {k: v.to(dev) for k, v in sd.items()}
+    bad["visual.foo"] = torch.zeros(3, device=dev)
+    with pytest.raises(KeyError, match=r"visual\.foo"):
+        engine.VitEngine(plain, bad, device=0)
+    # the C ABI refuses it too: LayerScale tensors with cfg.use_ls = 0, and any tensor the architecture does not read
+    for extra, use_ls, msg in (("visual.transformer.resblocks.0.ls_1.gamma", 0, b"unexpected weight tensor"), ("visual.foo", 1, b"visual.foo")):
+        names = sorted(k for k in sd if use_ls or ".ls_" not in k) + ([extra] if extra not in sd or not use_ls else [])
+        keep = [(sd[n] if n in sd else torch.zeros(plain.width)).float().contiguous() for n in names]
+        arr = (_lib.Tensor * len(names))()
+        for i, (n, t) in enumerate(zip(names, keep)):
+            arr[i].name, arr[i].data, arr[i].numel = n.encode(), t.data_ptr(), t.numel()
+        c = _lib.VitCfg(plain.image_size, plain.patch_size, plain.width, plain.layers, plain.heads, plain.mlp_dim, plain.out_dim,
+                        plain.pool_heads, 1, use_ls, plain.ln_eps, plain.rope_theta, plain.pool_mlp_dim)
+        h = C.c_void_p()
+        assert lib.revo_vit_create(C.byref(c), arr, len(names), 0, 2, C.byref(h)) == -2
+        assert msg in lib.revo_last_error(), lib.revo_last_error()

@@ -320,3 +320,32 @@ def test_killed_build_resumes_from_its_delta_shards(tmp_path, dev):
     assert len(os.listdir(done)) == n_files + 1
     r4 = SimpleReverso(model_name="PE-Tiny-T14-56", db_root=root, max_batch=4)
     assert r4.load_database("g").startswith("✅") and len(r4.vector_db) == 26
+
+
+def test_load_failure_falls_back_to_the_first_available_config(tmp_path, dev, capsys):
+    """core_system.py:183-191: if the target model fails to LOAD, the reference falls back to available_configs()[0].
+    Here a checkpoint file that does not fit PE-Core-L14-336 (it is a PE-Core-B16-224 one) makes the target's load fail
+    -- by name, in check_state_dict -- and the fallback config, which it does fit, is what the facade ends up with."""
+    from safetensors.torch import save_file
+    from reverso_amd import engine
+    cfg = reverso_amd.get_config("PE-Core-B16-224")
+    assert reverso_amd.available_configs()[0] == cfg.name
+    sd = weights.synth_weights(cfg, seed=5)
+    ck = str(tmp_path / "b16.safetensors")
+    save_file({k: v.contiguous() for k, v in sd.items()}, ck)
+    r = SimpleReverso(model_name="PE-Core-L14-336", checkpoint=ck, db_root=str(tmp_path / "db"), max_batch=2)
+    out = capsys.readouterr().out
+    assert "❌ Failed to load PE-Core-L14-336" in out and "lacks" in out and "🔄 Using fallback: PE-Core-B16-224" in out
+    assert r.pe_model.cfg.name == cfg.name
+    g = torch.Generator().manual_seed(1)
+    u8 = torch.randint(0, 256, (2, 3, 224, 224), generator=g, dtype=torch.uint8)
+    eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=2)
+    assert torch.equal(r.pe_model.embed(u8.to(dev)), eng.embed(u8.to(dev)))
+    eng.close()
+    # a checkpoint that fits nothing: the fallback's own failure propagates (the reference's second from_config is not guarded)
+    bad = dict(sd)
+    bad["visual.foo"] = torch.zeros(3)
+    ck2 = str(tmp_path / "bad.safetensors")
+    save_file({k: v.contiguous() for k, v in bad.items()}, ck2)
+    with pytest.raises(KeyError, match=r"visual\.foo"):
+        SimpleReverso(model_name="PE-Core-B16-224", checkpoint=ck2, db_root=str(tmp_path / "db2"), max_batch=2)

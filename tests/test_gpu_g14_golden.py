@@ -32,6 +32,8 @@ def test_g14_batch32_full_depth_vs_golden(dev):
     cfg, sd, u8 = mg.batch_case()
     assert int(u8.long().sum()) == int(gold["image_sum"])
     eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=mg.BATCH)
+    # the per-block taps come from a handle of librevo_exp.so (parity-test hooks; same sources as the product library)
+    engx = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=2, experiments=True)
     del sd
     imgs = u8.to(dev)
     emb = eng.embed(imgs)
@@ -58,12 +60,13 @@ def test_g14_batch32_full_depth_vs_golden(dev):
     # per-block activations of the two golden images (embedded as a batch of two)
     ttok = gold["tap_tokens"].tolist()
     two = imgs[gi]
+    assert torch.equal(engx.embed(two), eng.embed(two))
     rel = {}
     for b in gold["tap_blocks"].tolist():
-        x = eng.residual_after(two, b + 1)[:, ttok].cpu()
+        x = engx.residual_after(two, b + 1)[:, ttok].cpu()
         r = torch.from_numpy(gold[f"tap_block{b}"])
         rel[f"block{b}"] = float((x - r).norm() / r.norm())
-    taps = eng.taps(two)
+    taps = engx.taps(two)
     r = torch.from_numpy(gold["tap_ln_post"])
     rel["ln_post"] = float((taps["ln_post"][:, ttok].cpu() - r).norm() / r.norm())
     r = torch.from_numpy(gold["tap_pooled"])
@@ -72,6 +75,7 @@ def test_g14_batch32_full_depth_vs_golden(dev):
     print("G14 relative distance from the oracle by stage:", {k: round(v, 5) for k, v in rel.items()})
     assert max(rel.values()) <= 1.2e-2 and rel["embedding"] <= 8e-3, rel
     eng.close()
+    engx.close()
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(32768, 4608, 1536, 0), (32768, 8960, 1536, 1), (32768, 1536, 8960, 2),

@@ -38,11 +38,11 @@ def test_l14_error_budget_by_stage(dev):
         ref_out = pe_vit.encode_image(sdd, cfg, pe_vit.preprocess_u8(imgs), taps)
         ref = pe_vit.l2_normalize(ref_out)
     assert (ref.cpu() - torch.from_numpy(gold["embedding"])).abs().max().item() <= 2e-5
-    eng = engine.VitEngine(cfg, sdd, device=0, max_batch=len(idx))
-    got = eng.taps(imgs)
+    engx = engine.VitEngine(cfg, sdd, device=0, max_batch=len(idx), experiments=True)    # the tap hooks live in librevo_exp.so
+    got = engx.taps(imgs)
     budget = {"embed": _rel(got["embed"], taps["embed"])}
     for n in (1, 6, 12, 18, 24):
-        budget[f"block{n - 1}"] = _rel(eng.residual_after(imgs, n), taps[f"block{n - 1}"])
+        budget[f"block{n - 1}"] = _rel(engx.residual_after(imgs, n), taps[f"block{n - 1}"])
     budget["ln_post"] = _rel(got["ln_post"], taps["ln_post"])
     budget["pooled"] = _rel(got["pooled"], taps["pooled"])
     emb = got["embedding"]
@@ -59,5 +59,5 @@ def test_l14_error_budget_by_stage(dev):
     budget["cosine_min"] = float((emb * ref).sum(-1).min())
     budget["pairwise_cosine_between_images"] = float((ref @ ref.T).fill_diagonal_(0).max())
     print("L14 error budget:", json.dumps({k: round(v, 6) for k, v in budget.items()}))
-    eng.close()
+    engx.close()
     assert budget["embedding"] <= 1.2e-2 and budget["cosine_min"] >= 0.9999

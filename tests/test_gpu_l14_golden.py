@@ -58,12 +58,15 @@ def test_l14_headline_batch_64_images_vs_golden(dev):
     # intermediate activations of two images (the engine's taps are those of its last forward: embed them alone)
     timg, ttok = gold["tap_images"].tolist(), gold["tap_tokens"].tolist()
     two = u8[timg].to(dev)
+    # the taps come from a handle of librevo_exp.so (the product library has no parity hooks): same sources, same bits
+    engx = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=2, experiments=True)
+    assert torch.equal(engx.embed(two), eng.embed(two))
     rel = {}
     for b in gold["tap_blocks"].tolist():
-        x = eng.residual_after(two, b + 1)[:, ttok].cpu()
+        x = engx.residual_after(two, b + 1)[:, ttok].cpu()
         r = torch.from_numpy(gold[f"tap_block{b}"])
         rel[f"block{b}"] = float((x - r).norm() / r.norm())
-    taps = eng.taps(two)
+    taps = engx.taps(two)
     r = torch.from_numpy(gold["tap_ln_post"])
     rel["ln_post"] = float((taps["ln_post"][:, ttok].cpu() - r).norm() / r.norm())
     r = torch.from_numpy(gold["tap_pooled"])
@@ -77,6 +80,7 @@ def test_l14_headline_batch_64_images_vs_golden(dev):
     # the same images embedded alone take other GEMM tilings: still the oracle's vectors
     assert_embeddings_match(taps["embedding"].cpu(), ref[timg])
     eng.close()
+    engx.close()
 
 
 def test_l14_outlier_channels_vs_golden(dev):
@@ -94,7 +98,9 @@ def test_l14_outlier_channels_vs_golden(dev):
     gal = _probe_gallery(cfg.out_dim)
     assert ((emb @ gal.T) - (ref @ gal.T)).abs().max().item() <= 1e-3
     # the residual stream itself: the outlier channels after block 5 are as large on the device as in the oracle
-    x = eng.residual_after(u8.to(dev), 6).cpu()
+    engx = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=4, experiments=True)
+    x = engx.residual_after(u8.to(dev), 6).cpu()
+    engx.close()
     got = float(x[..., big].abs().max())
     assert abs(got - float(gold["resid_absmax_big"])) <= 0.03 * float(gold["resid_absmax_big"])
     eng.close()

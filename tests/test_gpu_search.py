@@ -18,6 +18,17 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 import make_golden  # noqa: E402
 
 
+
+def _bruteforce_twin(G):
+    """A handle of librevo_exp.so holding G's fp32 rows (bit for bit: they are stored normalised), forced through the
+    brute-force pass -- the exhaustive fp32 scoring the product handle's certified result must equal.  (The product
+    library cannot be switched: revo_search_set_mode exists only in the experiment build.)"""
+    Gx = engine.Gallery(G.dim, max(len(G), 1), device=0, experiments=True)
+    for s0 in range(0, len(G), 1 << 20):
+        Gx.add(G.read(s0, min(1 << 20, len(G) - s0)), normalize=False)
+    Gx.set_search_mode("bruteforce")
+    return Gx
+
 def _gold():
     return np.load(os.path.join(HERE, "golden", "search_4096x1024.npz"))
 
@@ -343,10 +354,12 @@ def test_wide_k_adversarial_overflow_and_ties(dev):
     out = G.search(qd, k)
     st = G.search_stats()
     assert st["checked"] == Q and st["uncertified"] >= Q // 2, st
-    G.set_search_mode("bruteforce")
-    ref = G.search(qd, k)
-    assert G.search_stats()["bruteforced"] == Q
-    G.set_search_mode("certified")
+    with pytest.raises(Exception, match="librevo_exp"):
+        G.set_search_mode("bruteforce")               # the product handle cannot leave the certified mode
+    Gx = _bruteforce_twin(G)
+    ref = Gx.search(qd, k)
+    assert Gx.search_stats()["bruteforced"] == Q
+    Gx.close()
     for a, b in zip(out, ref):
         assert torch.equal(a, b)
     s, i, c = (t.cpu().numpy() for t in out)
@@ -388,8 +401,9 @@ def test_near_duplicate_frame_clusters(dev, k, csize):
     st = G.search_stats()
     if csize > 64:
         assert st["uncertified"] == Q and st["bruteforced"] == 0, st      # every query needed (only) the collecting pass
-    G.set_search_mode("bruteforce")
-    ref = G.search(qd, k, None)
+    Gx = _bruteforce_twin(G)
+    ref = Gx.search(qd, k, None)
+    Gx.close()
     G.close()
     for a, b in zip(out, ref):
         assert torch.equal(a, b)
@@ -419,11 +433,14 @@ def test_certificate_modes_agree_and_count(dev):
         G = engine.Gallery(D, N, device=0)
         G.add(torch.from_numpy(gal).to(dev))
         qd = torch.from_numpy(qr).to(dev)
-        outs = {}
+        outs = {"product": G.search(qd, k, thr)}                  # librevo.so: certified, the only mode it has
+        stp = G.search_stats()
+        assert stp["checked"] == Q and 1 <= stp["uncertified"] <= Q // 4, stp
+        Gx = _bruteforce_twin(G)                                  # librevo_exp.so: the same rows, every mode
         for mode in ("certified", "collect", "bruteforce", "uncertified"):
-            G.set_search_mode(mode)
-            outs[mode] = G.search(qd, k, thr)
-            st = G.search_stats()
+            Gx.set_search_mode(mode)
+            outs[mode] = Gx.search(qd, k, thr)
+            st = Gx.search_stats()
             assert st["checked"] == Q, (mode, st)
             if mode == "certified":
                 assert 1 <= st["uncertified"] <= Q // 4, st            # the duplicate group's query, few others
@@ -432,7 +449,8 @@ def test_certificate_modes_agree_and_count(dev):
             if mode == "bruteforce":
                 assert st["bruteforced"] == Q, st
         G.close()
-        for mode in ("collect", "bruteforce"):
+        Gx.close()
+        for mode in ("product", "collect", "bruteforce"):
             for a, b in zip(outs["certified"], outs[mode]):
                 assert torch.equal(a, b), (N, k, mode)
         _check(outs["certified"], osearch.search(gal, qr, k, thr), atol=1e-5, near_tie=3e-7)
@@ -456,7 +474,7 @@ def test_certificate_error_bound_is_rigorous(dev):
         gal[:8] = u.view(np.float32)
         qr[:8] = gal[:8]
         Gs = engine.Gallery(D, N, device=0, keep_f32=False)
-        Gf = engine.Gallery(D, N, device=0)
+        Gf = engine.Gallery(D, N, device=0, experiments=True)
         gd, qd = torch.from_numpy(gal).to(dev), torch.from_numpy(qr).to(dev)
         Gs.add(gd, normalize=False)
         Gf.add(gd, normalize=False)
@@ -657,8 +675,9 @@ def test_wide_candidate_lists_on_very_large_galleries(dev):
     out = G.search(q, k)
     st = G.search_stats()
     assert st["checked"] == Q
-    G.set_search_mode("bruteforce")
-    ref = G.search(q, k)
+    Gx = _bruteforce_twin(G)
+    ref = Gx.search(q, k)
+    Gx.close()
     G.close()
     for a, b in zip(out, ref):
         assert torch.equal(a, b)
