@@ -88,6 +88,44 @@ def search(gallery, queries, k, threshold=None, normalize=True, acc=np.float64):
     return out_s, out_i, out_c
 
 
+def search_chunked(chunks, queries, k, threshold=None, normalize_queries=True, acc=np.float64):
+    """:func:`search` over a gallery that arrives in row chunks -- ``chunks`` yields ``(start, rows float32 [n, D])`` with
+    the rows ALREADY normalised (what a store hands back: qdrant normalises at insert, core_system.py:600-603) -- so that
+    the BASELINE gallery (1 M x 1024: 4 GB of float32, 8 GB as float64) can be ranked without holding it twice.  Same
+    arithmetic and order rule as :func:`search`: float64 accumulation, one rounding to float32, (score desc, index asc),
+    cut at ``score >= threshold``.  The Q x N float32 score matrix IS materialised (keep Q small)."""
+    q = normalize_rows(queries) if normalize_queries else np.asarray(queries, dtype=np.float32)
+    qa = q.astype(acc)
+    parts, starts = [], []
+    for start, rows in chunks:
+        parts.append((qa @ np.asarray(rows, dtype=np.float32).astype(acc).T).astype(np.float32))
+        starts.append(int(start))
+    Q = q.shape[0]
+    out_s = np.full((Q, k), -np.inf, dtype=np.float32)
+    out_i = np.full((Q, k), -1, dtype=np.int64)
+    out_c = np.zeros((Q,), dtype=np.int32)
+    if not parts:
+        return out_s, out_i, out_c
+    order = np.argsort(starts)
+    assert all(starts[order[j]] + parts[order[j]].shape[1] == starts[order[j + 1]] for j in range(len(order) - 1)), \
+        "chunks must tile the gallery"
+    sc = np.concatenate([parts[j] for j in order], axis=1)
+    for r in range(Q):
+        o = rank_topk(sc[r], min(k, sc.shape[1]), threshold) if sc.shape[1] <= 4 * k + 16 else None
+        if o is None:
+            row = sc[r]
+            kth = np.partition(row, row.shape[0] - k)[row.shape[0] - k]
+            cand = np.nonzero(row >= kth)[0]
+            o = cand[np.lexsort((cand, -row[cand].astype(np.float64)))][:k]
+            if threshold is not None:
+                o = o[row[o] >= np.float32(threshold)]
+        c = o.shape[0]
+        out_s[r, :c] = sc[r][o]
+        out_i[r, :c] = o
+        out_c[r] = c
+    return out_s, out_i, out_c
+
+
 def search_one_reference_style(gallery_f32_normalized, query, k, threshold=None):
     """The reference's actual usage: ONE query (``region_embeddings[0]``,
     core_system.py:657), float32 ``G @ q``, full argsort, walk until ``limit`` or

@@ -802,6 +802,14 @@ constexpr uint32_t C256_STG_OFF = G256_LDS;
 constexpr uint32_t C256_TAU_OFF = C256_STG_OFF + S256_STG * 8;
 constexpr uint32_t C256_CTRL_OFF = C256_TAU_OFF + 256 * 4;          // [0] running total of staged survivors
 
+// the finest column classes (col & 63) that a pass (groups, grp) of the retry ladder covers: col & (groups - 1) == grp
+__device__ inline uint64_t c256_class_mask(int groups, int grp) {
+    uint64_t m = 0;
+    for (int f = grp; f < S256_MAXGROUPS; f += groups) m |= 1ull << f;
+    return m;
+}
+static_assert(S256_MAXGROUPS == 64, "the collect pass keeps one bit per finest column class in a 64-bit mask");
+
 template <int ROWS>
 __global__ __launch_bounds__(G256_THREADS, 2) void topk_collect256_kernel(Collect256Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -837,6 +845,11 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_collect256_kernel(Collec
 
     long t = t0;
     int groups = 1, grp = 0;
+    // column classes (col & 63: the finest level of the ladder) of the CURRENT tile whose survivors are already in the
+    // lists.  A pass that did not overflow appends at once; when a later group of the same tile overflows and the
+    // ladder deepens, the classes of the passes before it must not be appended again (the exact finish re-scores
+    // every list entry and assumes each row appears once: a repeated row would take two places of a result).
+    uint64_t done = 0;
     uint32_t staged_before = 0;
     while (t < t1) {
         const long n0 = t * 256;
@@ -893,7 +906,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_collect256_kernel(Collec
                             const int col = cbase + n * 16 + j;
                             const bool pass = v >= taum[m];
                             if (__ballot(pass) == 0ull) continue;
-                            if (pass && (col & (groups - 1)) == grp) {
+                            if (pass && (col & (groups - 1)) == grp && !((done >> (col & 63)) & 1ull)) {
                                 const uint32_t pos = (uint32_t)s256_lds_inc(C256_CTRL_OFF) - staged_before;
                                 if (pos < (uint32_t)S256_STG) s256_lds_store64(C256_STG_OFF + pos * 8, s256_entry(row, v, rel0 + col));
                             }
@@ -919,9 +932,16 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_collect256_kernel(Collec
         if (overflow) {
             groups = groups < S256_MAXGROUPS ? groups * 2 : S256_MAXGROUPS;
             grp = 0;
-        } else if (++grp == groups) {
+        } else {
+            done |= c256_class_mask(groups, grp);            // this pass's columns are in the lists now
+            ++grp;
+        }
+        // the next group of the (possibly deeper) ladder that still has columns to append
+        while (grp < groups && (c256_class_mask(groups, grp) & ~done) == 0ull) ++grp;
+        if (grp == groups) {
             groups = 1;
             grp = 0;
+            done = 0;
             ++t;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

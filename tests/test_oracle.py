@@ -62,6 +62,12 @@ def test_search_matches_golden():
             assert np.array_equal(i, gold[t + "_indices"])
             assert np.array_equal(c, gold[t + "_counts"])
             np.testing.assert_allclose(s, gold[t + "_scores"], atol=1e-6, rtol=0)
+            # the chunked form (the one the full-size GPU test runs on the 1 M-row gallery) is the same oracle:
+            # the committed goldens pin it too
+            gn = osearch.normalize_rows(gal)
+            cs, ci, cc = osearch.search_chunked([(st, gn[st:st + 1000]) for st in range(4000, -1, -1000)], qr, k, thr)
+            assert np.array_equal(ci, gold[t + "_indices"]) and np.array_equal(cc, gold[t + "_counts"])
+            assert np.array_equal(cs, s)
     # planted neighbours are found first; duplicate group comes back index-ascending
     i10 = gold["k10_thrnone_indices"]
     assert np.array_equal(i10[0], np.arange(100, 110))
