@@ -133,10 +133,11 @@ int32_t revo_search_finish(revo_gallery* g, int32_t n_queries, int32_t k, int32_
 int32_t revo_search_exact(revo_gallery* g, int32_t n, const int32_t* q_idx, const float* need, int32_t k,
                           int32_t has_threshold, float threshold, int64_t index_offset, float* scores, int64_t* indices,
                           int32_t* counts, void* stream);
-/* counters of the handle's last search, read after `stream` has drained (host array): out4 = { queries the certificate
- * failed for (-1: the gallery has no fp32 rows), of those: brute-forced, queries the certificate was evaluated for,
- * rows the collecting passes re-scored } */
-int32_t revo_search_stats(revo_gallery* g, int32_t* out4, void* stream);
+/* counters of the handle's last search, read after `stream` has drained (host array of 8): out8 = { queries the
+ * certificate failed for (-1: the gallery has no fp32 rows), of those: brute-forced, queries the certificate was
+ * evaluated for, rows the exact passes re-scored, of the failed queries: resolved from what the scan had kept (no second
+ * pass over the gallery: searches with k > 25 scan with an admission margin for that), 0, 0, 0 } */
+int32_t revo_search_stats(revo_gallery* g, int32_t* out8, void* stream);
 /* merge `parts` result sets laid out [parts, n_queries, k] (the all-gathered per-shard
  * results of a row-sharded gallery) into one [n_queries, k] set, same ordering rule. */
 int32_t revo_topk_merge(const float* scores, const int64_t* indices, int32_t parts, int32_t n_queries, int32_t k,

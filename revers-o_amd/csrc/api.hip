@@ -627,6 +627,9 @@ struct revo_gallery {
     float* stage = nullptr; size_t stage_cap = 0;
     // candidates of the last scan (inside `part`), consumed by the finish step
     const uint64_t* cand = nullptr; long cand_stride = 0; int cand_Q = 0, cand_ksel = 0;
+    // the last scan ran with an admission margin: its segments can answer uncertified queries (CertArgs, kernels.h)
+    revo::SegSrc segs[2] = {}; int nsegs = 0; const uint64_t* prelist = nullptr;
+    float* marg = nullptr; int* dropflag = nullptr;
     // exactness certificate (kernels.h): per-query rounding norms of the last search's queries, running maxima over the
     // gallery's rows, the fallback workspace (sized with q_cap) and the handle's mode
     float* qstat = nullptr; uint32_t* gstat = nullptr;
@@ -635,13 +638,15 @@ struct revo_gallery {
     const uint32_t* seed_bounds = nullptr;   // experiment build only (revo_debug_seed_bounds): admission bounds from outside
     ~revo_gallery() {
         (void)hipFree(gb); (void)hipFree(gf); (void)hipFree(qf); (void)hipFree(qb); (void)hipFree(part);
-        (void)hipFree(tau0);
+        (void)hipFree(tau0); (void)hipFree(marg); (void)hipFree(dropflag);
         (void)hipFree(stage);
         (void)hipFree(qstat); (void)hipFree(gstat); (void)hipFree(xbuf);
     }
     revo::CertArgs cert_args(float* cert_out) const {
         revo::CertArgs c{};
         c.qstat = qstat; c.gstat = gstat; c.mode = mode; c.ws = xw; c.Qb = qb; c.ldq = D; c.cert_out = cert_out;
+        c.nsegs = nsegs; c.segs[0] = segs[0]; c.segs[1] = segs[1]; c.seg_ksel = cand_ksel; c.prelist = prelist;
+        c.tau_base = tau0; c.marg = marg; c.dropflag = dropflag;
         return c;
     }
 };
@@ -759,30 +764,36 @@ constexpr long SEARCH_WIDE_ROWS = 1l << 22;   // from here on the unsharded sear
 // Phase 1 of a search: normalise the queries, scan the gallery (bf16 MFMA scores) and leave each query's best
 // ksel candidates, sorted best first, in the handle (cand / cand_stride).  The gallery must not be empty.
 static int search_candidates(revo_gallery* g, const float* queries, int Q, int ksel, hipStream_t st,
-                             uint32_t* bounds = nullptr, int top_m = 0) {
+                             uint32_t* bounds = nullptr, int top_m = 0, bool margin = false) {
     using namespace revo;
     const int D = g->D;
     const long N = g->size;
     if (g->q_cap < Q) {
         REVO_HIP_CHECK(hipStreamSynchronize(st));
         (void)hipFree(g->qf); (void)hipFree(g->qb); (void)hipFree(g->tau0); (void)hipFree(g->qstat); (void)hipFree(g->xbuf);
+        (void)hipFree(g->marg); (void)hipFree(g->dropflag);
         g->qf = nullptr; g->qb = nullptr; g->tau0 = nullptr; g->qstat = nullptr; g->xbuf = nullptr; g->q_cap = 0;
+        g->marg = nullptr; g->dropflag = nullptr;
         g->xw = ExactWs{};
         REVO_HIP_CHECK(hipMalloc((void**)&g->qf, (size_t)Q * D * 4));
         REVO_HIP_CHECK(hipMalloc((void**)&g->qb, (size_t)Q * D * 2));
         REVO_HIP_CHECK(hipMalloc((void**)&g->tau0, (size_t)Q * 4 * 2));   // pre-pass bounds | live bounds
         REVO_HIP_CHECK(hipMalloc((void**)&g->qstat, (size_t)Q * 8));
+        REVO_HIP_CHECK(hipMalloc((void**)&g->marg, (size_t)Q * 4));
+        REVO_HIP_CHECK(hipMalloc((void**)&g->dropflag, (size_t)Q * 4));
         if (g->keep_f32) {
             // fallback workspace of the exactness certificate: counters | unc_q | unc_lb | col_cnt | over_j | qb_u | col
             auto up256 = [](size_t x) { return (x + 255) / 256 * 256; };
             const size_t o_q = 256, o_lb = o_q + up256((size_t)Q * 4), o_cnt = o_lb + up256((size_t)Q * 4),
-                         o_over = o_cnt + up256((size_t)Q * 4), o_qb = o_over + up256((size_t)Q * 4),
+                         o_over = o_cnt + up256((size_t)Q * 4), o_orow = o_over + up256((size_t)Q * 4),
+                         o_qb = o_orow + up256((size_t)Q * 4),
                          o_col = o_qb + up256((size_t)Q * D * 2), total = o_col + (size_t)Q * EXACT_COL_CAP * 8;
             REVO_HIP_CHECK(hipMalloc((void**)&g->xbuf, total));
             REVO_HIP_CHECK(hipMemsetAsync(g->xbuf, 0, 256, st));
             g->xw.ctr = (int*)g->xbuf; g->xw.unc_q = (int*)(g->xbuf + o_q); g->xw.unc_lb = (float*)(g->xbuf + o_lb);
             g->xw.col_cnt = (int*)(g->xbuf + o_cnt); g->xw.over_j = (int*)(g->xbuf + o_over);
             g->xw.qb_u = (bf16_t*)(g->xbuf + o_qb); g->xw.ldqb = D; g->xw.col = (uint64_t*)(g->xbuf + o_col);
+            g->xw.cap = Q; g->xw.orow = (int*)(g->xbuf + o_orow);
         }
         g->q_cap = Q;
     }
@@ -795,9 +806,13 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
         }
         return 0;
     };
-    g->cand = nullptr; g->cand_Q = 0;
+    g->cand = nullptr; g->cand_Q = 0; g->nsegs = 0; g->prelist = nullptr;
+    // the admission margin only pays where the certificate is expected to fail (see revo_search_topk) and only the
+    // 256 x 256 scan has segments; it needs the fp32 rows (no certificate without them)
+    margin = margin && g->keep_f32 && N >= SEARCH_SMALL_ROWS;
     { ProfScope ps("search_prep", st);
       CHECK_RC(launch_l2norm_rows(queries, D, g->qf, D, g->qb, D, Q, D, st, 1, g->qstat, nullptr));
+      if (margin) CHECK_RC(launch_cert_margin(g->qstat, g->gstat, D, Q, g->marg, g->dropflag, st));
       if (g->xbuf) REVO_HIP_CHECK(hipMemsetAsync(g->xw.ctr, 0, 32, st)); }
 
     if (N >= SEARCH_SMALL_ROWS) {
@@ -849,8 +864,11 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
               const Part& pt = parts[i];
               CHECK_RC(launch_topk_scan256(g->qb + (size_t)pt.q0 * D, D, g->gb, D, pt.nq, N, D, n_pre, pt.splits,
                                            (uint64_t*)(wsb + pt.seg_off), (int*)(wsb + pt.cnt_off), tau_live + pt.q0,
-                                           tau_base + pt.q0, hist + (size_t)pt.q0 * NB, ksel, st));
-          } }
+                                           tau_base + pt.q0, hist + (size_t)pt.q0 * NB, ksel, st,
+                                           margin ? g->marg + pt.q0 : nullptr, margin ? g->dropflag + pt.q0 : nullptr));
+              if (margin) g->segs[i] = SegSrc{(const uint64_t*)(wsb + pt.seg_off), (const int*)(wsb + pt.cnt_off), pt.splits, pt.q0, pt.nq};
+          }
+          if (margin) { g->nsegs = nparts; g->prelist = prelist; } }
         { ProfScope ps("topk_reduce", st);
           for (int i = 0; i < nparts; ++i) {
               const Part& pt = parts[i];
@@ -926,7 +944,11 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
     // that fails its certificate costs a whole extra pass over the gallery (10 M x 1536: 5.9 ms next to a 7.7 ms scan),
     // and the wider list all but rules that out (the k-th to 64th score gap is 1.6 x the k-th to 32nd) for 0.1 ms of re-scores
     const int ksel = g->size >= SEARCH_WIDE_ROWS ? 64 : search_ksel(k);
-    CHECK_RC(search_candidates(g, queries, Q, ksel, st));
+    // k > 25: 64 candidates leave the certificate less room than its error bound on ordinary data (the 50th-to-64th score
+    // gap of a random 1 M gallery is half of eps), so nearly every query fails it.  The scan then runs with an admission
+    // margin of 2 eps: what an uncertified query needs is in its segments, and no second pass over the gallery is made
+    // (and on very large galleries for every k: there a second pass costs most of a search)
+    CHECK_RC(search_candidates(g, queries, Q, ksel, st, nullptr, 0, k > 25 || g->size >= SEARCH_WIDE_ROWS));
     const CertArgs ca = g->cert_args(nullptr);
     { ProfScope ps("topk_finish", st);
       CHECK_RC(launch_topk_finish(g->cand, g->cand_stride, ksel, g->qf, g->D, g->keep_f32 ? g->gf : nullptr, g->D, g->D, Q, k,
@@ -955,8 +977,9 @@ extern "C" int32_t revo_search_candidates(revo_gallery* g, const float* queries,
         REVO_HIP_CHECK(hipMemsetAsync(bounds, 0, (size_t)Q * top_m * 4, st));
         return 0;
     }
-    // (the published scores come out of the final selection kernel: no launch of their own)
-    return search_candidates(g, queries, Q, ksel, st, bounds, top_m);
+    // (the published scores come out of the final selection kernel: no launch of their own; k > 25: with the admission
+    //  margin, so that the second round the merge's certificate then asks for needs no pass over the shard -- revo_search_topk)
+    return search_candidates(g, queries, Q, ksel, st, bounds, top_m, k > 25);
     API_END
 }
 extern "C" int32_t revo_search_finish(revo_gallery* g, int32_t Q, int32_t k, int32_t has_thr, float thr,
@@ -1000,7 +1023,8 @@ extern "C" int32_t revo_search_exact(revo_gallery* g, int32_t n, const int32_t* 
     if (g->size == 0) return launch_topk_fill_empty(scores, (long long*)indices, counts, n, k, st);
     REVO_REQUIRE(g->keep_f32 && g->xbuf, "search_exact: the gallery was created without the fp32 master copy");
     const CertArgs ca = g->cert_args(nullptr);
-    CHECK_RC(launch_topk_exact_prepare(g->xw, q_idx, need, n, ca, g->D, st));
+    REVO_HIP_CHECK(hipMemsetAsync(g->xw.ctr, 0, 32, st));
+    CHECK_RC(launch_topk_exact_prepare(g->xw, q_idx, need, n, ca, g->D, g->cand, g->cand_stride, g->cand_ksel, st));
     return search_fallback(g, n, k, has_thr, thr, index_offset, 1, scores, (long long*)indices, counts, st);
     API_END
 }
@@ -1012,16 +1036,17 @@ extern "C" int32_t revo_search_set_mode(revo_gallery* g, int32_t mode) {
     return 0;
 }
 #endif
-extern "C" int32_t revo_search_stats(revo_gallery* g, int32_t* out4, void* stream) {
+extern "C" int32_t revo_search_stats(revo_gallery* g, int32_t* out8, void* stream) {
     API_BEGIN
-    REVO_REQUIRE(g && out4, "search_stats: null argument");
-    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    REVO_REQUIRE(g && out8, "search_stats: null argument");
+    int32_t* out4 = out8;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
     if (!g->xbuf) { out4[0] = -1; return 0; }       // no fp32 master rows (or no search yet): nothing was certified
     REVO_ON_DEVICE(g->device);
     int c[8];
     REVO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     REVO_HIP_CHECK(hipMemcpy(c, g->xw.ctr, sizeof(c), hipMemcpyDeviceToHost));
-    out4[0] = c[0] + c[4]; out4[1] = c[1]; out4[2] = c[2]; out4[3] = c[3];
+    out4[0] = c[0] + c[4] + c[5]; out4[1] = c[1]; out4[2] = c[2]; out4[3] = c[3]; out8[4] = c[5];
     return 0;
     API_END
 }

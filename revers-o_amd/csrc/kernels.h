@@ -125,7 +125,8 @@ constexpr int EXACT_L3_SLICES = 32;     // gallery slices of the brute-force pas
 static_assert(EXACT_L3_SLICES * 64 == EXACT_COL_CAP, "the brute-force partial lists live in the collect buffer");
 struct ExactWs {
     int* ctr;            // [0] uncertified queries of this search, [1] of those: collect list overflowed -> brute force,
-                         // [2] queries the certificate was evaluated for, [3] rows collected (all lists), [4..7] spare
+                         // [2] queries the certificate was evaluated for, [3] rows collected (all lists), [4] mode 3: failed
+                         // (counted only), [5] uncertified queries resolved from the scan's segments (numbered from the back)
     int* unc_q;          // [cap] query index of uncertified entry j (or the output row, see out_compact)
     float* unc_lb;       // [cap] bf16-score bound of entry j's collect pass
     bf16_t* qb_u;        // [cap][ldqb] its bf16 query row (compacted: the collect pass reads whole query tiles)
@@ -133,7 +134,12 @@ struct ExactWs {
     int* col_cnt;        // [cap] rows appended to entry j's list (may exceed EXACT_COL_CAP: overflow)
     uint64_t* col;       // [cap][EXACT_COL_CAP] keys (bf16 score, row)
     int* over_j;         // [cap] entries that overflowed
+    int* orow;           // [cap] out_compact results: the output row of entry j (its place in the caller's list)
+    int cap;             // entries the arrays hold.  Entries the finish step fills from the scan's own segments (no gallery
+                         // pass needed) are numbered from the BACK: cap - 1, cap - 2, ...; their count is ctr[5]
 };
+// The scan's segments of one launch part (queries [q0, q0 + nq) of the search): every survivor the scan appended
+struct SegSrc { const uint64_t* seg; const int* cnt; int splits, q0, nq; };
 struct CertArgs {
     const float* qstat;      // [Q][2] (||qb - qf||, ||qb||) from the query normalisation
     const uint32_t* gstat;   // [2] fp32 bit patterns: max ||g||, max ||gb - g|| over the gallery's rows
@@ -143,7 +149,22 @@ struct CertArgs {
     const bf16_t* Qb; long ldq;   // the search's bf16 query rows (source of qb_u)
     float* cert_out;         // row-sharded search: [Q] this shard's bound U + eps for the merge step's certificate (then no
                              // local decision is taken); null otherwise
+    // Resolving an uncertified query WITHOUT another pass over the gallery (nsegs > 0: the scan ran with an admission
+    // margin, launch_topk_scan256): the scan admitted every row scoring at least max(pre-pass bound, bound - marg[q]),
+    // where `bound` is any lower bound of the query's ksel-th best scan score it held at the time -- so every row with
+    // scan score >= max(base, U - marg[q]), U = the ksel-th best scan score, sits in the query's segments (or, a
+    // pre-pass row, in prelist), unless a drain or a recomputed tile touched the query (dropflag).  If the bound the
+    // collect pass would use reaches that level, the finish step fills the entry's list from there.
+    SegSrc segs[2]; int nsegs;
+    int seg_ksel;                // ksel of the scan (segments hold 2 * ksel keys)
+    const uint64_t* prelist;     // [Q][ksel] the pre-pass rows' best keys
+    const uint32_t* tau_base;    // [Q] the pre-pass bound (order-preserving u32)
+    const float* marg;           // [Q] admission margins
+    const int* dropflag;         // [Q] != 0: the query's segments may be incomplete or hold repeated keys
 };
+// marg[q] = 2 eps(q) (+ rounding slack), dropflag[q] = 0: the admission margins of a scan whose uncertified queries are
+// to be resolved from its segments
+int launch_cert_margin(const float* qstat, const uint32_t* gstat, int D, int Q, float* marg, int* dropflag, hipStream_t st);
 // exact fp32 re-score of the ksel candidates of each query, final order (score desc, index asc),
 // threshold cut, write k results.  Gf may be null: then the bf16-scan scores are returned (and nothing is certified).
 // all_bounds (optional): [parts][Q][top_m] order-preserving u32 scores published by every shard of a row-sharded
@@ -185,7 +206,10 @@ int launch_topk_exact_bruteforce(const ExactWs& ws, int max_entries, const float
 // entries from an explicit list (the row-sharded search's second round): entry j = query q_idx[j], collect bound
 // need[j] - eps(query, this gallery); sets ws.ctr[0] = n
 int launch_topk_exact_prepare(const ExactWs& ws, const int* q_idx, const float* need, int n, const CertArgs& cert, int D,
-                              hipStream_t st);
+                              const uint64_t* cand, long cand_stride, int ksel, hipStream_t st);
+// (cand: the handle's candidate lists of the last scan, [Q][cand_stride], best first: with segments to draw from
+//  (cert.nsegs > 0) an entry whose bound they cover is filled from them and numbered from the back, ExactWs::cap;
+//  ws.ctr[0..7] must be zero when this runs)
 // bounds[q][0..top_m) = order-preserving u32 scores of the query's best top_m candidates (0 = none)
 int launch_topk_publish(const uint64_t* part, long part_stride, int Q, int top_m, uint32_t* bounds, hipStream_t st);
 // 256 x 256 tile scan (topk256.hip): survivors are appended to per-(query, slice) segments of 2 * ksel keys and
@@ -204,7 +228,9 @@ unsigned long long* topk_scan256_stats();
 // the pre-pass bound (constant), hist [Q][buckets] zeroed and then seeded by launch_topk_select_rows
 int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
                         int splits, uint64_t* seg, int* seg_cnt, uint32_t* tau_g, const uint32_t* tau_base, uint32_t* hist,
-                        int ksel, hipStream_t st);
+                        int ksel, hipStream_t st, const float* marg = nullptr, int* dropflag = nullptr);
+// marg / dropflag (optional, [Q]): admit every score >= max(pre-pass bound, bound - marg[q]) instead of >= bound, and flag
+// the queries whose segments a drain or a recomputed tile touched (CertArgs: the finish step's segment collect)
 // out[q][ksel] = best ksel distinct keys (sorted, best first) of prelist[q][ksel] and the query's segments;
 // bounds (optional) [Q][top_m]: the order-preserving u32 scan scores of each query's best top_m candidates (what
 // launch_topk_publish writes: the row-sharded search's published admission scores, without a launch of their own)

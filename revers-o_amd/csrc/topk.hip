@@ -310,20 +310,46 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __rest
     const bool certified = (U == -INFINITY || need > U + eps) && cert.mode != 1 && cert.mode != 2;
     if (lane == 0) atomicAdd(cert.ws.ctr + 2, 1);
     if (certified) return;
+    float lb = need - eps;                     // rows that can enter the result have a bf16 score of at least this
+    lb -= fabsf(lb) * 2.4e-7f;                 // (the subtraction's own rounding)
+    // Can the scan's own segments answer?  It admitted every row scoring at least max(base, t - marg) for bounds
+    // t <= U (fl(t - marg) is monotone in t): every row with scan score >= max(base, fl(U - marg)) that is not a
+    // pre-pass row is in the query's segments, and every pre-pass row scoring above `base` is in its pre-pass list.
+    // If `lb` reaches that level, the rows the collect pass would find are all there: no pass over the gallery.
+    const bool from_seg = cert.mode == 0 && ne == ksel && cert_segments_cover(cert, q, lb, U);
     int j = 0;
-    if (lane == 0) j = atomicAdd(cert.ws.ctr + (cert.mode == 3 ? 4 : 0), 1);
+    if (lane == 0) j = atomicAdd(cert.ws.ctr + (cert.mode == 3 ? 4 : (from_seg ? 5 : 0)), 1);
     if (cert.mode == 3) return;                // counted only
     j = __builtin_amdgcn_readfirstlane(j);
+    if (from_seg) j = cert.ws.cap - 1 - j;     // numbered from the back: the collect pass takes the front entries
     if (lane == 0) {
-        float lb = need - eps;                 // rows that can enter the result have a bf16 score of at least this
-        lb -= fabsf(lb) * 2.4e-7f;             // (the subtraction's own rounding)
         cert.ws.unc_q[j] = q;
         cert.ws.unc_lb[j] = need == -INFINITY ? -INFINITY : lb;
-        cert.ws.col_cnt[j] = 0;
+        if (!from_seg) cert.ws.col_cnt[j] = 0;
     }
-    const bf16_t* qs = cert.Qb + (long)q * cert.ldq;
-    bf16_t* qd = cert.ws.qb_u + (long)j * cert.ws.ldqb;
-    for (int c = lane * 8; c < D; c += 512) *(uint4*)(qd + c) = *(const uint4*)(qs + c);
+    if (!from_seg) {
+        const bf16_t* qs = cert.Qb + (long)q * cert.ldq;
+        bf16_t* qd = cert.ws.qb_u + (long)j * cert.ws.ldqb;
+        for (int c = lane * 8; c < D; c += 512) *(uint4*)(qd + c) = *(const uint4*)(qs + c);
+        return;
+    }
+    cert_fill_from_segments(cert, q, lb, j, lane);
+}
+__global__ __launch_bounds__(256) void cert_margin_kernel(const float* __restrict__ qstat, const uint32_t* __restrict__ gstat,
+                                                          int D, int Q, float* __restrict__ marg, int* __restrict__ dropflag) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Q) return;
+    const float eps = cert_eps(qstat[(long)q * 2], qstat[(long)q * 2 + 1], __uint_as_float(gstat[0]), __uint_as_float(gstat[1]), D);
+    // 2 eps: the k-th re-scored score is at least U - eps (each of the ksel candidates scores at least U in the scan), so
+    // the collect bound need - eps is at least U - 2 eps; a little more for the roundings on the way
+    marg[q] = 2.0f * eps * 1.0001f + 1e-7f;
+    dropflag[q] = 0;
+}
+int launch_cert_margin(const float* qstat, const uint32_t* gstat, int D, int Q, float* marg, int* dropflag, hipStream_t st) {
+    if (Q <= 0) return 0;
+    hipLaunchKernelGGL(cert_margin_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, st, qstat, gstat, D, Q, marg, dropflag);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const float* Qf, long ldqf, const float* Gf,
                        long ldgf, int D, int Q, int k, int has_thr, float thr, long idx_offset, const uint32_t* all_bounds,

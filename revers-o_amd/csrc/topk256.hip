@@ -197,14 +197,21 @@ struct S256Lds {
 // least KSEL scores, KSEL distinct gallery rows score at least the lower edge of bucket b: a valid lower
 // bound of the query's final KSEL-th best.  Counts only ever lag (a store may not have landed yet): stale
 // reads give weaker bounds, never wrong ones.  One wave per row, rows strided by 8.
+// the admission score for a (valid) bound t: with a margin, max(pre-pass bound, t - margin) (CertArgs, kernels.h)
+__device__ __forceinline__ float s256_admit(float t, uint32_t base, float mg) {
+    return mg > 0.f ? fmaxf(orderable_f32(base), t - mg) : t;
+}
 template <int KSEL>
 __device__ __noinline__ void s256_refresh_hist(const S256Lds& L, const uint32_t* hist, const uint32_t* tau_g, int q0,
-                                               int qvalid, int tid) {
+                                               int qvalid, int tid, const float* marg) {
     const int wave = tid >> 6, lane = tid & 63;
     // the drain-published bounds of this wave's 32 rows (rows wave + 8 i), one per lane
     uint32_t tgv = 0u;
-    if (lane < 32 && wave + 8 * lane < qvalid)
+    float mgv = 0.f;
+    if (lane < 32 && wave + 8 * lane < qvalid) {
         tgv = __hip_atomic_load(tau_g + q0 + wave + 8 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (marg) mgv = marg[q0 + wave + 8 * lane];
+    }
     // all 32 rows' counters are requested before any is used: one L2 round trip per refresh, not one per batch
     uint32_t h[32];
 #pragma unroll
@@ -231,6 +238,7 @@ __device__ __noinline__ void s256_refresh_hist(const S256Lds& L, const uint32_t*
                 const float th = orderable_f32(L.base[r] + ((uint32_t)b << S256_SH));
                 t = th > t ? th : t;
             }
+            t = s256_admit(t, L.base[r], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mgv), u)));
             if (t > L.tau[r]) L.tau[r] = t;
         }
     }
@@ -242,7 +250,7 @@ __device__ __noinline__ void s256_refresh_hist(const S256Lds& L, const uint32_t*
 // keys: those go back to the head of the segment (sorted, best first), the rest of it is free again.
 template <int KSEL>
 __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* seg0, long seg_row_stride, int q0, int qvalid,
-                                        uint32_t idx_base, int tid, uint32_t* tau_g) {
+                                        uint32_t idx_base, int tid, uint32_t* tau_g, const float* marg, int* dropflag) {
     constexpr int SEG = 2 * KSEL;
     const int wave = tid >> 6, lane = tid & 63;
     // The segments were written by other waves of this workgroup since this CU last read them (appends by the
@@ -325,9 +333,12 @@ __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* seg0, long s
                 // this slice's KSEL-th best is a lower bound of the query's final KSEL-th best: publish it
                 const uint32_t lo = (uint32_t)(last >> 32);
                 (void)__hip_atomic_fetch_max(tau_g + q0 + r, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float t = orderable_f32(lo);
+                const float t = s256_admit(orderable_f32(lo), L.base[r], marg ? marg[q0 + r] : 0.f);
                 if (t > L.tau[r]) L.tau[r] = t;
             }
+            // a drained segment keeps its best KSEL keys only, and from here on the row admits against them: rows inside
+            // the admission margin are no longer all kept
+            if (dropflag) dropflag[q0 + r] = 1;
         }
     }
     __syncthreads();
@@ -347,6 +358,8 @@ struct Scan256Args {
     uint32_t* tau_g;              // [Q] shared admission scores (order-preserving u32), seeded by the pre-pass, raised by drains
     const uint32_t* tau_base;     // [Q] the pre-pass bound, constant during the scan: origin of the histogram buckets
     uint32_t* hist;               // [Q][S256_NB] score histogram shared by all slices (seeded with the pre-pass list)
+    const float* marg;            // [Q] admission margins (null: none): every score >= max(pre-pass bound, bound - marg) is kept
+    int* dropflag;                // [Q] set when a drain or a recomputed tile touched the query's segments (with marg)
     int dbg;                      // timing experiments only (REVO_EXPERIMENTS): 1 = skip the selection, 4 = skip the slow path, 8 = no global stores / atomics from the selection, 16 = no refreshes (wrong results)
     unsigned long long* stats;    // optional counters (REVO_EXPERIMENTS): [0] drains, [1] queued entries, [2] retry passes, [3] fragments scanned slowly, [4] appended entries, [5] refreshes
 };
@@ -400,8 +413,9 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     uint32_t* myhist = p.hist + (long)q0 * S256_NB;
 
     if (tid < 256) {
-        L.tau[tid] = tid < qvalid ? orderable_f32(p.tau_g[q0 + tid]) : INFINITY;
-        L.base[tid] = tid < qvalid ? p.tau_base[q0 + tid] : 0u;
+        const uint32_t b0 = tid < qvalid ? p.tau_base[q0 + tid] : 0u;
+        L.tau[tid] = tid < qvalid ? s256_admit(orderable_f32(p.tau_g[q0 + tid]), b0, p.marg ? p.marg[q0 + tid] : 0.f) : INFINITY;
+        L.base[tid] = b0;
         L.wkey[tid] = 0ull;
         L.cnt[tid] = 0;
     }
@@ -421,7 +435,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     // slice's first tile admitted about one score per row: at 24 tiles per slice a third of all slow fragments.)
     if (!(p.dbg & 17)) {
         if (p.stats && tid == 0) atomicAdd(p.stats + 5, 1ull);
-        s256_refresh_hist<KSEL>(L, p.hist, p.tau_g, q0, qvalid, tid);
+        s256_refresh_hist<KSEL>(L, p.hist, p.tau_g, q0, qvalid, tid, p.marg);
     }
 
     // Normal mode: one pass per tile (groups == 1).  If a pass pushes more entries to the overflow queue than
@@ -536,8 +550,10 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
                 if (slot < SEG) {
                     if (!(p.dbg & 8)) {
                         myseg[(long)row * seg_row_stride + slot] = s256_entry_to_key(e, idx_base);
-                        if (groups == 1) {                     // a recomputed tile must not be counted twice
-                            uint32_t b = ((uint32_t)(e >> 24) - s256_lds_u32(S256_BASE_OFF + row * 4)) >> S256_SH;
+                        const uint32_t so = (uint32_t)(e >> 24), bo = s256_lds_u32(S256_BASE_OFF + row * 4);
+                        if (groups == 1 && so >= bo) {         // a recomputed tile must not be counted twice; a score admitted
+                                                               // by the margin only lies below the histogram's origin
+                            uint32_t b = (so - bo) >> S256_SH;
                             b = b < (uint32_t)(S256_NB - 1) ? b : (uint32_t)(S256_NB - 1);
                             (void)__hip_atomic_fetch_add(myhist + (long)row * S256_NB + b, 1u, __ATOMIC_RELAXED, S256_HIST_SCOPE);
                         }
@@ -558,20 +574,22 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
         }
         if (groups == 1 && !overflow) {
             if (qc >= S256_DRAIN || (t + 1 >= t1 && qc > 0))
-                s256_drain<KSEL>(L, myseg, seg_row_stride, q0, qvalid, idx_base, tid, p.tau_g);
+                s256_drain<KSEL>(L, myseg, seg_row_stride, q0, qvalid, idx_base, tid, p.tau_g, p.marg, p.dropflag);
             // what all slices of these queries have learnt meanwhile: after the first two tiles (the bound moves
             // fastest early on: it follows KSEL / rows seen), then every fourth tile, every 16th from tile 32 on
             // (each refresh is an L2 round trip plus ~3 us of wave scans)
             const long tl = t - t0;
             if (t + 1 < t1 && !(p.dbg & 17) && (tl < 2 || ((tl & 3) == 3 && tl < 32) || (tl & 15) == 15)) {
                 if (p.stats && tid == 0) atomicAdd(p.stats + 5, 1ull);
-                s256_refresh_hist<KSEL>(L, p.hist, p.tau_g, q0, qvalid, tid);
+                s256_refresh_hist<KSEL>(L, p.hist, p.tau_g, q0, qvalid, tid, p.marg);
             }
             ++t;
             continue;
         }
         // retry mode (or entering it): merge what was queued, then recompute this tile / its next column group
-        s256_drain<KSEL>(L, myseg, seg_row_stride, q0, qvalid, idx_base, tid, p.tau_g);
+        s256_drain<KSEL>(L, myseg, seg_row_stride, q0, qvalid, idx_base, tid, p.tau_g, p.marg, p.dropflag);
+        // a recomputed tile appends its survivors a second time: these queries' segments may hold repeated keys
+        if (p.dropflag && tid < qvalid) p.dropflag[q0 + tid] = 1;
         if (overflow) {
             groups = groups < S256_MAXGROUPS ? groups * 2 : S256_MAXGROUPS;
             grp = 0;
@@ -710,7 +728,7 @@ int topk_scan256_hist_shift() { return S256_SH; }
 
 int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
                         int splits, uint64_t* seg, int* seg_cnt, uint32_t* tau_g, const uint32_t* tau_base, uint32_t* hist,
-                        int ksel, hipStream_t st) {
+                        int ksel, hipStream_t st, const float* marg, int* dropflag) {
     REVO_REQUIRE(ksel == 32 || ksel == 64, "search: the 256 x 256 scan keeps 32 or 64 candidates per query");
     REVO_REQUIRE(D % 64 == 0 && ldq % 8 == 0 && ldg % 8 == 0, "search: D must be a multiple of 64");
     REVO_REQUIRE(N < (1ll << 32), "search: a shard holds at most 2^32 rows");
@@ -722,7 +740,7 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
     if (Q <= 0 || N <= n_begin) return 0;
     const int qtiles = (Q + 255) / 256;
     const int qt_pad = qtiles >= 8 ? (qtiles + 7) / 8 * 8 : qtiles;
-    Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, qt_pad, seg, seg_cnt, tau_g, tau_base, hist, g_scan_dbg,
+    Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, qt_pad, seg, seg_cnt, tau_g, tau_base, hist, marg, dropflag, g_scan_dbg,
                   (g_scan_dbg & 2) ? topk_scan256_stats() : nullptr};
     const dim3 grid((unsigned)((long)qt_pad * splits)), block(G256_THREADS);
 #define S256_LAUNCH(KS, RW)                                                                                    \

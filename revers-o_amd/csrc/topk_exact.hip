@@ -45,8 +45,10 @@ __global__ __launch_bounds__(XF_WAVES * 64) void topk_exact_finish_kernel(ExactW
                                                                           int* __restrict__ out_counts) {
     __shared__ uint64_t partial[XF_WAVES][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int entries = ws.ctr[0];
-    for (int j = blockIdx.x; j < entries; j += gridDim.x) {
+    // entries 0 .. ctr[0] - 1 were filled by the collect pass, cap - 1 .. cap - ctr[5] by the finish step from the scan's segments
+    const int nfront = ws.ctr[0], entries = nfront + ws.ctr[5];
+    for (int jj = blockIdx.x; jj < entries; jj += gridDim.x) {
+    const int j = jj < nfront ? jj : ws.cap - 1 - (jj - nfront);
     const int n = ws.col_cnt[j];
     if (n > EXACT_COL_CAP || force_bruteforce) {
         if (threadIdx.x == 0) ws.over_j[atomicAdd(ws.ctr + 1, 1)] = j;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(XF_WAVES * 64) void topk_exact_finish_kernel(ExactW
             const uint64_t rev = partial[o][63 - lane];
             run = wave_bitonic_merge_desc(run > rev ? run : rev, lane);
         }
-        exact_write(run, lane, out_compact ? (long)j : (long)q, k, has_thr, thr, idx_offset, out_scores, out_idx, out_counts);
+        exact_write(run, lane, out_compact ? (long)ws.orow[j] : (long)q, k, has_thr, thr, idx_offset, out_scores, out_idx, out_counts);
     }
     __syncthreads();                           // `partial` is reused by the next entry
     }
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void topk_exact_bruteforce_final_kernel(ExactW
         const uint64_t rev = lists[s * 64 + 63 - lane];
         run = wave_bitonic_merge_desc(run > rev ? run : rev, lane);
     }
-    exact_write(run, lane, out_compact ? (long)j : (long)ws.unc_q[j], k, has_thr, thr, idx_offset, out_scores, out_idx,
+    exact_write(run, lane, out_compact ? (long)ws.orow[j] : (long)ws.unc_q[j], k, has_thr, thr, idx_offset, out_scores, out_idx,
                 out_counts);
     }
 }
@@ -188,30 +190,44 @@ int launch_topk_exact_bruteforce(const ExactWs& ws, int max_entries, const float
 
 // ------------------------------------------------- entries from an explicit list ----
 __global__ __launch_bounds__(256) void topk_exact_prepare_kernel(ExactWs ws, const int* __restrict__ q_idx,
-                                                                 const float* __restrict__ need, int n, CertArgs cert, int D) {
+                                                                 const float* __restrict__ need, int n, CertArgs cert, int D,
+                                                                 const uint64_t* __restrict__ cand, long cand_stride, int ksel) {
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ws.ctr[0] = n; ws.ctr[1] = 0; }
-    if (j >= n) return;
-    const int q = q_idx[j];
-    if (lane == 0) {
-        const float G = __uint_as_float(cert.gstat[0]), Eg = __uint_as_float(cert.gstat[1]);
-        const float eps = cert_eps(cert.qstat[(long)q * 2], cert.qstat[(long)q * 2 + 1], G, Eg, D);
-        const float nd = need[j];
-        float lb = nd - eps;
-        lb -= fabsf(lb) * 2.4e-7f;
-        ws.unc_q[j] = q;
-        ws.unc_lb[j] = nd == -INFINITY ? -INFINITY : lb;
-        ws.col_cnt[j] = 0;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);        // place in the caller's list = output row
+    if (i >= n) return;
+    const int q = q_idx[i];
+    const float G = __uint_as_float(cert.gstat[0]), Eg = __uint_as_float(cert.gstat[1]);
+    const float eps = cert_eps(cert.qstat[(long)q * 2], cert.qstat[(long)q * 2 + 1], G, Eg, D);
+    const float nd = need[i];
+    float lb = nd - eps;
+    lb -= fabsf(lb) * 2.4e-7f;
+    if (nd == -INFINITY) lb = -INFINITY;
+    // the scan's segments answer if they hold every row at or above lb (topk_util.h); U = this shard's ksel-th best scan score
+    bool from_seg = false;
+    if (cert.mode == 0 && cert.nsegs > 0 && cand) {
+        const uint64_t last = cand[(long)q * cand_stride + ksel - 1];
+        from_seg = last != 0ull && cert_segments_cover(cert, q, lb, key_score(last));
     }
+    int j = 0;
+    if (lane == 0) j = atomicAdd(ws.ctr + (from_seg ? 5 : 0), 1);
+    j = __builtin_amdgcn_readfirstlane(j);
+    if (from_seg) j = ws.cap - 1 - j;
+    if (lane == 0) {
+        ws.unc_q[j] = q;
+        ws.unc_lb[j] = lb;
+        ws.orow[j] = i;
+        if (!from_seg) ws.col_cnt[j] = 0;
+    }
+    if (from_seg) { cert_fill_from_segments(cert, q, lb, j, lane); return; }
     const bf16_t* qs = cert.Qb + (long)q * cert.ldq;
     bf16_t* qd = ws.qb_u + (long)j * ws.ldqb;
     for (int c = lane * 8; c < D; c += 512) *(uint4*)(qd + c) = *(const uint4*)(qs + c);
 }
 int launch_topk_exact_prepare(const ExactWs& ws, const int* q_idx, const float* need, int n, const CertArgs& cert, int D,
-                              hipStream_t st) {
-    hipLaunchKernelGGL(topk_exact_prepare_kernel, dim3((unsigned)((n > 0 ? n : 1) + 3) / 4), dim3(256), 0, st, ws, q_idx, need, n,
-                       cert, D);
+                              const uint64_t* cand, long cand_stride, int ksel, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(topk_exact_prepare_kernel, dim3((unsigned)(n + 3) / 4), dim3(256), 0, st, ws, q_idx, need, n,
+                       cert, D, cand, cand_stride, ksel);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -3,6 +3,7 @@
 // RETURNED is computed, so the fast path, the collect path and the brute-force path give the same bits).
 #pragma once
 #include "common.h"
+#include "kernels.h"
 
 namespace revo {
 
@@ -90,6 +91,54 @@ __device__ __forceinline__ void exact_dot4(const float* __restrict__ qr, const f
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) out[u] = wave_sum(acc[u]);
+}
+
+// ------------------------------------- uncertified queries answered by the scan's own segments (CertArgs, kernels.h) ----
+// Can the segments of query q hold every row whose scan score reaches lb?  The scan admitted every row scoring at least
+// max(base, fl(t - marg)) for bounds t <= U (U = the query's ksel-th best scan score; fl(t - marg) is monotone in t), so
+// every row at or above max(base, fl(U - marg)) that is not a pre-pass row is in the segments, and every pre-pass row
+// scoring above `base` is in the pre-pass list -- unless a drain or a recomputed tile touched the query (dropflag).
+__device__ __forceinline__ bool cert_segments_cover(const CertArgs& cert, int q, float lb, float U) {
+    if (cert.nsegs <= 0 || !(U > -INFINITY) || !(lb > -INFINITY)) return false;
+    const float basef = orderable_f32(cert.tau_base[q]);
+    return lb > basef && lb >= U - cert.marg[q] && cert.dropflag[q] == 0;
+}
+// One wave: entry j's list := every key of query q's pre-pass list and segments whose scan score reaches lb.
+__device__ __forceinline__ void cert_fill_from_segments(const CertArgs& cert, int q, float lb, int j, int lane) {
+    const SegSrc sg = (cert.nsegs > 1 && q >= cert.segs[1].q0) ? cert.segs[1] : cert.segs[0];
+    const int SEG = 2 * cert.seg_ksel;
+    const long ql = q - sg.q0;
+    const int* cq = sg.cnt + ql * sg.splits;
+    const uint64_t* sq = sg.seg + ql * (long)sg.splits * SEG;
+    uint64_t* col = cert.ws.col + (long)j * EXACT_COL_CAP;
+    const uint32_t lbk = f32_orderable(lb);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int n = 0;                                 // wave-uniform
+    {
+        const uint64_t pk = lane < cert.seg_ksel ? cert.prelist[(long)q * cert.seg_ksel + lane] : 0ull;
+        const bool take = pk != 0ull && (uint32_t)(pk >> 32) >= lbk;
+        const unsigned long long m = __ballot(take);
+        if (take) col[__popcll(m & below)] = pk;
+        n = __popcll(m);
+    }
+    for (int sb = 0; sb < sg.splits; sb += 64) {
+        const int my = sb + lane;
+        int c = my < sg.splits ? cq[my] : 0;
+        c = c < SEG ? c : SEG;
+        int mc = c;                            // the longest of these 64 segments
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mc, o, 64); mc = mc > t ? mc : t; }
+        for (int e = 0; e < mc; ++e) {
+            const uint64_t key = e < c ? sq[(long)my * SEG + e] : 0ull;
+            const bool take = key != 0ull && (uint32_t)(key >> 32) >= lbk;
+            const unsigned long long m = __ballot(take);
+            if (m == 0ull) continue;
+            const int pos = n + __popcll(m & below);
+            if (take && pos < EXACT_COL_CAP) col[pos] = key;
+            n += __popcll(m);
+        }
+    }
+    if (lane == 0) cert.ws.col_cnt[j] = n;     // more than the list holds: the exact finish passes the entry on (brute force)
 }
 
 }  // namespace revo

@@ -260,10 +260,11 @@ class Gallery:
 
     def search_stats(self):
         """Counters of the last search on this handle (synchronises the current stream)."""
-        out = (C.c_int32 * 4)()
+        out = (C.c_int32 * 8)()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.revo_search_stats(self._h, out, _lib.current_stream()), "revo_search_stats")
-        return {"uncertified": int(out[0]), "bruteforced": int(out[1]), "checked": int(out[2]), "collected_rows": int(out[3])}
+        return {"uncertified": int(out[0]), "bruteforced": int(out[1]), "checked": int(out[2]), "collected_rows": int(out[3]),
+                "from_segments": int(out[4])}
 
     def search_plan(self, n_queries, k=5):
         """How a search would run (reporting): dict with the scan form, the pre-pass rows, slices and ksel."""

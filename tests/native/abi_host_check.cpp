@@ -126,7 +126,7 @@ int main() {
             EXPECT(revo_search_topk(g, v, 1, 51, 0, 0.f, 0, s, i, cnt, nullptr) == -2);
             EXPECT(revo_search_finish(g, 3, 5, 0, 0.f, 0, nullptr, 0, 0, s, i, cnt, nullptr, nullptr) == -2 && err_has("no matching"));
             EXPECT(revo_gallery_read(g, 0, 1, v, 0) == -2 && err_has("outside"));
-            int32_t st4[4] = {7, 7, 7, 7};
+            int32_t st4[8] = {7, 7, 7, 7, 7, 7, 7, 7};
             EXPECT(revo_search_stats(g, st4, nullptr) == 0 && st4[0] == -1 && st4[1] == 0);      // no search yet
             int32_t qi[1] = {0}; float nd[1] = {0.f};
             EXPECT(revo_search_exact(g, 2, qi, nd, 5, 0, 0.f, 0, s, i, cnt, nullptr) == -2 && err_has("more entries"));

@@ -742,3 +742,85 @@ def test_collect_pass_appends_every_row_once_when_its_retry_ladder_deepens(dev, 
     for q in range(Q - 3):
         assert i[q].cpu().tolist() == want, (q, i[q].cpu().tolist())
     _check((s, i, c), osearch.search(gal, qr, k), atol=1e-5, near_tie=3e-7)
+
+
+@pytest.mark.parametrize("Q", [3, 70, 300])
+def test_k50_is_resolved_from_the_scans_own_segments(dev, Q):
+    """limit 50 (ui.py:342) on an ordinary gallery: 64 candidates leave the certificate less room (the 50th-to-64th score
+    gap) than its error bound, so nearly every query fails it.  The scan runs with an admission margin of 2 eps for
+    k > 25: everything an uncertified query can need is already in its segments, the exact finish re-scores that, and
+    NO second pass over the gallery is made (from_segments == uncertified) -- with the exhaustive fp32 result, bit for
+    bit, and the oracle's ranking."""
+    N, D, k = 262144 + 777, 1024, 50
+    g = torch.Generator(device=dev).manual_seed(77 + Q)
+    G = engine.Gallery(D, N, device=0)
+    for s0 in range(0, N, 65536):
+        G.add(torch.randn(min(65536, N - s0), D, generator=g, device=dev))
+    q = torch.randn(Q, D, generator=g, device=dev)
+    q[0] = G.read(N // 2, 1)[0] + 0.05 * torch.randn(D, generator=g, device=dev)      # one planted neighbour
+    for thr in (None, 0.08):
+        out = G.search(q, k, thr)
+        st = G.search_stats()
+        assert st["checked"] == Q and st["uncertified"] >= (Q * 3) // 4, st          # the certificate does fail here
+        assert st["from_segments"] == st["uncertified"] and st["bruteforced"] == 0, st
+        assert st["collected_rows"] >= 50 * st["uncertified"], st
+        Gx = _bruteforce_twin(G)
+        ref = Gx.search(q, k, thr)
+        Gx.close()
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+    assert int(out[1][0, 0]) == N // 2
+    # k <= 25 keeps the plain scan (no margin): certified by the first pass on this gallery
+    G.search(q, 20)
+    st = G.search_stats()
+    assert st["from_segments"] == 0 and st["uncertified"] <= max(1, Q // 20), st
+    # the fp64 oracle over all rows for a few of the queries
+    n16 = min(Q, 8)
+    chunks = ((s0, G.read(s0, min(65536, N - s0)).cpu().numpy()) for s0 in range(0, N, 65536))
+    rs, ri, rc = osearch.search_chunked(chunks, q[:n16].cpu().numpy(), k)
+    gs, gi, gc = (t.cpu().numpy() for t in G.search(q[:n16], k))
+    assert np.array_equal(gc, rc) and np.abs(gs - rs).max() <= 1e-5
+    _assert_indices_equal_up_to_fp32_ties(gi, ri, rs, lambda r: G.read(r, 1).cpu().numpy()[0], q[:n16].cpu().numpy(), tie=6e-7)
+    G.close()
+
+
+@pytest.mark.parametrize("P,min_second_round", [(2, 24), (8, 1)])
+def test_sharded_k50_second_round_draws_on_the_shards_segments(dev, P, min_second_round):
+    """k = 50 over the shards of an ordinary gallery: the merge's certificate fails (two shards together re-score little
+    more than 64 rows per query -- too few, as on one GPU -- so it fails for most queries; eight shards publish eight
+    scores each, re-score about a hundred rows between them and fail for a few), so the protocol's second round runs --
+    and every shard answers it from what its scan kept under the admission margin (from_segments), not by another pass
+    over its rows.  Merged result == the unsharded search == the exhaustive fp32 scoring, bit for bit."""
+    from reverso_amd import sharded
+    N, D, Q, k = 8 * 40000, 1024, 48, 50
+    g = torch.Generator(device=dev).manual_seed(5150)
+    G = engine.Gallery(D, N, device=0)
+    for s0 in range(0, N, 40000):
+        G.add(torch.randn(40000, D, generator=g, device=dev))
+    shards = []
+    for p in range(P):
+        Gp = engine.Gallery(D, N // P, device=0)
+        Gp.add(G.read(p * (N // P), N // P), normalize=False)
+        shards.append(Gp)
+    q = torch.randn(Q, D, generator=g, device=dev)
+    ls = sharded.LocalShards.from_galleries(shards)
+    for thr in (None, 0.07):
+        ref = G.search(q, k, thr)
+        st = G.search_stats()
+        assert st["uncertified"] >= Q // 2 and st["from_segments"] == st["uncertified"], st
+        out = ls.search(q, k, thr)
+        n2 = ls.last_uncertified
+        assert n2 >= min_second_round                         # the second round did run
+        for Gp in shards:
+            sp = Gp.search_stats()                            # the shard's counters of that round
+            assert sp["from_segments"] == n2 and sp["bruteforced"] == 0, sp
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+    Gx = _bruteforce_twin(G)
+    bf = Gx.search(q, k, 0.07)
+    Gx.close()
+    for a, b in zip(ref, bf):
+        assert torch.equal(a, b)
+    for Gp in shards:
+        Gp.close()
+    G.close()
