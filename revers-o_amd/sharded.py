@@ -93,9 +93,14 @@ class ShardedSearch:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.local_rows = int(local_rows)
-        self.last_uncertified = 0          # queries of the last search that needed the second round
+        self.last_uncertified = 0          # queries of the last finished search that needed the second round
+        self._gen = 0                      # searches started (whose candidates the shard handle holds: PendingSearch)
+        self._pinned = None                # host landing places of the uncertified counts (search_async)
         self._gbuf = {}                    # gather targets, reused from search to search
         self.offset, self.total_rows = self._exchange_offsets()
+        if torch.cuda.is_available():
+            self._pinned = [torch.zeros((1,), dtype=torch.int32).pin_memory() for _ in range(8)]
+        self._inflight = [None] * 8
 
     def _gather_buf(self, tag, shape, dtype, device):
         key = (tag, tuple(shape), dtype)
@@ -159,10 +164,20 @@ class ShardedSearch:
 
     def search(self, queries, k, threshold=None):
         """queries: identical [Q, D] on every rank.  Returns the global top-k triple on every rank."""
+        return self.search_async(queries, k, threshold).result()
+
+    def search_async(self, queries, k, threshold=None):
+        """The same search with its one host decision deferred: everything of the first round (scan, both exchanges,
+        merge with the cross-shard certificate) is enqueued and a :class:`PendingSearch` comes back at once;
+        ``result()`` waits for the count of uncertified queries and, only if there are any, runs the second round.
+        A caller with a stream of query batches enqueues batch i + 1 before asking for batch i's result: the device never
+        waits for the host between searches (``search()`` = ``search_async().result()`` does, once per call).
+        Every rank must issue the same calls in the same order (the collectives are matched by order)."""
         Q = queries.shape[0]
         top_m = self.top_m(k)
         if self.world == 1:
-            return self.backend.search(queries, k, threshold)                    # one shard: the plain single-GPU search
+            return PendingSearch(self, self.backend.search(queries, k, threshold), None, None, queries, k, threshold, 0)
+        self._gen += 1                                                           # the shard handle's candidates are this search's now
         mine = self.backend.candidates(queries, k, top_m)                        # [Q, top_m] int32
         allb = self._gather_buf("bounds", (self.world * Q, top_m), mine.dtype, mine.device)
         self._all_gather(allb, mine)                                             # exchange 1: admission scores
@@ -170,21 +185,69 @@ class ShardedSearch:
         allp = self._gather_buf("packed", (self.world * packed.numel(),), torch.uint8, packed.device)
         self._all_gather(allp, packed)                                           # exchange 2: packed per-rank top-k
         scores, idx, counts, unc = self.backend.merge(allp, self.world, Q, k, threshold, certify=True)
-        n = int(unc[0].item())                                                   # identical on every rank
-        self.last_uncertified = n
-        if n > 0:
-            # second round: the uncertified queries, in one canonical order on every rank, exactly on every shard
-            qs, order = torch.sort(unc[1][:n])
-            need = unc[2][:n][order].contiguous()
-            packed2 = self.backend.exact(qs.contiguous(), need, k, self.offset)
-            allp2 = torch.empty((self.world * packed2.numel(),), dtype=torch.uint8, device=packed2.device)
-            self._all_gather(allp2, packed2)                                     # exchange 3 (rare)
-            s2, i2, c2 = self.backend.merge(allp2, self.world, n, k, threshold)
-            rows = qs.long()
-            scores[rows] = s2
-            idx[rows] = i2
-            counts[rows] = c2
+        host_n, ev = None, None
+        if unc[0].is_cuda:
+            # the count goes to pinned host memory behind the merge; nobody waits for it here
+            slot = self._gen % len(self._pinned)
+            if self._inflight[slot] is not None:
+                self._inflight[slot].result()        # eight searches back and never asked for: finish it before its landing place is reused
+            host_n = self._pinned[slot]
+            host_n.copy_(unc[0], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            p = PendingSearch(self, (scores, idx, counts), unc, (host_n, ev), queries, k, threshold, self._gen)
+            self._inflight[slot] = p
+            return p
+        return PendingSearch(self, (scores, idx, counts), unc, (host_n, ev), queries, k, threshold, self._gen)
+
+    def _second_round(self, res, unc, n, k, threshold):
+        """The uncertified queries (identical on every rank: same merged data), in one canonical order, exactly on every shard."""
+        scores, idx, counts = res
+        qs, order = torch.sort(unc[1][:n])
+        need = unc[2][:n][order].contiguous()
+        packed2 = self.backend.exact(qs.contiguous(), need, k, self.offset)
+        allp2 = torch.empty((self.world * packed2.numel(),), dtype=torch.uint8, device=packed2.device)
+        self._all_gather(allp2, packed2)                                         # exchange 3 (rare)
+        s2, i2, c2 = self.backend.merge(allp2, self.world, n, k, threshold)
+        rows = qs.long()
+        scores[rows] = s2
+        idx[rows] = i2
+        counts[rows] = c2
         return scores, idx, counts
+
+
+class PendingSearch:
+    """A sharded search whose first round is enqueued (ShardedSearch.search_async)."""
+
+    def __init__(self, owner, res, unc, host, queries, k, threshold, gen):
+        self._owner, self._res, self._unc, self._host = owner, res, unc, host
+        self._queries, self._k, self._thr, self._gen = queries, k, threshold, gen
+        self._done = unc is None
+
+    def result(self):
+        """(scores, indices, counts), final: certified exact, or re-done exactly by the second round."""
+        if self._done:
+            return self._res
+        o = self._owner
+        host_n, ev = self._host
+        if ev is not None:
+            ev.synchronize()
+            n = int(host_n[0])
+        else:
+            n = int(self._unc[0][0])                                             # CPU backends (tests)
+        o.last_uncertified = n
+        if n > 0:
+            if o._gen == self._gen:
+                self._res = o._second_round(self._res, self._unc, n, self._k, self._thr)
+            else:
+                # another search has used the shard handle since (its candidates are gone): the whole search again, in step
+                self._res = o.search(self._queries, self._k, self._thr)
+        self._done = True
+        if ev is not None:
+            slot = self._gen % len(o._inflight)
+            if o._inflight[slot] is self:
+                o._inflight[slot] = None
+        return self._res
 
 
 class LocalShards:

@@ -184,6 +184,15 @@ def _shard_worker(rank, world, port, tmp, N, D, Q, k, noise=0.0):
     # a noisy scan (the bf16 scan's stand-in) must have sent some queries, not all, through the second, exact round;
     # an exact scan sends only queries whose k-th place ties with the candidate list's last (none here)
     assert (second_rounds > 0 and backend.exact_calls > 0) if noise > 0 else (second_rounds == 0 and backend.exact_calls == 0)
+    # pipelined form: the next search is started before the previous one's result is asked for (no host wait between
+    # searches).  A pending search whose shard state has been overwritten meanwhile re-does itself in step on every
+    # rank if it needs the second round; same answers either way.
+    pend = [ss.search_async(allq, k, thr) for thr in (None, 0.05)]
+    for thr, p in zip((None, 0.05), pend):
+        s, i, c = p.result()
+        assert np.array_equal(i.numpy(), out[str(thr)][1]) and np.array_equal(c.numpy(), out[str(thr)][2])
+        assert np.array_equal(s.numpy(), out[str(thr)][0])
+        assert p.result()[1] is i                                # a finished search hands back the same tensors
     np.savez(os.path.join(tmp, f"rank{rank}.npz"), **{f"{t}_{n}": v for t, (a, b, c) in out.items()
                                                         for n, v in (("s", a), ("i", b), ("c", c))})
     dist.barrier()
