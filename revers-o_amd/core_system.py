@@ -114,14 +114,20 @@ class SimpleReverso:
         """core_system.py:74-88"""
         if not os.path.exists(self.db_root):
             return []
+        for n in os.listdir(self.db_root):              # a crash inside the final swap of a build: put the database back
+            for suf in (BUILDING, ".old"):
+                if n.endswith(suf):
+                    st.recover(os.path.join(self.db_root, n[: -len(suf)]), BUILDING)
         return [n for n in os.listdir(self.db_root)
-                if os.path.isdir(os.path.join(self.db_root, n)) and n != "checkpoints" and not n.endswith(BUILDING)]
+                if os.path.isdir(os.path.join(self.db_root, n)) and n != "checkpoints" and not n.endswith(BUILDING)
+                and not n.endswith(".old")]
 
     def load_database(self, database_name):
         """core_system.py:90-119"""
         if not database_name:
             return "❌ Please provide a database name"
         db_path = os.path.join(self.db_root, database_name)
+        st.recover(db_path, BUILDING)
         if not os.path.exists(db_path):
             return f"❌ Database not found: {database_name}"
         try:
@@ -145,6 +151,10 @@ class SimpleReverso:
             return f"❌ Database not found: {database_name}"
         try:
             shutil.rmtree(db_path)
+            # an unfinished build of the same name and its checkpoint note go with it
+            shutil.rmtree(db_path + BUILDING, ignore_errors=True)
+            shutil.rmtree(db_path + ".old", ignore_errors=True)
+            st.remove_checkpoint(os.path.join(self.db_root, "checkpoints", f"{database_name}_checkpoint"))
             return f"✅ Deleted database: {database_name}"
         except Exception as e:
             return f"❌ Error deleting database: {str(e)}"
@@ -374,9 +384,19 @@ class SimpleReverso:
         self._partial_embeddings, self._partial_metadata = [], []          # (kept for callers that look at them: always empty now)
         build_path = db_path + BUILDING
         self._build_store = None
+        build_info = self._build_info(folder_path, use_direct_pe, include_subfolders)
         if resume_from_checkpoint and os.path.exists(os.path.join(build_path, st.MANIFEST)):
             try:
-                self._build_store = st.GalleryStore.load(build_path, device=self.device.index or 0, allow_partial=True)
+                header = st.read_manifest(os.path.join(build_path, st.MANIFEST))[0]
+                diff = [k for k in build_info if header.get("build", {}).get(k) != build_info[k]]
+                if header.get("dim") != self.pe_model.cfg.out_dim:
+                    diff.append("dim")
+                if diff:
+                    # another folder, model or mode: its rows must not be mixed with this build's
+                    raise ValueError(f"the unfinished build was made with a different {', '.join(diff)}")
+                n_files = len(os.listdir(folder_path)) if os.path.isdir(folder_path) else 0
+                self._build_store = st.GalleryStore.load(build_path, device=self.device.index or 0, allow_partial=True,
+                                                         capacity=n_files)        # room for the rest: no regrow right away
                 processed_files = set(self._build_store.files_done)
                 log_status(f"📋 Resuming from checkpoint: {len(processed_files)} files already processed")
             except Exception as e:
@@ -393,6 +413,12 @@ class SimpleReverso:
             if self._build_store is not None:               # stopped or failed: the shards on disk are the checkpoint
                 self._build_store.close()
                 self._build_store = None
+
+    def _build_info(self, folder_path, use_direct_pe, include_subfolders):
+        """What a collection is made from and how: written into the build's manifest header, compared on resume."""
+        return {"folder_path": os.path.abspath(folder_path), "model": self.pe_model.cfg.name,
+                "use_ls": bool(self.pe_model.cfg.use_ls), "region_mode": self.region_mode,
+                "use_direct_pe": bool(use_direct_pe), "include_subfolders": bool(include_subfolders)}
 
     def _create_database_body(self, folder_path, database_name, text_prompt, use_direct_pe, resume_from_checkpoint,
                               include_subfolders, log_status, status_messages, db_path, ckpt_base, processed_files):
@@ -431,7 +457,8 @@ class SimpleReverso:
                 shutil.rmtree(build_path)
             self._build_store = st.GalleryStore(self.pe_model.cfg.out_dim, device=self.device.index or 0,
                                                 capacity=max(len(image_files), 1024), collection=collection_name,
-                                                path=build_path)
+                                                path=build_path,
+                                                build_info=self._build_info(folder_path, use_direct_pe, include_subfolders))
         store_db = self._build_store
 
         def checkpoint():
@@ -742,6 +769,10 @@ class SimpleReverso:
             stats["bookkeeping_s"] += time.perf_counter() - t_b
 
         if len(store_db) == 0:
+            store_db.close()                                    # nothing to keep: no empty build directory or note stays behind
+            self._build_store = None
+            shutil.rmtree(build_path, ignore_errors=True)
+            st.remove_checkpoint(ckpt_base)
             return str(log_status("❌ No embeddings extracted from any images"))
 
         log_status(f"📦 Recreated collection: {collection_name}", 0.8)
@@ -757,9 +788,7 @@ class SimpleReverso:
             log_status(f"💾 Stored {len(store_db)} points in {store_db._shards} shards", 0.9)
             if self.vector_db is not None:
                 self.vector_db.close()
-            if os.path.isdir(db_path):
-                shutil.rmtree(db_path)                          # recreate_collection: the new one replaces the old one only now
-            os.replace(build_path, db_path)
+            st.swap_in(build_path, db_path)                     # recreate_collection: the new one replaces the old one only now
             store_db.path = db_path
             self.vector_db = store_db
             self._build_store = None

@@ -20,6 +20,7 @@ Round-1/2 directories (one ``vectors.f32.npy`` + ``meta.json``) still load.
 """
 import json
 import os
+import shutil
 from dataclasses import dataclass
 
 import numpy as np
@@ -28,6 +29,54 @@ import torch
 from .engine import Gallery
 
 MANIFEST = "manifest.jsonl"
+
+
+def _fsync_dir(path):
+    """Make a rename / create inside `path` durable (no-op where directories cannot be opened)."""
+    try:
+        fd = os.open(path, os.O_RDONLY)
+    except OSError:
+        return
+    try:
+        os.fsync(fd)
+    except OSError:
+        pass
+    finally:
+        os.close(fd)
+
+
+def swap_in(build_path, db_path):
+    """Replace the database directory by the finished build without a moment in which neither exists under a name
+    list_databases / load_database look at: old -> <db>.old, build -> <db>, then the old one is removed.  A crash in
+    between leaves <db>.old (complete) and possibly <db>.building (complete): recover() puts things right."""
+    old = db_path + ".old"
+    if os.path.isdir(old):
+        shutil.rmtree(old)
+    had = os.path.isdir(db_path)
+    if had:
+        os.replace(db_path, old)
+    os.replace(build_path, db_path)
+    _fsync_dir(os.path.dirname(db_path) or ".")
+    if had:
+        shutil.rmtree(old, ignore_errors=True)
+
+
+def recover(db_path, building_suffix=".building"):
+    """After a crash inside swap_in: a database that is missing while a COMPLETE build (or the set-aside old one) sits
+    next to it is put back under its name.  Returns what was adopted, or None."""
+    if os.path.isdir(db_path):
+        return None
+    for cand, what in ((db_path + building_suffix, "build"), (db_path + ".old", "old")):
+        man = os.path.join(cand, MANIFEST)
+        if os.path.isfile(man):
+            try:
+                complete = read_manifest(man)[2]
+            except (OSError, ValueError):
+                complete = False
+            if complete:
+                os.replace(cand, db_path)
+                return what
+    return None
 
 
 def read_manifest(man):
@@ -66,7 +115,10 @@ class ScoredPoint:
 
 
 class GalleryStore:
-    def __init__(self, dim, device=0, capacity=65536, collection="simple_reverso", path=None, _fresh=True):
+    def __init__(self, dim, device=0, capacity=65536, collection="simple_reverso", path=None, _fresh=True, build_info=None):
+        """``build_info``: what the vectors were made from and how (source folder, model, region mode, ...), written into
+        the manifest header; a resume compares it (core_system.create_database) so that rows of different builds never mix."""
+        self.build_info = dict(build_info or {})
         self.dim = int(dim)
         self.device = device
         self.collection = collection
@@ -84,7 +136,7 @@ class GalleryStore:
             open(os.path.join(path, ".lock"), "a").close()
             if _fresh:
                 with open(os.path.join(path, MANIFEST), "w") as f:
-                    f.write(json.dumps({"format": 2, "collection": collection, "dim": self.dim}) + "\n")
+                    f.write(json.dumps({"format": 2, "collection": collection, "dim": self.dim, "build": self.build_info}) + "\n")
 
     def __len__(self):
         return len(self.ids)
@@ -96,8 +148,9 @@ class GalleryStore:
         old = self.gallery
         new = Gallery(self.dim, cap, device=self.device)
         n = len(old)
-        if n:
-            new.add(old.read(0, n), normalize=False)       # device to device
+        step = max(1, (128 << 20) // (self.dim * 4))       # 128 MB of fp32 rows at a time: the peak is old + new + one chunk,
+        for s0 in range(0, n, step):                       # not old + new + a full fp32 copy of old
+            new.add(old.read(s0, min(step, n - s0)), normalize=False)       # device to device
         old.close()
         self.gallery = new
 
@@ -139,8 +192,12 @@ class GalleryStore:
             name = f"vectors.{self._shards:05d}.f32.npy"
             vec = self.gallery.read(self._flushed, new).cpu().numpy()
             tmp = os.path.join(path, name + ".tmp.npy")
-            np.save(tmp, vec)
+            with open(tmp, "wb") as f:                     # the shard's bytes and its name are on disk BEFORE the manifest
+                np.save(f, vec)                            # line that points to them is appended: after a power loss the
+                f.flush()                                  # manifest never names a shard that is not there
+                os.fsync(f.fileno())
             os.replace(tmp, os.path.join(path, name))
+            _fsync_dir(path)
         line = {"shard": self._shards, "file": name, "rows": new, "ids": self.ids[self._flushed:n],
                 "payloads": self.payloads[self._flushed:n], "files_done": self._files_pending}
         with open(os.path.join(path, MANIFEST), "a") as f:
@@ -163,7 +220,7 @@ class GalleryStore:
         if path != self.path:                              # saving somewhere else: write everything there
             other = os.path.join(path, MANIFEST)
             with open(other, "w") as f:
-                f.write(json.dumps({"format": 2, "collection": self.collection, "dim": self.dim}) + "\n")
+                f.write(json.dumps({"format": 2, "collection": self.collection, "dim": self.dim, "build": self.build_info}) + "\n")
             keep = (self._flushed, self._shards, self._files_pending, self.path)
             self._flushed, self._shards, self._files_pending = 0, 0, sorted(self.files_done) + self._files_pending
             try:
@@ -197,7 +254,7 @@ class GalleryStore:
                 f.truncate(good_bytes)
         rows = sum(s["rows"] for s in shards)
         st = cls(header["dim"], device=device, capacity=max(rows, capacity, 1), collection=header["collection"], path=path,
-                 _fresh=False)
+                 _fresh=False, build_info=header.get("build"))
         for s in shards:
             if s["rows"]:
                 vec = np.load(os.path.join(path, s["file"]))

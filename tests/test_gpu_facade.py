@@ -349,3 +349,43 @@ def test_load_failure_falls_back_to_the_first_available_config(tmp_path, dev, ca
     save_file({k: v.contiguous() for k, v in bad.items()}, ck2)
     with pytest.raises(KeyError, match=r"visual\.foo"):
         SimpleReverso(model_name="PE-Core-B16-224", checkpoint=ck2, db_root=str(tmp_path / "db2"), max_batch=2)
+
+
+def test_resume_refuses_a_build_of_another_folder_model_or_mode(tmp_path, dev):
+    """A stale <db>.building of ANOTHER source folder (or model, or mode) must not be continued: its rows would be mixed
+    with this build's.  The manifest header records what a build is made from; a resume on a mismatch says why and
+    starts fresh.  delete_database takes an unfinished build of that name and its checkpoint note with it."""
+    fa, fb = str(tmp_path / "a"), str(tmp_path / "b")
+    _make_jpegs(fa, n=8, seed=1)
+    _make_jpegs(fb, n=8, seed=2)
+    root = str(tmp_path / "db")
+
+    class Kill(BaseException):
+        pass
+
+    def killer(msg, v=None):
+        if msg.startswith("💾 Checkpoint: shard 0 "):
+            raise Kill()
+    r = SimpleReverso(model_name="PE-Tiny-T14-56", db_root=root, max_batch=4, checkpoint_interval_s=0.0)
+    with pytest.raises(Kill):
+        r.create_database(fa, "g", use_direct_pe=True, progress_callback=killer)
+    build = os.path.join(root, "g.building")
+    hdr = json.loads(open(os.path.join(build, "manifest.jsonl")).readline())
+    assert hdr["build"]["folder_path"] == os.path.abspath(fa) and hdr["build"]["model"] == "PE-Tiny-T14-56"
+    assert hdr["build"]["use_direct_pe"] is True and hdr["build"]["region_mode"] == "global"
+    r2 = SimpleReverso(model_name="PE-Tiny-T14-56", db_root=root, max_batch=4)
+    msg = r2.create_database(fb, "g", use_direct_pe=True, resume_from_checkpoint=True)            # another folder
+    assert "different folder_path" in msg and "Starting fresh" in msg and "ready for searching" in msg, msg[-500:]
+    assert len(r2.vector_db) == 8 and all(fb in p["image_source"] for p in r2.vector_db.payloads)
+    # the same folder in another mode is refused too
+    with pytest.raises(Kill):
+        r.create_database(fa, "h", use_direct_pe=True, progress_callback=killer)
+    msg = r2.create_database(fa, "h", use_direct_pe=False, resume_from_checkpoint=True)
+    assert "different use_direct_pe" in msg and "Starting fresh" in msg
+    # delete: the database, a stale build of that name and the checkpoint note
+    with pytest.raises(Kill):
+        r.create_database(fa, "h", use_direct_pe=True, progress_callback=killer)
+    assert os.path.isdir(os.path.join(root, "h.building"))
+    assert r2.delete_database("h").startswith("✅")
+    assert not os.path.exists(os.path.join(root, "h")) and not os.path.exists(os.path.join(root, "h.building"))
+    assert not os.path.exists(os.path.join(root, "checkpoints", "h_checkpoint.json"))

@@ -243,3 +243,39 @@ def test_local_shards_protocol_on_cpu(noise, shards):
         assert np.array_equal(i.numpy(), ri) and np.array_equal(c.numpy(), rc)
         np.testing.assert_allclose(s.numpy(), rs, atol=1e-6)
     assert (second > 0) == (noise > 0)
+
+
+def test_swap_in_and_recover_after_a_crash_in_the_final_swap(tmp_path):
+    """The finished build replaces the database by two renames (old -> <db>.old, build -> <db>); whatever a crash between
+    them leaves behind, recover() -- run by list_databases / load_database -- puts a COMPLETE directory back under the
+    database's name, and never adopts an unfinished build."""
+    def make(path, complete, tag):
+        os.makedirs(path)
+        with open(os.path.join(path, st.MANIFEST), "w") as f:
+            f.write(json.dumps({"format": 2, "collection": tag, "dim": 64}) + "\n")
+            if complete:
+                f.write(json.dumps({"complete": True, "rows": 0}) + "\n")
+    db = str(tmp_path / "db")
+    # the normal swap, with and without an old database
+    make(db + ".building", True, "new1")
+    st.swap_in(db + ".building", db)
+    assert st.read_manifest(os.path.join(db, st.MANIFEST))[0]["collection"] == "new1" and not os.path.exists(db + ".building")
+    make(db + ".building", True, "new2")
+    st.swap_in(db + ".building", db)
+    assert st.read_manifest(os.path.join(db, st.MANIFEST))[0]["collection"] == "new2"
+    assert not os.path.exists(db + ".old") and not os.path.exists(db + ".building")
+    # crash after "old -> .old", before "build -> db": the complete build is adopted
+    make(db + ".building", True, "new3")
+    os.replace(db, db + ".old")
+    assert st.recover(db) == "build"
+    assert st.read_manifest(os.path.join(db, st.MANIFEST))[0]["collection"] == "new3"
+    assert st.recover(db) is None                                # nothing to do when the database is there
+    # the database is gone and only an UNFINISHED build and the set-aside old one exist: the old one comes back
+    import shutil
+    shutil.rmtree(db)
+    make(db + ".building", False, "half")
+    assert st.recover(db) == "old"
+    assert st.read_manifest(os.path.join(db, st.MANIFEST))[0]["collection"] == "new2" and os.path.isdir(db + ".building")
+    # only an unfinished build: nothing is adopted
+    shutil.rmtree(db)
+    assert st.recover(db) is None and not os.path.exists(db)
