@@ -29,6 +29,7 @@ def _worker(rank, world, port, tmp, N, B, k):
     g = torch.Generator().manual_seed(99)
     gal = torch.randn(N, D, generator=g)
     imgs = torch.randint(0, 256, (world * B, 3, 56, 56), generator=g, dtype=torch.uint8)
+    gal[100:160] = gal[100]                      # a tie group wider than the candidate list
     sizes = [N // world + (1 if r < N % world else 0) for r in range(world)]
     lo = sum(sizes[:rank])
     G = engine.Gallery(D, sizes[rank], device=0)
@@ -41,6 +42,23 @@ def _worker(rank, world, port, tmp, N, B, k):
     for thr in (None, 0.02):
         s, i, c = ss.search(q, k, thr)
         out[str(thr)] = (s.cpu().numpy(), i.cpu().numpy(), c.cpu().numpy())
+    # pipelined form (bench.py's loops): the next search is enqueued before the previous one's result is asked for.  One
+    # query sits on a group of 60 identical rows (wider than the candidate lists): its certificate fails, and by the time
+    # its result is asked for the shard handle holds the NEXT search's candidates -- the pending search re-does itself,
+    # in step on both ranks.  Also limit 50, whose second round draws on the scan's segments.
+    qx = torch.cat([q, gal[100:101].to(dev)])
+    want = [ss.search(qx, kk, thr) for kk, thr in ((k, None), (50, None), (k, 0.02))]
+    assert ss.last_uncertified >= 0
+    pend = [ss.search_async(qx, kk, thr) for kk, thr in ((k, None), (50, None), (k, 0.02))]
+    unc = []
+    for w, p in zip(want, pend):
+        got = p.result()
+        unc.append(ss.last_uncertified)
+        for a, b in zip(got, w):
+            assert torch.equal(a, b)
+    assert unc[0] >= 1 and unc[2] >= 1, unc              # the tie-group query did need the second round
+    out["x"] = tuple(t.cpu().numpy() for t in want[0])
+    out["x50"] = tuple(t.cpu().numpy() for t in want[1])
     np.savez(os.path.join(tmp, f"rank{rank}.npz"), q=q.cpu().numpy(),
              **{f"{t}_{n}": v for t, (a, b, c) in out.items() for n, v in (("s", a), ("i", b), ("c", c))})
     dist.barrier()
@@ -58,6 +76,7 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_search(tmp_path, dev):
     g = torch.Generator().manual_seed(99)
     gal = torch.randn(N, D, generator=g)
     imgs = torch.randint(0, 256, (world * B, 3, 56, 56), generator=g, dtype=torch.uint8)
+    gal[100:160] = gal[100]
     q = torch.cat([eng.embed(imgs[r * B:(r + 1) * B].to(dev)) for r in range(world)])
     G = engine.Gallery(D, N, device=0)
     G.add(gal.to(dev))
@@ -68,6 +87,13 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_search(tmp_path, dev):
             assert np.array_equal(got["q"], q.cpu().numpy())
             assert np.array_equal(got[f"{thr}_i"], i) and np.array_equal(got[f"{thr}_c"], c)
             assert np.array_equal(got[f"{thr}_s"], s)
+    qx = torch.cat([q, gal[100:101].to(dev)])
+    for tag, kk in (("x", k), ("x50", 50)):
+        s, i, c = (t.cpu().numpy() for t in G.search(qx, kk))
+        assert i[-1, :min(kk, 60)].tolist() == list(range(100, 100 + min(kk, 60)))       # the tie group, index ascending
+        for rank in range(world):
+            got = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+            assert np.array_equal(got[f"{tag}_i"], i) and np.array_equal(got[f"{tag}_c"], c) and np.array_equal(got[f"{tag}_s"], s)
 
 
 def _nccl_worker(rank, world, port, tmp, N, D, Q, k):
