@@ -824,3 +824,27 @@ def test_sharded_k50_second_round_draws_on_the_shards_segments(dev, P, min_secon
     for Gp in shards:
         Gp.close()
     G.close()
+
+
+def test_segment_answered_query_with_more_rows_than_its_list_holds_goes_to_brute_force(dev):
+    """3 000 exact duplicates of the query spread evenly over the gallery (every 87th row), limit 50: no slice's segment
+    overflows (so the scan's segments DO hold every row that matters and the query is numbered among the
+    segment-answered entries), but their number exceeds the 2 048-key collect list -- the exact finish passes the entry
+    on to the brute-force pass.  Result: the 50 duplicates with the smallest indices, as the oracle has them."""
+    N, D, k = 300000, 128, 50
+    rng = np.random.default_rng(31)
+    gal = rng.standard_normal((N, D), dtype=np.float32)
+    v = rng.standard_normal(D).astype(np.float32)
+    dup = np.arange(40057, N, 87)                 # behind the pre-pass rows (a pre-pass full of duplicates has its own bound
+    assert len(dup) > 2048                        # at their score: then the segments alone cannot answer, and the search says so)
+    gal[dup] = v
+    qr = np.stack([v, rng.standard_normal(D).astype(np.float32), v * 2.0])
+    G = engine.Gallery(D, N, device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    s, i, c = G.search(torch.from_numpy(qr).to(dev), k)
+    st = G.search_stats()
+    assert st["uncertified"] >= 2 and st["bruteforced"] == 2, st       # both duplicate queries: segments -> list overflow -> brute force
+    assert st["from_segments"] >= 2, st
+    assert i[0].cpu().tolist() == dup[:k].tolist() and i[2].cpu().tolist() == dup[:k].tolist()
+    _check((s, i, c), osearch.search(gal, qr, k), atol=1e-5, near_tie=3e-7)
+    G.close()
