@@ -106,7 +106,7 @@ __device__ __forceinline__ void tile_step(const uint32_t (&kaddr)[4], const uint
             }
 }
 
-template <int NQ, int NW, int MINW>
+template <int NQ, int NW, int MINW, int BAR>
 __global__ __launch_bounds__(NW * 64, MINW) void probe_kernel(float* out, long long* cycles, int nt, float c) {
     __shared__ __attribute__((aligned(16))) char lds[2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,7 +133,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void probe_kernel(float* out, long l
     __syncthreads();
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
 #pragma unroll 1
-    for (int t = 0; t < nt; ++t) tile_step<NQ>(kaddr, vaddr, qf, oacc, m_run, l_run, c);
+    for (int t = 0; t < nt; ++t) {
+        if (BAR) __builtin_amdgcn_s_barrier();      // the kernel's per-tile workgroup barrier (nothing to wait for here: it only re-aligns the waves)
+        tile_step<NQ>(kaddr, vaddr, qf, oacc, m_run, l_run, c);
+    }
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
     float acc = 0.f;
     for (int q = 0; q < NQ; ++q) {
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void probe_kernel(float* out, long l
     if (lane == 0) cycles[(long)blockIdx.x * NW + wave] = t1 - t0;
 }
 
-template <int NQ, int NW, int MINW>
+template <int NQ, int NW, int MINW, int BAR = 0>
 static void run(const char* name, int wgs_per_cu, int nt) {
     const int blocks = 256 * wgs_per_cu;
     float* out; long long* cyc;
@@ -153,11 +156,11 @@ static void run(const char* name, int wgs_per_cu, int nt) {
     hipMalloc(&cyc, (size_t)blocks * NW * 8);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((probe_kernel<NQ, NW, MINW>), dim3(blocks), dim3(NW * 64), 0, 0, out, cyc, nt, 0.18f);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((probe_kernel<NQ, NW, MINW, BAR>), dim3(blocks), dim3(NW * 64), 0, 0, out, cyc, nt, 0.18f);
     hipDeviceSynchronize();
     hipEventRecord(e0);
     const int reps = 10;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe_kernel<NQ, NW, MINW>), dim3(blocks), dim3(NW * 64), 0, 0, out, cyc, nt, 0.18f);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe_kernel<NQ, NW, MINW, BAR>), dim3(blocks), dim3(NW * 64), 0, 0, out, cyc, nt, 0.18f);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms = 0.f;
@@ -183,5 +186,11 @@ int main() {
     run<2, 4, 1>("B: 64 rows/wave, 4 waves per CU", 1, nt);
     run<2, 8, 2>("B2: 64 rows/wave, 8 waves per CU (256 VGPRs)", 1, nt);
     run<3, 4, 1>("C: 96 rows/wave, 4 waves per CU", 1, nt);
+    // with the per-tile workgroup barrier (what re-aligns the waves of a workgroup after every key tile)
+    run<1, 8, 4, 1>("A + barrier: 32 rows/wave, 2 x 8 waves", 2, nt);
+    run<2, 4, 2, 1>("D + barrier: 64 rows/wave, 2 x 4 waves", 2, nt);
+    run<2, 4, 2, 0>("D: 64 rows/wave, 2 x 4 waves", 2, nt);
+    run<1, 4, 4, 1>("E + barrier: 32 rows/wave, 4 x 4 waves", 4, nt);
+    run<2, 8, 2, 1>("B2 + barrier: 64 rows/wave, 1 x 8 waves", 1, nt);
     return 0;
 }
