@@ -848,3 +848,37 @@ def test_segment_answered_query_with_more_rows_than_its_list_holds_goes_to_brute
     assert i[0].cpu().tolist() == dup[:k].tolist() and i[2].cpu().tolist() == dup[:k].tolist()
     _check((s, i, c), osearch.search(gal, qr, k), atol=1e-5, near_tie=3e-7)
     G.close()
+
+
+def test_k50_edges_smallest_scan256_gallery_and_no_fp32_rows(dev):
+    """limit 50 where the margin machinery starts and where it must stay off: the smallest gallery the 256 x 256 scan takes
+    (16 384 rows: a 4 096-row pre-pass, three slices) against the oracle, one row less (the small-gallery scan: no
+    segments, the collect pass answers), and a gallery without fp32 rows (nothing to certify: the scan's own scores,
+    no margin, stats say -1)."""
+    D, k, Q = 256, 50, 40
+    rng = np.random.default_rng(91)
+    for N in (16384, 16383):
+        gal = rng.standard_normal((N, D), dtype=np.float32)
+        qr = rng.standard_normal((Q, D), dtype=np.float32)
+        G = engine.Gallery(D, N, device=0)
+        G.add(torch.from_numpy(gal).to(dev))
+        out = G.search(torch.from_numpy(qr).to(dev), k)
+        st = G.search_stats()
+        assert st["checked"] == Q and st["bruteforced"] == 0, st
+        if N < 16384:
+            assert st["from_segments"] == 0, st
+        else:
+            assert st["from_segments"] == st["uncertified"], st
+        _check(out, osearch.search(gal, qr, k), atol=1e-5, near_tie=3e-7)
+        G.close()
+    N = 40000
+    gal = rng.standard_normal((N, D), dtype=np.float32)
+    qr = rng.standard_normal((Q, D), dtype=np.float32)
+    G = engine.Gallery(D, N, device=0, keep_f32=False)
+    G.add(torch.from_numpy(gal).to(dev))
+    s, i, c = G.search(torch.from_numpy(qr).to(dev), k)
+    assert G.search_stats()["uncertified"] == -1
+    rs, ri, rc = osearch.search(gal, qr, k)
+    assert np.array_equal(c.cpu().numpy(), rc) and np.abs(s.cpu().numpy() - rs).max() <= 1e-2     # bf16-input scores
+    assert (np.sort(i.cpu().numpy()[:, :10], axis=1) == np.sort(ri[:, :10], axis=1)).mean() >= 0.9
+    G.close()
