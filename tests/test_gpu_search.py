@@ -882,3 +882,26 @@ def test_k50_edges_smallest_scan256_gallery_and_no_fp32_rows(dev):
     assert np.array_equal(c.cpu().numpy(), rc) and np.abs(s.cpu().numpy() - rs).max() <= 1e-2     # bf16-input scores
     assert (np.sort(i.cpu().numpy()[:, :10], axis=1) == np.sort(ri[:, :10], axis=1)).mean() >= 0.9
     G.close()
+
+
+@pytest.mark.parametrize("Q", [193, 224, 256])
+def test_193_to_256_queries_against_the_oracle(dev, Q):
+    """193..256 queries (the 256-row form of the scan with a partly empty query tile; a two-128-row-tile form was measured
+    and dropped): the oracle's results, with a tie group on the last query, a planted neighbour, a
+    threshold, limit 10 and 50 (the latter with the admission margin), a ragged gallery size."""
+    N, D = 70001, 128
+    rng = np.random.default_rng(Q)
+    gal = rng.standard_normal((N, D), dtype=np.float32)
+    gal[N // 3: N // 3 + 40] = gal[N // 3]
+    qr = rng.standard_normal((Q, D), dtype=np.float32)
+    qr[Q - 1] = gal[N // 3]                                   # the last query of the second tile sits on the tie group
+    qr[130] = gal[777] + 0.05 * rng.standard_normal(D).astype(np.float32)
+    G = engine.Gallery(D, N, device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    qd = torch.from_numpy(qr).to(dev)
+    for k, thr in ((10, None), (50, None), (10, 0.3)):
+        out = G.search(qd, k, thr)
+        _check(out, osearch.search(gal, qr, k, thr), atol=1e-5, near_tie=3e-7)
+        assert out[1][Q - 1, :min(k, 40)].cpu().tolist() == list(range(N // 3, N // 3 + min(k, 40)))
+        assert int(out[1][130, 0]) == 777
+    G.close()
