@@ -92,9 +92,9 @@ int32_t revo_gallery_read(revo_gallery* g, int64_t start, int64_t n, float* dst,
  * was not re-scored by more than a rigorous bound of |bf16 score - fp32 score|, computed from the rounding norms of
  * the query and of the gallery's rows), and a query that fails it is re-done by a collecting pass over the gallery
  * (every row within that bound of what is needed, re-scored in fp32) and, if that list overflows, by a brute-force
- * fp32 pass.  Searches with k > 25 (64 candidates leave the certificate too little room on ordinary data) and every
- * search of a gallery of 2^22 rows or more scan with an admission margin of twice that bound: what an uncertified query
- * needs is then among the rows its scan kept, and it is re-done exactly WITHOUT another pass over the gallery.  All of it is enqueued on `stream`; revo_search_stats reports how often it happened.  (A gallery created
+ * fp32 pass.  Searches with k > 25 (64 candidates leave the certificate too little room on ordinary data) scan with an
+ * admission margin of twice that bound: what an uncertified query needs is then among the rows its scan kept, and it is
+ * re-done exactly WITHOUT another pass over the gallery.  All of it is enqueued on `stream`; revo_search_stats reports how often it happened.  (A gallery created
  * with keep_f32 = 0 has no fp32 rows: it returns the scan's own scores and certifies nothing.) */
 int32_t revo_search_topk(revo_gallery* g, const float* queries, int32_t n_queries, int32_t k, int32_t has_threshold,
                          float threshold, int64_t index_offset, float* scores, int64_t* indices, int32_t* counts,

@@ -947,8 +947,10 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
     // k > 25: 64 candidates leave the certificate less room than its error bound on ordinary data (the 50th-to-64th score
     // gap of a random 1 M gallery is half of eps), so nearly every query fails it.  The scan then runs with an admission
     // margin of 2 eps: what an uncertified query needs is in its segments, and no second pass over the gallery is made
-    // (and on very large galleries for every k: there a second pass costs most of a search)
-    CHECK_RC(search_candidates(g, queries, Q, ksel, st, nullptr, 0, k > 25 || g->size >= SEARCH_WIDE_ROWS));
+    // (Not for smaller k, not even on very large galleries where a second pass costs most of a search: measured on 10 M x
+    //  1536 with 256 queries, the margin's extra survivors cost the scan 18 % on EVERY search -- 7.5 -> 8.9 ms -- to save a
+    //  pass that the 64-candidate lists kept there for every k already make a rarity.)
+    CHECK_RC(search_candidates(g, queries, Q, ksel, st, nullptr, 0, k > 25));
     const CertArgs ca = g->cert_args(nullptr);
     { ProfScope ps("topk_finish", st);
       CHECK_RC(launch_topk_finish(g->cand, g->cand_stride, ksel, g->qf, g->D, g->keep_f32 ? g->gf : nullptr, g->D, g->D, Q, k,

@@ -201,7 +201,7 @@ struct S256Lds {
 __device__ __forceinline__ float s256_admit(float t, uint32_t base, float mg) {
     return mg > 0.f ? fmaxf(orderable_f32(base), t - mg) : t;
 }
-template <int KSEL>
+template <int KSEL, bool MARGIN>
 __device__ __noinline__ void s256_refresh_hist(const S256Lds& L, const uint32_t* hist, const uint32_t* tau_g, int q0,
                                                int qvalid, int tid, const float* marg) {
     const int wave = tid >> 6, lane = tid & 63;
@@ -210,7 +210,7 @@ __device__ __noinline__ void s256_refresh_hist(const S256Lds& L, const uint32_t*
     float mgv = 0.f;
     if (lane < 32 && wave + 8 * lane < qvalid) {
         tgv = __hip_atomic_load(tau_g + q0 + wave + 8 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (marg) mgv = marg[q0 + wave + 8 * lane];
+        if constexpr (MARGIN) mgv = marg[q0 + wave + 8 * lane];
     }
     // all 32 rows' counters are requested before any is used: one L2 round trip per refresh, not one per batch
     uint32_t h[32];
@@ -238,7 +238,8 @@ __device__ __noinline__ void s256_refresh_hist(const S256Lds& L, const uint32_t*
                 const float th = orderable_f32(L.base[r] + ((uint32_t)b << S256_SH));
                 t = th > t ? th : t;
             }
-            t = s256_admit(t, L.base[r], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mgv), u)));
+            if constexpr (MARGIN)
+                t = s256_admit(t, L.base[r], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mgv), u)));
             if (t > L.tau[r]) L.tau[r] = t;
         }
     }
@@ -248,7 +249,7 @@ __device__ __noinline__ void s256_refresh_hist(const S256Lds& L, const uint32_t*
 // All 512 threads; the slow, exact path.  Sort the overflow queue (row, score, index descending) and, for
 // every row that has queued entries, merge them with the row's segment into the row's best KSEL distinct
 // keys: those go back to the head of the segment (sorted, best first), the rest of it is free again.
-template <int KSEL>
+template <int KSEL, bool MARGIN>
 __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* seg0, long seg_row_stride, int q0, int qvalid,
                                         uint32_t idx_base, int tid, uint32_t* tau_g, const float* marg, int* dropflag) {
     constexpr int SEG = 2 * KSEL;
@@ -333,12 +334,13 @@ __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* seg0, long s
                 // this slice's KSEL-th best is a lower bound of the query's final KSEL-th best: publish it
                 const uint32_t lo = (uint32_t)(last >> 32);
                 (void)__hip_atomic_fetch_max(tau_g + q0 + r, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float t = s256_admit(orderable_f32(lo), L.base[r], marg ? marg[q0 + r] : 0.f);
+                float t = orderable_f32(lo);
+                if constexpr (MARGIN) t = s256_admit(t, L.base[r], marg[q0 + r]);
                 if (t > L.tau[r]) L.tau[r] = t;
             }
             // a drained segment keeps its best KSEL keys only, and from here on the row admits against them: rows inside
             // the admission margin are no longer all kept
-            if (dropflag) dropflag[q0 + r] = 1;
+            if constexpr (MARGIN) dropflag[q0 + r] = 1;
         }
     }
     __syncthreads();
@@ -366,7 +368,11 @@ struct Scan256Args {
 
 // ROWS: 0 = all 256 query rows of a tile may be valid; 64 / 128 / 192 = the whole search has at most that many
 // queries (one query tile), and the main loop skips the MFMA work of the rows that cannot be valid.
-template <int KSEL, int ROWS>
+// MARGIN: the scan admits against max(pre-pass bound, bound - marg[q]) and flags the queries whose segments a drain or a
+// recomputed tile touched (CertArgs, kernels.h).  A template parameter, not a run-time switch: the 256-row form runs at
+// the 256-VGPR limit, and with the margin's pointers and branches compiled into it the plain scan spilled 16 VGPRs and
+// lost 5 % (10 000 queries) to 17 % (256 queries) -- measured in round 4 before this was split off.
+template <int KSEL, int ROWS, bool MARGIN = false>
 __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Args p) {
     constexpr int SEG = 2 * KSEL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -414,7 +420,9 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
 
     if (tid < 256) {
         const uint32_t b0 = tid < qvalid ? p.tau_base[q0 + tid] : 0u;
-        L.tau[tid] = tid < qvalid ? s256_admit(orderable_f32(p.tau_g[q0 + tid]), b0, p.marg ? p.marg[q0 + tid] : 0.f) : INFINITY;
+        float t0_ = tid < qvalid ? orderable_f32(p.tau_g[q0 + tid]) : INFINITY;
+        if constexpr (MARGIN) { if (tid < qvalid) t0_ = s256_admit(t0_, b0, p.marg[q0 + tid]); }
+        L.tau[tid] = t0_;
         L.base[tid] = b0;
         L.wkey[tid] = 0ull;
         L.cnt[tid] = 0;
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     // slice's first tile admitted about one score per row: at 24 tiles per slice a third of all slow fragments.)
     if (!(p.dbg & 17)) {
         if (p.stats && tid == 0) atomicAdd(p.stats + 5, 1ull);
-        s256_refresh_hist<KSEL>(L, p.hist, p.tau_g, q0, qvalid, tid, p.marg);
+        s256_refresh_hist<KSEL, MARGIN>(L, p.hist, p.tau_g, q0, qvalid, tid, MARGIN ? p.marg : nullptr);
     }
 
     // Normal mode: one pass per tile (groups == 1).  If a pass pushes more entries to the overflow queue than
@@ -551,8 +559,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
                     if (!(p.dbg & 8)) {
                         myseg[(long)row * seg_row_stride + slot] = s256_entry_to_key(e, idx_base);
                         const uint32_t so = (uint32_t)(e >> 24), bo = s256_lds_u32(S256_BASE_OFF + row * 4);
-                        if (groups == 1 && so >= bo) {         // a recomputed tile must not be counted twice; a score admitted
-                                                               // by the margin only lies below the histogram's origin
+                        if (groups == 1 && (!MARGIN || so >= bo)) {   // a recomputed tile must not be counted twice; a score
+                                                               // admitted by the margin only may lie below the histogram's origin
                             uint32_t b = (so - bo) >> S256_SH;
                             b = b < (uint32_t)(S256_NB - 1) ? b : (uint32_t)(S256_NB - 1);
                             (void)__hip_atomic_fetch_add(myhist + (long)row * S256_NB + b, 1u, __ATOMIC_RELAXED, S256_HIST_SCOPE);
@@ -574,22 +582,22 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
         }
         if (groups == 1 && !overflow) {
             if (qc >= S256_DRAIN || (t + 1 >= t1 && qc > 0))
-                s256_drain<KSEL>(L, myseg, seg_row_stride, q0, qvalid, idx_base, tid, p.tau_g, p.marg, p.dropflag);
+                s256_drain<KSEL, MARGIN>(L, myseg, seg_row_stride, q0, qvalid, idx_base, tid, p.tau_g, MARGIN ? p.marg : nullptr, MARGIN ? p.dropflag : nullptr);
             // what all slices of these queries have learnt meanwhile: after the first two tiles (the bound moves
             // fastest early on: it follows KSEL / rows seen), then every fourth tile, every 16th from tile 32 on
             // (each refresh is an L2 round trip plus ~3 us of wave scans)
             const long tl = t - t0;
             if (t + 1 < t1 && !(p.dbg & 17) && (tl < 2 || ((tl & 3) == 3 && tl < 32) || (tl & 15) == 15)) {
                 if (p.stats && tid == 0) atomicAdd(p.stats + 5, 1ull);
-                s256_refresh_hist<KSEL>(L, p.hist, p.tau_g, q0, qvalid, tid, p.marg);
+                s256_refresh_hist<KSEL, MARGIN>(L, p.hist, p.tau_g, q0, qvalid, tid, MARGIN ? p.marg : nullptr);
             }
             ++t;
             continue;
         }
         // retry mode (or entering it): merge what was queued, then recompute this tile / its next column group
-        s256_drain<KSEL>(L, myseg, seg_row_stride, q0, qvalid, idx_base, tid, p.tau_g, p.marg, p.dropflag);
+        s256_drain<KSEL, MARGIN>(L, myseg, seg_row_stride, q0, qvalid, idx_base, tid, p.tau_g, MARGIN ? p.marg : nullptr, MARGIN ? p.dropflag : nullptr);
         // a recomputed tile appends its survivors a second time: these queries' segments may hold repeated keys
-        if (p.dropflag && tid < qvalid) p.dropflag[q0 + tid] = 1;
+        if constexpr (MARGIN) { if (tid < qvalid) p.dropflag[q0 + tid] = 1; }
         if (overflow) {
             groups = groups < S256_MAXGROUPS ? groups * 2 : S256_MAXGROUPS;
             grp = 0;
@@ -743,12 +751,21 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
     Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, qt_pad, seg, seg_cnt, tau_g, tau_base, hist, marg, dropflag, g_scan_dbg,
                   (g_scan_dbg & 2) ? topk_scan256_stats() : nullptr};
     const dim3 grid((unsigned)((long)qt_pad * splits)), block(G256_THREADS);
+#define S256_LAUNCH_M(KS, RW, MG)                                                                              \
+    do {                                                                                                       \
+        REVO_FUNC_LDS((topk_scan256_kernel<KS, RW, MG>), S256_LDS);                                              \
+        hipLaunchKernelGGL((topk_scan256_kernel<KS, RW, MG>), grid, block, S256_LDS, st, a);                   \
+    } while (0)
+    // the margin form exists for 64-candidate scans only (searches with k > 25: api.hip)
+    REVO_REQUIRE(!marg || (ksel == 64 && dropflag), "search: the admission margin goes with 64 candidates and drop flags");
 #define S256_LAUNCH(KS, RW)                                                                                    \
     do {                                                                                                       \
-        REVO_FUNC_LDS((topk_scan256_kernel<KS, RW>), S256_LDS);                                                  \
-        hipLaunchKernelGGL((topk_scan256_kernel<KS, RW>), grid, block, S256_LDS, st, a);                       \
+        if (KS == 64 && RW != 192 && marg) S256_LAUNCH_M(64, (RW == 192 ? 0 : RW), true);                      \
+        else S256_LAUNCH_M(KS, RW, false);                                                                     \
     } while (0)
-    const int rows_mode = Q <= 64 ? 64 : (Q <= 128 ? 128 : (Q <= 192 ? 192 : 0));
+    // (the 192-row form is not built with the margin: hipcc 7.2 spills 464 VGPRs in that combination; 129..192 queries of a
+    //  margin scan take the 256-row form)
+    const int rows_mode = Q <= 64 ? 64 : (Q <= 128 ? 128 : ((Q <= 192 && !marg) ? 192 : 0));
     if (ksel == 32) {
         if (rows_mode == 64) S256_LAUNCH(32, 64);
         else if (rows_mode == 128) S256_LAUNCH(32, 128);
@@ -761,6 +778,7 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
         else S256_LAUNCH(64, 0);
     }
 #undef S256_LAUNCH
+#undef S256_LAUNCH_M
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
