@@ -1,7 +1,9 @@
 #!/bin/bash
 # A/B of the scan kernel across this round's changes (admission margin, drop flags, histogram guard): the library of the
 # commit before them (REVO_LIBRARY_PATH) against the tree's, alternated on one box.
-OLD=${1:-_bisect/premargin/librevo.so}
+# The other library: build an older commit in a scratch worktree and keep the .so under _bisect/ (git-ignored, travels with gpurun):
+#   git worktree add /tmp/wt <commit> && make -C /tmp/wt/revers-o_amd/csrc -j8 all && mkdir -p _bisect/prev && cp /tmp/wt/revers-o_amd/librevo.so _bisect/prev/ && git worktree remove --force /tmp/wt
+OLD=${1:-_bisect/prev/librevo.so}
 for r in 1 2; do
   REVO_LIBRARY_PATH=$OLD python scripts/search_small_q.py > gpurun_out/reg_old_$r.json 2>/dev/null
   python scripts/search_small_q.py > gpurun_out/reg_new_$r.json 2>/dev/null
