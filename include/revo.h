@@ -114,6 +114,12 @@ int32_t revo_search_topk(revo_gallery* g, const float* queries, int32_t n_querie
  *   4. all-gather the per-rank results and revo_topk_merge / revo_topk_merge_packed them.
  * The merged result equals the unsharded revo_search_topk of the concatenated gallery. */
 int32_t revo_search_ksel(int32_t k);     /* candidates the scan keeps per query for a top-k search (32 or 64) */
+/* Tell a shard's handle how many rows the WHOLE row-sharded gallery has (0 = forget).  revo_search_candidates then starts
+ * its scan from an estimate of the score a candidate of the whole gallery has to reach (extrapolated from the shard's own
+ * first rows) instead of what the shard's own rows would admit: fewer survivors per tile, a faster scan.  The estimate is
+ * not trusted: step 4's certificate counts it as the score an unseen row may have, and step 5 re-does what it cannot
+ * certify -- results are the exhaustive search's whatever the estimate was.  revo_search_topk ignores the setting. */
+int32_t revo_search_set_total_rows(revo_gallery* g, int64_t total_rows);
 /* how a search of n_queries against the gallery's current rows would run (reporting only): out4 = { 1 if the 256 x 256
  * scan takes it (0: the small-gallery scan), rows covered by the pre-pass GEMM, gallery slices per query tile, ksel } */
 int32_t revo_search_plan(const revo_gallery* g, int32_t n_queries, int32_t k, int64_t* out4);

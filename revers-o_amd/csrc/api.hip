@@ -630,6 +630,8 @@ struct revo_gallery {
     // the last scan ran with an admission margin: its segments can answer uncertified queries (CertArgs, kernels.h)
     revo::SegSrc segs[2] = {}; int nsegs = 0; const uint64_t* prelist = nullptr;
     float* marg = nullptr; int* dropflag = nullptr;
+    int64_t total_rows = 0;        // revo_search_set_total_rows: this handle is one shard of a gallery of that many rows (0: the whole)
+    bool cand_estimated = false;   // the last scan started from estimated admission scores (CertArgs::estimated)
     // exactness certificate (kernels.h): per-query rounding norms of the last search's queries, running maxima over the
     // gallery's rows, the fallback workspace (sized with q_cap) and the handle's mode
     float* qstat = nullptr; uint32_t* gstat = nullptr;
@@ -646,7 +648,7 @@ struct revo_gallery {
         revo::CertArgs c{};
         c.qstat = qstat; c.gstat = gstat; c.mode = mode; c.ws = xw; c.Qb = qb; c.ldq = D; c.cert_out = cert_out;
         c.nsegs = nsegs; c.segs[0] = segs[0]; c.segs[1] = segs[1]; c.seg_ksel = cand_ksel; c.prelist = prelist;
-        c.tau_base = tau0; c.marg = marg; c.dropflag = dropflag;
+        c.tau_base = tau0; c.marg = marg; c.dropflag = dropflag; c.estimated = cand_estimated ? 1 : 0;
         return c;
     }
 };
@@ -675,6 +677,11 @@ extern "C" int32_t revo_gallery_destroy(revo_gallery* g) {
     API_END
 }
 extern "C" int64_t revo_gallery_size(const revo_gallery* g) { return g ? g->size : -1; }
+extern "C" int32_t revo_search_set_total_rows(revo_gallery* g, int64_t total_rows) {
+    REVO_REQUIRE(g && total_rows >= 0, "search_set_total_rows: null handle or negative row count");
+    g->total_rows = total_rows;
+    return 0;
+}
 extern "C" int32_t revo_gallery_clear(revo_gallery* g) {
     REVO_REQUIRE(g, "null handle");
     REVO_ON_DEVICE(g->device);
@@ -763,6 +770,24 @@ constexpr long SEARCH_WIDE_ROWS = 1l << 22;   // from here on the unsharded sear
 
 // Phase 1 of a search: normalise the queries, scan the gallery (bf16 MFMA scores) and leave each query's best
 // ksel candidates, sorted best first, in the handle (cand / cand_stride).  The gallery must not be empty.
+// z with P(standard normal > z) = p (Acklam's rational approximation, |relative error| < 1.2e-9; 0 < p < 0.5 here)
+static double upper_normal_quantile(double p) {
+    static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02, 1.383577518672690e+02,
+                               -3.066479806614716e+01, 2.506628277459239e+00};
+    static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02, 6.680131188771972e+01,
+                               -1.328068155288572e+01};
+    static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00, -2.549732539343734e+00,
+                               4.374664141464968e+00, 2.938163982698783e+00};
+    static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+    if (p < 0.02425) {
+        const double q = std::sqrt(-2.0 * std::log(p));
+        return -(((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1.0);
+    }
+    const double q = (1.0 - p) - 0.5, r = q * q;
+    return (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q /
+           (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1.0);
+}
+
 static int search_candidates(revo_gallery* g, const float* queries, int Q, int ksel, hipStream_t st,
                              uint32_t* bounds = nullptr, int top_m = 0, bool margin = false) {
     using namespace revo;
@@ -806,7 +831,7 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
         }
         return 0;
     };
-    g->cand = nullptr; g->cand_Q = 0; g->nsegs = 0; g->prelist = nullptr;
+    g->cand = nullptr; g->cand_Q = 0; g->nsegs = 0; g->prelist = nullptr; g->cand_estimated = false;
     // the admission margin only pays where the certificate is expected to fail (see revo_search_topk) and only the
     // 256 x 256 scan has segments; it needs the fp32 rows (no certificate without them)
     margin = margin && g->keep_f32 && N >= SEARCH_SMALL_ROWS;
@@ -853,8 +878,23 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
             ga.C = pre_scores; ga.ldc = n_pre; ga.prefer256 = 1;
             CHECK_RC(launch_gemm(EPI_F32, ga, st));
             REVO_HIP_CHECK(hipMemsetAsync(hist, 0, hist_bytes, st));
+            // One shard of a larger gallery, in the two-phase search: what its candidates have to reach is decided by ALL
+            // shards' rows (the finish step re-scores only candidates among the best min(64, 2 ksel) of the whole gallery),
+            // but its scan can only learn its own rows' scores -- at an eighth of the rows its admission bound sits at an
+            // 8 x higher quantile and a third of its tile fragments still hold a survivor.  So it
+            // starts from an ESTIMATE of the whole gallery's level, extrapolated from its own pre-pass scores
+            // (topk_select_rows_kernel); an estimate, not a bound: the protocol's certificate and second round cover it.
+            float est_z = 0.f;
+            if (bounds && !margin && g->total_rows > N) {
+                int j = 2 * ksel < 64 ? 2 * ksel : 64;
+#ifdef REVO_EXPERIMENTS
+                if (const char* e = getenv("REVO_EST_J")) j = atoi(e) > 0 ? atoi(e) : j;      // sweep of the estimate's rank (scripts/)
+#endif
+                est_z = (float)upper_normal_quantile((double)j / (double)g->total_rows);
+                g->cand_estimated = true;
+            }
             CHECK_RC(launch_topk_select_rows(pre_scores, n_pre, (int)n_pre, Q, prelist, ksel, 0, tau_base, ksel, hist, NB,
-                                             topk_scan256_hist_shift(), st, tau_live));
+                                             topk_scan256_hist_shift(), st, tau_live, est_z));
 #ifdef REVO_EXPERIMENTS
             if (g->seed_bounds) hipLaunchKernelGGL(seed_bounds_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, tau_live, g->seed_bounds, Q);
 #endif

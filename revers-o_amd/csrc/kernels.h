@@ -158,7 +158,9 @@ struct CertArgs {
     SegSrc segs[2]; int nsegs;
     int seg_ksel;                // ksel of the scan (segments hold 2 * ksel keys)
     const uint64_t* prelist;     // [Q][ksel] the pre-pass rows' best keys
-    const uint32_t* tau_base;    // [Q] the pre-pass bound (order-preserving u32)
+    const uint32_t* tau_base;    // [Q] the pre-pass bound (order-preserving u32) -- or, `estimated`, the estimate the scan started from
+    int estimated;               // the scan's starting admission scores were estimates (a shard of a larger gallery): finish counts
+                                 // them as the score an unseen row can have
     const float* marg;           // [Q] admission margins
     const int* dropflag;         // [Q] != 0: the query's segments may be incomplete or hold repeated keys
 };
@@ -240,7 +242,8 @@ int launch_topk_reduce_segs(const uint64_t* seg, const int* seg_cnt, int splits,
 // tau0[q] = the KSEL-th score; hist (optional): the kept scores are counted into the query's histogram
 int launch_topk_select_rows(const float* scores, long ld, int n, int Q, uint64_t* part, long part_row_stride, int slot,
                             uint32_t* tau0, int ksel, uint32_t* hist, int hist_buckets, int hist_shift, hipStream_t st,
-                            uint32_t* tau_copy = nullptr);
+                            uint32_t* tau_copy = nullptr, float est_z = 0.f);
+// (est_z != 0: tau0[q] = max(KSEL-th best score, mean + est_z * sigma of the row's scores): an estimated admission level)
 // all-padding result for an empty gallery
 int launch_topk_fill_empty(float* s, long long* i, int* c, int Q, int k, hipStream_t st);
 // merge P per-shard result lists [P][Q][k] -> [Q][k]

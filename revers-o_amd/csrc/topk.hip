@@ -298,6 +298,9 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __rest
     float U = -INFINITY;
     if (nv < ne) U = key_score(readlane_u64(key, nv));
     else if (ne == ksel) U = key_score(readlane_u64(key, ksel - 1));
+    // the scan started from an ESTIMATED admission score (topk_select_rows_kernel, est_z): rows below it were dropped
+    // unseen, whatever the list holds (a full list whose last entry reaches the estimate proves it was a true bound)
+    if (cert.estimated) U = fmaxf(U, orderable_f32(cert.tau_base[q]));
     const float G = __uint_as_float(cert.gstat[0]), Eg = __uint_as_float(cert.gstat[1]);
     const float eps = cert_eps(cert.qstat[(long)q * 2], cert.qstat[(long)q * 2 + 1], G, Eg, D);
     if (cert.cert_out) {                       // row-sharded search: the merge step decides, over all shards
@@ -422,8 +425,9 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
                                                                         long part_row_stride, int slot,
                                                                         uint32_t* __restrict__ tau0, uint32_t* __restrict__ hist,
                                                                         int hist_buckets, int hist_shift,
-                                                                        uint32_t* __restrict__ tau_copy) {
+                                                                        uint32_t* __restrict__ tau_copy, float est_z) {
     __shared__ uint64_t partial[SEL_MAXW][64];
+    __shared__ float mom[SEL_MAXW][3];          // est_z != 0: per-wave count, sum, sum of squares of the strip's scores
     __shared__ uint64_t cand[SEL_MAXW][64];     // per wave: survivors of pass 2, compacted
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nw = blockDim.x >> 6;
@@ -441,6 +445,22 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
     }
 #pragma unroll
     for (int i = 0; i < SEL_NV; ++i) mx = fmaxf(fmaxf(mx, fmaxf(v[i][0], v[i][1])), fmaxf(v[i][2], v[i][3]));
+    if (est_z != 0.f) {
+        // first two moments of the query's pre-pass scores (for the estimated admission level, below)
+        float n_ = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < SEL_NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = v[i][e];
+                const bool ok = x > -INFINITY;
+                n_ += ok ? 1.f : 0.f;
+                s1 += ok ? x : 0.f;
+                s2 = ok ? fmaf(x, x, s2) : s2;
+            }
+        n_ = wave_sum(n_); s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) { mom[w][0] = n_; mom[w][1] = s1; mom[w][2] = s2; }
+    }
     // T = KSEL-th largest of the 64 lane maxima (order-preserving u32; NaN scores cannot occur: unit rows)
     uint32_t o = f32_orderable(mx);
 #pragma unroll
@@ -511,11 +531,28 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
         }
         if (lane < KSEL) part[(long)q * part_row_stride + (long)slot * KSEL + lane] = run;
         const uint64_t last = readlane_u64(run, KSEL - 1);
-        const uint32_t base = f32_orderable(last ? key_score(last) : -INFINITY);      // order-preserving u32
+        uint32_t base = f32_orderable(last ? key_score(last) : -INFINITY);      // order-preserving u32
+        if (est_z != 0.f) {
+            // One shard of a row-sharded gallery (api.hip, revo_search_set_total_rows): start the scan not from this shard's
+            // own KSEL-th best of the pre-pass rows but from an ESTIMATE of the score that the candidates of the WHOLE
+            // gallery will have to reach -- mean + z sigma of this query's pre-pass scores, z from the quantile
+            // min(64, 2 KSEL) / total rows (a Gaussian tail: what unit vectors in many dimensions give; a heavier tail
+            // only makes the estimate low, which costs survivors, not results).  It is not a bound: the finish step counts
+            // it as the score an unseen row of this shard can have (CertArgs::estimated), and the merge's certificate and
+            // second round make the result exact whatever the estimate was.
+            float n_ = 0.f, s1 = 0.f, s2 = 0.f;
+            for (int ow = 0; ow < nw; ++ow) { n_ += mom[ow][0]; s1 += mom[ow][1]; s2 += mom[ow][2]; }
+            if (n_ > 1.f) {
+                const float mu = s1 / n_;
+                const float var = fmaxf(s2 / n_ - mu * mu, 0.f);
+                const uint32_t eo = f32_orderable(mu + est_z * sqrtf(var));
+                base = eo > base ? eo : base;
+            }
+        }
         if (lane == 0) { tau0[q] = base; if (tau_copy) tau_copy[q] = base; }     // tau_copy: the scan's live bounds start here
         // seed the query's score histogram (origin = this bound) with the kept scores: the scan counts its
         // survivors into the same buckets, so "KSEL scores at or above an edge" includes the pre-pass rows
-        if (hist && last && lane < KSEL && run) {
+        if (hist && last && lane < KSEL && run && (uint32_t)(run >> 32) >= base) {
             uint32_t b = ((uint32_t)(run >> 32) - base) >> hist_shift;
             b = b < (uint32_t)(hist_buckets - 1) ? b : (uint32_t)(hist_buckets - 1);
             atomicAdd(hist + (long)q * hist_buckets + b, 1u);
@@ -524,17 +561,17 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
 }
 int launch_topk_select_rows(const float* scores, long ld, int n, int Q, uint64_t* part, long part_row_stride, int slot,
                             uint32_t* tau0, int ksel, uint32_t* hist, int hist_buckets, int hist_shift, hipStream_t st,
-                            uint32_t* tau_copy) {
+                            uint32_t* tau_copy, float est_z) {
     if (Q <= 0) return 0;
     REVO_REQUIRE(n >= 1 && n <= SEL_STRIP * SEL_MAXW, "search: the pre-pass selection takes at most 65536 columns");
     REVO_REQUIRE(n % 4 == 0 && ld % 4 == 0 && (((uintptr_t)scores) & 15) == 0, "search: pre-pass score rows must be 16-byte aligned");
     const int nw = (n + SEL_STRIP - 1) / SEL_STRIP;
     if (ksel == 32)
         hipLaunchKernelGGL((topk_select_rows_kernel<32>), dim3(Q), dim3(nw * 64), 0, st, scores, ld, n, Q, part,
-                           part_row_stride, slot, tau0, hist, hist_buckets, hist_shift, tau_copy);
+                           part_row_stride, slot, tau0, hist, hist_buckets, hist_shift, tau_copy, est_z);
     else
         hipLaunchKernelGGL((topk_select_rows_kernel<64>), dim3(Q), dim3(nw * 64), 0, st, scores, ld, n, Q, part,
-                           part_row_stride, slot, tau0, hist, hist_buckets, hist_shift, tau_copy);
+                           part_row_stride, slot, tau0, hist, hist_buckets, hist_shift, tau_copy, est_z);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -266,6 +266,11 @@ class Gallery:
         return {"uncertified": int(out[0]), "bruteforced": int(out[1]), "checked": int(out[2]), "collected_rows": int(out[3]),
                 "from_segments": int(out[4])}
 
+    def set_total_rows(self, total_rows):
+        """This handle holds ONE SHARD of a row-sharded gallery of ``total_rows`` rows (0: forget): its two-phase scans
+        start from an estimate of the whole gallery's admission level (include/revo.h, revo_search_set_total_rows)."""
+        _lib.check(self._lib.revo_search_set_total_rows(self._h, int(total_rows)), "revo_search_set_total_rows")
+
     def search_plan(self, n_queries, k=5):
         """How a search would run (reporting): dict with the scan form, the pre-pass rows, slices and ksel."""
         out = (C.c_int64 * 4)()

@@ -80,6 +80,9 @@ class GalleryBackend:
     def merge(self, packed_all, parts, n_queries, k, threshold, certify=False):
         return self._engine.merge_topk_packed(packed_all, parts, n_queries, k, threshold, certify=certify)
 
+    def set_total_rows(self, total_rows):
+        self.gallery.set_total_rows(total_rows)
+
     def exact(self, q_idx, need, k, index_offset):
         out = self._packed("exact", int(q_idx.shape[0]), k)
         self.gallery.search_exact(q_idx, need, k, index_offset, out_packed=out)
@@ -94,10 +97,12 @@ class ShardedSearch:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.local_rows = int(local_rows)
         self.last_uncertified = 0          # queries of the last finished search that needed the second round
+        self._estimating, self._unc_rate = False, 0.0      # see _note_second_rounds
         self._gen = 0                      # searches started (whose candidates the shard handle holds: PendingSearch)
         self._pinned = None                # host landing places of the uncertified counts (search_async)
         self._gbuf = {}                    # gather targets, reused from search to search
         self.offset, self.total_rows = self._exchange_offsets()
+        self._tell_total()
         if torch.cuda.is_available():
             self._pinned = [torch.zeros((1,), dtype=torch.int32).pin_memory() for _ in range(8)]
         self._inflight = [None] * 8
@@ -128,10 +133,33 @@ class ShardedSearch:
         sizes = [int(t.item()) for t in allrows]
         return sum(sizes[: self.rank]), sum(sizes)
 
+    def _note_second_rounds(self, n, n_queries):
+        """The shards start their scans from an ESTIMATE of the whole gallery's admission level (_tell_total), tuned to
+        the tail that unit vectors in many dimensions give.  On data with a lighter tail it comes out too high, the
+        merge's certificate then fails for many queries and every search pays the second round -- exact, but slower
+        than not estimating at all.  So the share of uncertified queries is watched (a running mean; the count is the
+        same on every rank, so every rank decides alike) and above 2 % the estimate is switched off for this gallery."""
+        if not self._estimating or n_queries <= 0:
+            return
+        self._unc_rate = 0.8 * self._unc_rate + 0.2 * (n / n_queries)
+        if self._unc_rate > 0.02:
+            tell = getattr(self.backend, "set_total_rows", None)
+            if tell is not None:
+                tell(0)
+            self._estimating = False
+
+    def _tell_total(self):
+        """The shard's scans start from an estimate of the WHOLE gallery's admission level (backends that can use it)."""
+        tell = getattr(self.backend, "set_total_rows", None)
+        if tell is not None and self.world > 1:
+            tell(self.total_rows)
+            self._estimating, self._unc_rate = True, 0.0
+
     def refresh(self, local_rows):
         """Call after the local shard grew."""
         self.local_rows = int(local_rows)
         self.offset, self.total_rows = self._exchange_offsets()
+        self._tell_total()
 
     def _all_gather(self, out, inp):
         """all_gather_into_tensor; device tensors on a gloo group (a rehearsal of the N > 1 path on one GPU,
@@ -236,6 +264,7 @@ class PendingSearch:
         else:
             n = int(self._unc[0][0])                                             # CPU backends (tests)
         o.last_uncertified = n
+        o._note_second_rounds(n, int(self._queries.shape[0]))
         if n > 0:
             if o._gen == self._gen:
                 self._res = o._second_round(self._res, self._unc, n, self._k, self._thr)
@@ -266,6 +295,9 @@ class LocalShards:
         for g in galleries:
             offs.append(tot)
             tot += len(g)
+        if len(galleries) > 1:
+            for g in galleries:
+                g.set_total_rows(tot)
         return cls([GalleryBackend(g) for g in galleries], offs)
 
     def search(self, queries, k, threshold=None):

@@ -20,6 +20,8 @@ shards = []
 for p in range(P):
     Gp = engine.Gallery(D, shard, device=0)
     Gp.add(full.read(p * shard, shard), normalize=False)
+    if not os.environ.get("REVO_NO_EST"):          # (A/B: without the whole-gallery admission estimate, round 3's behaviour)
+        Gp.set_total_rows(N)
     shards.append(Gp)
 q = torch.randn(Q, D, generator=g, device=dev)
 ksel = engine.search_ksel(k)

@@ -905,3 +905,46 @@ def test_193_to_256_queries_against_the_oracle(dev, Q):
         assert out[1][Q - 1, :min(k, 40)].cpu().tolist() == list(range(N // 3, N // 3 + min(k, 40)))
         assert int(out[1][130, 0]) == 777
     G.close()
+
+
+def test_shard_admission_estimate_that_is_far_too_high_still_gives_the_exhaustive_result(dev):
+    """Shards of a row-sharded gallery start their scans from an ESTIMATE of the whole gallery's admission level (mean + z
+    sigma of the shard's pre-pass scores, revo_search_set_total_rows).  Here the estimate is made useless on purpose: the
+    first rows of shard 0 hold 300 near-copies of MINUS the query (scores ~ -0.95 among scores ~N(0, 0.09)), which blows
+    the sample's sigma up and puts shard 0's estimate (~0.6) above its true matches (~0.55, further down the shard): its
+    scan drops them, its list comes out below the estimate, the merge's certificate fails and the second round re-does
+    the query exactly: merged result == the unsharded search,
+    bit for bit; with a sane estimate (ordinary queries) no second round is needed."""
+    from reverso_amd import sharded
+    D, k, P, n = 128, 10, 2, 40000
+    rng = np.random.default_rng(2718)
+    gal = rng.standard_normal((P * n, D), dtype=np.float32)
+    centre = rng.standard_normal(D).astype(np.float32)
+    early = rng.choice(6000, size=300, replace=False)                            # inside shard 0's pre-pass rows
+    gal[early] = -centre[None] + 0.33 * rng.standard_normal((300, D)).astype(np.float32)    # scores ~ -0.95: sigma blown up
+    late = 20000 + np.arange(12)                                                  # the true matches (~0.55): shard 0, behind its pre-pass
+    gal[late] = centre[None] + 1.5 * rng.standard_normal((12, D)).astype(np.float32)
+    qr = np.concatenate([centre[None], rng.standard_normal((30, D), dtype=np.float32)])
+    G = engine.Gallery(D, P * n, device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    shards = []
+    for p in range(P):
+        Gp = engine.Gallery(D, n, device=0)
+        Gp.add(G.read(p * n, n), normalize=False)
+        shards.append(Gp)
+    ls = sharded.LocalShards.from_galleries(shards)                               # tells every shard the total row count
+    qd = torch.from_numpy(qr).to(dev)
+    ref = G.search(qd, k)
+    out = ls.search(qd, k)
+    assert ls.last_uncertified >= 1                                               # the poisoned query went through the second round
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    assert set(out[1][0].cpu().tolist()) == set(late[:k].tolist()) or set(out[1][0].cpu().tolist()) <= set(late.tolist())
+    _check(out, osearch.search(gal, qr, k), atol=1e-5, near_tie=3e-7)
+    out2 = ls.search(qd[1:], k)                                                   # ordinary queries: the estimate is sane
+    assert ls.last_uncertified == 0
+    for a, b in zip(out2, G.search(qd[1:], k)):
+        assert torch.equal(a, b)
+    for Gp in shards:
+        Gp.close()
+    G.close()
