@@ -948,3 +948,39 @@ def test_shard_admission_estimate_that_is_far_too_high_still_gives_the_exhaustiv
     for Gp in shards:
         Gp.close()
     G.close()
+
+
+def test_shard_admission_estimate_on_clustered_and_on_light_tailed_galleries(dev):
+    """The shards' admission estimate assumes a Gaussian tail.  (1) A clustered gallery (2 000 tight clusters, queries near
+    cluster centres: a HEAVY tail -- a few dozen rows far above the bulk): the estimate comes out low, which costs
+    survivors, not results, and no second round is needed.  (2) Rows and queries with +-1 coordinates (scores are a scaled
+    binomial: bounded, a lighter tail than the Gaussian's far out): whatever the estimate does there -- measured: still no
+    second round at 256 dimensions -- the result must be the exhaustive one.  Both: merged == unsharded, bit for bit."""
+    from reverso_amd import sharded
+    D, k, P, n = 256, 10, 4, 40000
+    rng = np.random.default_rng(99)
+    centres = rng.standard_normal((2000, D), dtype=np.float32)
+    gal = centres[rng.integers(0, 2000, P * n)] + 0.25 * rng.standard_normal((P * n, D), dtype=np.float32)
+    qr = centres[rng.integers(0, 2000, 200)] + 0.25 * rng.standard_normal((200, D), dtype=np.float32)
+    light = np.sign(rng.standard_normal((P * n, D), dtype=np.float32))            # +-1 rows: scores of a +-1 query are a narrow binomial
+    ql = np.sign(rng.standard_normal((64, D), dtype=np.float32))
+    for name, g_np, q_np in (("clustered", gal, qr), ("light-tailed", light, ql)):
+        G = engine.Gallery(D, P * n, device=0)
+        G.add(torch.from_numpy(g_np).to(dev))
+        shards = []
+        for p in range(P):
+            Gp = engine.Gallery(D, n, device=0)
+            Gp.add(G.read(p * n, n), normalize=False)
+            shards.append(Gp)
+        ls = sharded.LocalShards.from_galleries(shards)
+        qd = torch.from_numpy(q_np).to(dev)
+        ref = G.search(qd, k)
+        out = ls.search(qd, k)
+        print(name, "uncertified after the merge:", ls.last_uncertified, "of", len(q_np))
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b), name
+        if name == "clustered":
+            assert ls.last_uncertified <= len(q_np) // 20
+        for Gp in shards:
+            Gp.close()
+        G.close()
