@@ -120,6 +120,10 @@ int32_t revo_search_ksel(int32_t k);     /* candidates the scan keeps per query 
  * not trusted: step 4's certificate counts it as the score an unseen row may have, and step 5 re-does what it cannot
  * certify -- results are the exhaustive search's whatever the estimate was.  revo_search_topk ignores the setting. */
 int32_t revo_search_set_total_rows(revo_gallery* g, int64_t total_rows);
+/* 1 if a two-phase search for the best k on shards that know the total row count scans against that estimate (then every
+ * shard's list is already cut at the whole gallery's level and step 2's exchange may be skipped: pass all_bounds = NULL to
+ * revo_search_finish on EVERY rank), 0 if not (k > 25: those scans run with the admission margin of revo_search_topk instead) */
+int32_t revo_search_estimates(int32_t k);
 /* how a search of n_queries against the gallery's current rows would run (reporting only): out4 = { 1 if the 256 x 256
  * scan takes it (0: the small-gallery scan), rows covered by the pre-pass GEMM, gallery slices per query tile, ksel } */
 int32_t revo_search_plan(const revo_gallery* g, int32_t n_queries, int32_t k, int64_t* out4);

@@ -50,6 +50,7 @@ SIGNATURES = {
     "revo_search_topk": (_i32, [_p, _p, _i32, _i32, _i32, _f32, _i64, _p, _p, _p, _p]),
     "revo_search_ksel": (_i32, [_i32]),
     "revo_search_set_total_rows": (_i32, [_p, _i64]),
+    "revo_search_estimates": (_i32, [_i32]),
     "revo_search_plan": (_i32, [_p, _i32, _i32, C.POINTER(C.c_int64)]),
     "revo_search_candidates": (_i32, [_p, _p, _i32, _i32, _i32, _p, _p]),
     "revo_search_finish": (_i32, [_p, _i32, _i32, _i32, _f32, _i64, _p, _i32, _i32, _p, _p, _p, _p, _p]),

@@ -955,6 +955,10 @@ static int search_fallback(revo_gallery* g, int max_entries, int k, int has_thr,
 // over-selection: the bf16 scan keeps ksel >= k + margin candidates, the fp32 re-score decides
 static int search_ksel(int k) { return (k <= 16) ? 32 : 64; }
 extern "C" int32_t revo_search_ksel(int32_t k) { return (k >= 1 && k <= 50) ? search_ksel(k) : -1; }
+// k > 25: the scan runs with the admission margin (revo_search_topk); a shard's two-phase scan estimates the whole gallery's
+// admission level only without it -- one rule, asked for by the host side that decides whether to exchange bounds
+static bool search_uses_margin(int k) { return k > 25; }
+extern "C" int32_t revo_search_estimates(int32_t k) { return (k >= 1 && k <= 50) ? (search_uses_margin(k) ? 0 : 1) : -1; }
 extern "C" int32_t revo_search_plan(const revo_gallery* g, int32_t Q, int32_t k, int64_t* out4) {
     REVO_REQUIRE(g && out4 && Q >= 1 && k >= 1 && k <= 50, "search_plan: bad arguments");
     const long N = g->size;
@@ -990,7 +994,7 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
     // (Not for smaller k, not even on very large galleries where a second pass costs most of a search: measured on 10 M x
     //  1536 with 256 queries, the margin's extra survivors cost the scan 18 % on EVERY search -- 7.5 -> 8.9 ms -- to save a
     //  pass that the 64-candidate lists kept there for every k already make a rarity.)
-    CHECK_RC(search_candidates(g, queries, Q, ksel, st, nullptr, 0, k > 25));
+    CHECK_RC(search_candidates(g, queries, Q, ksel, st, nullptr, 0, search_uses_margin(k)));
     const CertArgs ca = g->cert_args(nullptr);
     { ProfScope ps("topk_finish", st);
       CHECK_RC(launch_topk_finish(g->cand, g->cand_stride, ksel, g->qf, g->D, g->keep_f32 ? g->gf : nullptr, g->D, g->D, Q, k,
@@ -1021,7 +1025,7 @@ extern "C" int32_t revo_search_candidates(revo_gallery* g, const float* queries,
     }
     // (the published scores come out of the final selection kernel: no launch of their own; k > 25: with the admission
     //  margin, so that the second round the merge's certificate then asks for needs no pass over the shard -- revo_search_topk)
-    return search_candidates(g, queries, Q, ksel, st, bounds, top_m, k > 25);
+    return search_candidates(g, queries, Q, ksel, st, bounds, top_m, search_uses_margin(k));
     API_END
 }
 extern "C" int32_t revo_search_finish(revo_gallery* g, int32_t Q, int32_t k, int32_t has_thr, float thr,

@@ -249,6 +249,14 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __rest
         const int brank = 2 * ksel < 64 ? 2 * ksel : 64;
         bound = (uint32_t)__shfl((int)run, brank - 1, 64);     // 0 while fewer than that were published
     }
+    // (a scan that started from an estimated admission score, CertArgs::estimated: entries below the estimate -- rows of the
+    //  pre-pass list that the estimate overtook -- are not worth a re-score: the certificate counts the estimate as the
+    //  score an un-re-scored row may have anyway.  With the estimate in place a shard's list is about as short as the
+    //  exchanged bound would make it, so the sharded search can do without that exchange: sharded.py)
+    if (has_cert && cert.estimated) {
+        const uint32_t eo = cert.tau_base[q];
+        bound = eo > bound ? eo : bound;
+    }
     const bool valid = key != 0ull && (uint32_t)(key >> 32) >= bound;
     const uint32_t idx = key_index(key);
     float score = valid ? key_score(key) : -INFINITY;

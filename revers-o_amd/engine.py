@@ -346,6 +346,11 @@ class Gallery:
         return scores, idx, counts
 
 
+def search_estimates(k):
+    """True if shards that know the whole gallery's row count scan a best-k search against its estimated admission level."""
+    return int(_lib.load().revo_search_estimates(int(k))) == 1
+
+
 def search_ksel(k):
     """Candidates the scan keeps per query for a top-k search (32 or 64)."""
     return int(_lib.load().revo_search_ksel(int(k)))

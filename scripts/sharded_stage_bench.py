@@ -48,7 +48,8 @@ for p, Gp in enumerate(shards):
     Gp.search_finish(Q, k, allb, None, p * shard, out_packed=packed[p * pb:(p + 1) * pb])
 shards[0].search_candidates(q, k, top_m)
 tf, stf = timed(lambda: shards[0].search_finish(Q, k, allb, None, 0, out_packed=packed[:pb]))
-tfu, _ = timed(lambda: shards[0].search_finish(Q, k, None, None, 0, out_packed=packed[:pb]))
+tfu, _ = timed(lambda: shards[0].search_finish(Q, k, None, None, 0, out_packed=packed[:pb]))      # no exchanged bounds: with the
+# shards' admission estimate the lists are cut at the estimate instead (what sharded.py does then: one all-gather fewer)
 tm, stm = timed(lambda: engine.merge_topk_packed(packed, P, Q, k))
 s_ref, i_ref, c_ref = full.search(q, k)
 for p, Gp in enumerate(shards):
@@ -56,7 +57,10 @@ for p, Gp in enumerate(shards):
     Gp.search_finish(Q, k, allb, None, p * shard, out_packed=packed[p * pb:(p + 1) * pb])
 s2, i2, c2 = engine.merge_topk_packed(packed, P, Q, k)
 kept = int((packed.view(P, pb)[:, : Q * k * 8].contiguous().view(torch.int64) >= 0).sum())
-comm_ms = 2 * 0.06     # assumption: two latency-bound RCCL all-gathers (0.3 MB and 1.2 MB per rank) at ~60 us each on xGMI
+EST = not os.environ.get("REVO_NO_EST")
+# assumption: latency-bound RCCL all-gathers at ~60 us each on xGMI -- two (admission scores 0.3 MB, packed top-k 1.2 MB per
+# rank), or only the second when the shards scan against the estimated level (sharded.py leaves the first out then)
+comm_ms = (1 if EST else 2) * 0.06
 # the certificate's second round: the whole protocol in one process over the 8 shards tells how many queries
 # need it; its per-rank cost = the exact pass of ONE shard for those queries (+ a third, small all-gather when it happens)
 from reverso_amd import sharded
@@ -72,13 +76,13 @@ if n_unc:
     shards[0].search_candidates(q, k, top_m)
     t_exact, _ = timed(lambda: shards[0].search_exact(qi, need, k, 0))
     comm_ms += 0.06
-t8 = tc + tf + tm + comm_ms + t_exact
+t8 = tc + (tfu if EST else tf) + tm + comm_ms + t_exact
 print(json.dumps({
     "N": N, "Q": Q, "shards": P, "top_m": top_m,
     "one_gpu_ms": round(t1, 4), "one_gpu_stage_ms": {c: round(v, 4) for c, v in sorted(st1.items())},
     "per_rank_phase1_ms": round(tc, 4), "phase1_stage_ms": {c: round(v, 4) for c, v in sorted(stc.items())},
     "per_rank_finish_bounded_ms": round(tf, 4), "finish_unbounded_ms": round(tfu, 4), "merge_ms": round(tm, 4),
-    "assumed_comm_ms": comm_ms, "projected_8gpu_ms": round(t8, 4), "projected_speedup": round(t1 / t8, 3),
+    "assumed_comm_ms": comm_ms, "shards_estimate_the_whole_gallerys_level": EST, "projected_8gpu_ms": round(t8, 4), "projected_speedup": round(t1 / t8, 3),
     "uncertified_queries_sharded": n_unc, "uncertified_queries_one_gpu": full_unc, "per_rank_exact_round_ms": round(t_exact, 4),
     "results_equal_unsharded": bool(torch.equal(i3, i_ref) and torch.equal(s3, s_ref) and torch.equal(c3, c_ref)),
     "first_round_equal_unsharded": bool(torch.equal(i2, i_ref) and torch.equal(s2, s_ref) and torch.equal(c2, c_ref)),

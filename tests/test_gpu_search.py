@@ -653,9 +653,10 @@ def test_config4_gallery_10m_x_1536(dev):
 
 def test_sharded_two_phase_with_certificate_equals_unsharded(dev):
     """Eight shards in one process through the whole protocol (revers-o_amd/sharded.py LocalShards: candidates, bound
-    exchange, bounded re-score with per-shard certificate bounds, packed merge with the cross-shard certificate, second
-    exact round) on a gallery of near-duplicate clusters that overflow the candidate lists: the merged result equals
-    the unsharded search bit for bit (both are the exhaustive fp32 search), and the second round was needed."""
+    exchange or estimated level, bounded re-score with per-shard certificate bounds, packed merge with the cross-shard
+    certificate, second exact round where needed) on a gallery of near-duplicate clusters that overflow the unsharded
+    search's candidate lists: the merged result equals the unsharded search bit for bit (both are the exhaustive fp32
+    search)."""
     from reverso_amd import sharded
     N, D, Q, k = 160000, 128, 64, 10
     rng = np.random.default_rng(77)
@@ -679,7 +680,11 @@ def test_sharded_two_phase_with_certificate_equals_unsharded(dev):
         ref = G.search(qd, k, thr)
         assert G.search_stats()["uncertified"] >= Q // 2
         out = ls.search(qd, k, thr)
-        assert Q // 4 <= ls.last_uncertified < Q          # (the shards together re-score 64 rows per query: a few clusters certify)
+        # (up to round 3 the shards together re-scored ~64 rows per query and the clusters of 120 sent most queries through
+        #  the second round; a shard that scans against the whole gallery's estimated level keeps and re-scores ALL its rows
+        #  above that level -- every cluster member -- and the merge certifies them: the second round is exercised by
+        #  test_shard_admission_estimate_that_is_far_too_high_... and the limit-50 tests instead)
+        assert 0 <= ls.last_uncertified <= Q
         for a, b in zip(out, ref):
             assert torch.equal(a, b)
     _check(ref if thr is None else G.search(qd, k, None), osearch.search(gal, qr, k), atol=1e-5, near_tie=3e-7)
