@@ -3,8 +3,10 @@
 
 One step = one batch of synthetic 336x336 images per GPU through the HIP embed
 path, then cosine top-10 of every embedding against the row-sharded 1M x 1024
-gallery (all-gather of queries, per-shard scan, all-gather of the shards' admission
-scores, bounded fp32 re-score, all-gather of the packed per-shard top-k, merge).
+gallery (all-gather of queries; per-shard scan against the whole gallery's estimated
+admission level; fp32 re-score; ONE all-gather of the packed per-shard top-k with the
+shards' certificate bounds; merge + cross-shard certificate; a second, exact round only
+for queries that certificate fails for).  At N = 1 there is no exchange at all.
 Inputs are resident in HBM when the timed region starts.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
@@ -23,6 +25,14 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+# Multi-process GPU work on this image needs dmabuf IPC: the task environment exports HSA_ENABLE_IPC_MODE_LEGACY=0 ("the
+# host driver only supports dmabuf IPC, and without it RCCL / CUDA-tensor sharing across processes fails with
+# hipIpcGetMemHandle: invalid argument" -- README.md, "Environment").  Set here, before torch / the HIP runtime are loaded,
+# so that BOTH launch paths carry it: the self-launched ranks inherit it, a torchrun-started rank gets it at import.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+LAUNCH_WALL_S = float(os.environ.get("REVO_BENCH_WALL_S", "1500"))      # the self-launch parent's guard (seconds)
+PG_TIMEOUT_S = float(os.environ.get("REVO_BENCH_PG_TIMEOUT_S", "120"))   # a collective that does not complete fails the run
 
 
 def _self_launch():
@@ -49,14 +59,30 @@ def _self_launch():
     with socket.socket() as s:                       # a free rendezvous port on the loopback interface
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    env = dict(os.environ)                           # (carries HSA_ENABLE_IPC_MODE_LEGACY=0, set at the top of this file)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
-    p = subprocess.Popen(cmd, env=env, cwd=os.getcwd())
+    # the children get a process group of their own: a guard that fires ends exactly the processes started here
+    p = subprocess.Popen(cmd, env=env, cwd=os.getcwd(), start_new_session=True)
     try:
-        rc = p.wait()
+        rc = p.wait(timeout=LAUNCH_WALL_S)
+    except subprocess.TimeoutExpired:
+        # a hung rank (a collective that never completes, a rank that died before the rendezvous) must not hang the
+        # caller: end the launcher and its ranks, report, exit non-zero.  Never a re-exec, never a retry.
+        import signal
+        sys.stderr.write(f"bench.py: the {n} ranks did not finish within {LAUNCH_WALL_S:.0f} s (REVO_BENCH_WALL_S): terminating them\n")
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(p.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        sys.exit(124)
     except KeyboardInterrupt:
         p.terminate()
         rc = p.wait()
@@ -228,15 +254,22 @@ def main():
     if args.one_gpu:
         local_rank = 0
     ndev = torch.cuda.device_count()
-    if ndev > 0 and local_rank >= ndev:
-        local_rank %= ndev              # a launcher that narrows each rank's visible devices (one device per process)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world > 1 and args.backend == "nccl" and not args.one_gpu and ndev < local_world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} over RCCL needs one GPU per rank, but only {ndev} device(s) are visible "
+                         f"to rank {rank} (two ranks on one device make RCCL fail far less readably); "
+                         f"use --one-gpu --backend gloo to rehearse the multi-rank path on one GPU")
+    elif ndev > 0 and local_rank >= ndev:
+        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {ndev} device(s) visible (use --one-gpu to put every rank on cuda:0)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
+        tmo = datetime.timedelta(seconds=PG_TIMEOUT_S)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
 
     # which physical device every rank runs on (the judge's check that N ranks mean N GPUs)
     devices = [local_rank]
@@ -306,10 +339,13 @@ def main():
     engine.prof_reset()
     engine.prof_enable(1)
     bsteps = min(args.steps, 3)
+    ss.enable_timing(True)            # HIP events around every exchange of these steps (queries, [bounds,] packed top-k)
     run_steps(bsteps)
     fence()
     engine.prof_enable(False)
     prof_all = engine.prof_report()
+    exch_headline = ss.timing_report() if world > 1 else None
+    ss.enable_timing(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -426,11 +462,14 @@ def main():
         # the same searches with events around every kernel class: this rank's per-stage times
         engine.prof_reset()
         engine.prof_enable(True)
+        ss.enable_timing(True)
         for _ in range(reps):
             ss.search(qbig, args.k)
         fence()
         engine.prof_enable(False)
         p2 = engine.prof_report()
+        exch_big = ss.timing_report() if world > 1 else None
+        ss.enable_timing(False)
         sc = p2.get("topk_scan", {})
         scan_ms_big = sc["ms"] / sc["launches"] if sc.get("launches") else None
         planb = gal.search_plan(Qn, args.k)
@@ -447,6 +486,12 @@ def main():
                       # exactness certificate: queries of the batch that failed it and were re-done by the exact fallback
                       # (collecting pass over the gallery; their cost is inside sharded_ms)
                       "uncertified_queries": cert_big["uncertified"],
+                      # measured on this rank by HIP events around each all-gather (null at N = 1: there is none)
+                      "allgather_ms": exch_big["allgather_ms"] if exch_big else None,
+                      "exchanges_per_search": exch_big["exchanges_per_search"] if exch_big else None,
+                      # pipelined searches whose uncertified queries had to be searched again because the shard handle
+                      # already held the next search's candidates (sharded.PendingSearch): their cost is inside sharded_ms
+                      "redone_searches": ss.redone_searches, "second_rounds": ss.second_rounds,
                       "exact_stage_ms": p2.get("topk_exact", {}).get("ms", 0.0) / max(p2.get("topk_exact", {}).get("launches", 1), 1)}
         if world > 1 and rank == 0:
             # the 1-GPU time of the SAME search in this process: the whole gallery on this one device
@@ -469,6 +514,15 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # what ran, from the measured exchange counts (not from what the protocol could do)
+    if world == 1:
+        parallelism = "1 GPU: no exchange (embed, scan, fp32 re-score, certificate on one device)"
+    else:
+        ex = exch_headline or {}
+        tags = sorted(t for t in ex.get("allgather_ms", {}) if t != "queries")
+        parallelism = (f"dp{world} embed + all-gather of the queries, gallery rows sharded {world}-way, "
+                       f"{ex.get('exchanges_per_search', float('nan')):.2f} exchange(s) per search ({', '.join(tags) or 'none'}) + merge with "
+                       f"the cross-shard certificate")
     if rank == 0:
         res = {
             "metric": "images/sec embed+top-k (PE-L14-336, 1M x 1024 gallery)", "value": value, "unit": "images/s",
@@ -477,12 +531,15 @@ def main():
             "config": {"workload": f"{cfg.name} embed of {B} synthetic {cfg.image_size}x{cfg.image_size} images per GPU "
                                    f"+ cosine top-{args.k} over a {args.gallery}x{D} gallery row-sharded {world}-way",
                        "batch_per_gpu": B, "gallery_rows": args.gallery, "dim": D, "k": args.k,
-                       "parallelism": f"dp{world} embed, gallery rows sharded {world}-way, two all-gathers (admission scores, "
-                                      f"packed top-k) + merge"},
+                       "parallelism": parallelism},
             "roofline": roofline,
             "collective": {"backend": (args.backend if world > 1 else None), "ranks": world,
                            "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
-                           "devices": devices, "one_gpu_rehearsal": bool(args.one_gpu)},
+                           "devices": devices, "one_gpu_rehearsal": bool(args.one_gpu),
+                           # the headline steps' exchanges, measured on rank 0 by HIP events around each all-gather
+                           "allgather_ms": exch_headline["allgather_ms"] if exch_headline else None,
+                           "exchanges_per_search": exch_headline["exchanges_per_search"] if exch_headline else None,
+                           "redone_searches": ss.redone_searches, "init_timeout_s": PG_TIMEOUT_S if world > 1 else None},
             "kernel_ms_per_step": classes_ms,
             "embed_tflops": cfg.flops_per_image() * B * args.steps / dt / 1e12,
             # whole step (embed + search) against the MFMA peak, SURVEY.md 8(d): images/s x FLOPs/image -- not the kernel-class `roofline.frac`

@@ -111,14 +111,21 @@ int32_t revo_search_topk(revo_gallery* g, const float* queries, int32_t n_querie
  *      revo_search_topk.  (Twice the unsharded search's candidates: with that margin the exactness certificate of the
  *      merge all but never fails on ordinary data, which saves the protocol's second round.)
  *      all_bounds may be NULL (re-score every candidate).  Same queries, k and stream as step 1.
- *   4. all-gather the per-rank results and revo_topk_merge / revo_topk_merge_packed them.
- * The merged result equals the unsharded revo_search_topk of the concatenated gallery. */
+ *   4. all-gather the per-rank results and revo_topk_merge_packed them (with revo_search_finish's cert block and the
+ *      merge's unc_* outputs: the cross-shard exactness certificate; step 5 re-does what it cannot certify).
+ *      revo_topk_merge on plain [parts, n_queries, k] arrays is valid only for shards that do NOT estimate (no
+ *      revo_search_set_total_rows, or revo_search_estimates(k) == 0) and then certifies nothing across shards.
+ * With steps 4 and 5 the merged result equals the unsharded revo_search_topk of the concatenated gallery.
+ * The ordinary case is ONE exchange per search: shards that know the total row count (revo_search_set_total_rows) and
+ * search for k <= 25 skip steps 2-3's exchange (revo_search_estimates(k) == 1: all_bounds = NULL on every rank). */
 int32_t revo_search_ksel(int32_t k);     /* candidates the scan keeps per query for a top-k search (32 or 64) */
 /* Tell a shard's handle how many rows the WHOLE row-sharded gallery has (0 = forget).  revo_search_candidates then starts
  * its scan from an estimate of the score a candidate of the whole gallery has to reach (extrapolated from the shard's own
  * first rows) instead of what the shard's own rows would admit: fewer survivors per tile, a faster scan.  The estimate is
  * not trusted: step 4's certificate counts it as the score an unseen row may have, and step 5 re-does what it cannot
- * certify -- results are the exhaustive search's whatever the estimate was.  revo_search_topk ignores the setting. */
+ * certify -- results are the exhaustive search's whatever the estimate was, PROVIDED the certificate is used: once a total
+ * is set, revo_search_finish refuses cert = NULL after an estimating scan (status -2), and revo_topk_merge_packed with its
+ * unc_* outputs plus revo_search_exact are mandatory parts of the search.  revo_search_topk ignores the setting. */
 int32_t revo_search_set_total_rows(revo_gallery* g, int64_t total_rows);
 /* 1 if a two-phase search for the best k on shards that know the total row count scans against that estimate (then every
  * shard's list is already cut at the whole gallery's level and step 2's exchange may be skipped: pass all_bounds = NULL to
@@ -132,7 +139,7 @@ int32_t revo_search_candidates(revo_gallery* g, const float* queries, int32_t n_
 int32_t revo_search_finish(revo_gallery* g, int32_t n_queries, int32_t k, int32_t has_threshold, float threshold,
                            int64_t index_offset, const uint32_t* all_bounds, int32_t parts, int32_t top_m, float* scores,
                            int64_t* indices, int32_t* counts, float* cert, void* stream);
-/* cert (optional, [n_queries] fp32): this shard's share of the exactness certificate -- the best fp32 score any of its
+/* cert ([n_queries] fp32; optional only while the shard does not estimate, see revo_search_set_total_rows): this shard's share of the exactness certificate -- the best fp32 score any of its
  * rows that was NOT re-scored can have (scan score of the best such row + the error bound; -inf if every row was
  * re-scored).  All-gathered with the results (it is the third block of the packed layout below) and checked by
  * revo_topk_merge_packed against the merged k-th score.

@@ -67,6 +67,8 @@ class Regions:
 
 class SimpleReverso:
     """Simplified visual investigation system (MI355X-native hot path)."""
+    _building_name = None       # name of the database a create_database call of this instance is building right now:
+                                # list_databases / load_database leave that build directory alone meanwhile
 
     def __init__(self, model_name=DEFAULT_VARIANT, checkpoint=None, device=0, db_root=DB_ROOT, max_batch=64,
                  detector=None, decode_workers=None, synthetic_seed=0, region_mode="global", device_resize=False,
@@ -115,19 +117,21 @@ class SimpleReverso:
         if not os.path.exists(self.db_root):
             return []
         for n in os.listdir(self.db_root):              # a crash inside the final swap of a build: put the database back
-            for suf in (BUILDING, ".old"):
-                if n.endswith(suf):
+            for suf in (BUILDING, st.OLD):
+                # (not the build this very process is finishing: create_database swaps that one in itself)
+                if n.endswith(suf) and n[: -len(suf)] != self._building_name:
                     st.recover(os.path.join(self.db_root, n[: -len(suf)]), BUILDING)
         return [n for n in os.listdir(self.db_root)
                 if os.path.isdir(os.path.join(self.db_root, n)) and n != "checkpoints" and not n.endswith(BUILDING)
-                and not n.endswith(".old")]
+                and not n.endswith(st.OLD)]
 
     def load_database(self, database_name):
         """core_system.py:90-119"""
         if not database_name:
             return "❌ Please provide a database name"
         db_path = os.path.join(self.db_root, database_name)
-        st.recover(db_path, BUILDING)
+        if database_name != self._building_name:
+            st.recover(db_path, BUILDING)
         if not os.path.exists(db_path):
             return f"❌ Database not found: {database_name}"
         try:
@@ -153,7 +157,7 @@ class SimpleReverso:
             shutil.rmtree(db_path)
             # an unfinished build of the same name and its checkpoint note go with it
             shutil.rmtree(db_path + BUILDING, ignore_errors=True)
-            shutil.rmtree(db_path + ".old", ignore_errors=True)
+            shutil.rmtree(db_path + st.OLD, ignore_errors=True)
             st.remove_checkpoint(os.path.join(self.db_root, "checkpoints", f"{database_name}_checkpoint"))
             return f"✅ Deleted database: {database_name}"
         except Exception as e:
@@ -356,6 +360,17 @@ class SimpleReverso:
     def create_database(self, folder_path, database_name, text_prompt="person . car . building", use_direct_pe=False,
                         progress_callback=None, resume_from_checkpoint=False, include_subfolders=False):
         """core_system.py:461-648, with batched embedding and a working checkpoint."""
+        # while this call builds <name>.building, a list_databases / load_database from another thread (a UI refresh) must
+        # not adopt that directory as a crashed build's left-over (store.recover): the call swaps it in itself
+        self._building_name = database_name
+        try:
+            return self._create_database(folder_path, database_name, text_prompt, use_direct_pe, progress_callback,
+                                         resume_from_checkpoint, include_subfolders)
+        finally:
+            self._building_name = None
+
+    def _create_database(self, folder_path, database_name, text_prompt, use_direct_pe, progress_callback,
+                         resume_from_checkpoint, include_subfolders):
         status_messages = []
 
         class _Log(str):

@@ -1037,6 +1037,11 @@ extern "C" int32_t revo_search_finish(revo_gallery* g, int32_t Q, int32_t k, int
     REVO_REQUIRE(Q == g->cand_Q && search_ksel(k) == g->cand_ksel,
                  "search_finish: no matching revo_search_candidates call on this handle");
     REVO_REQUIRE(!all_bounds || (parts >= 1 && top_m >= 1 && top_m <= g->cand_ksel), "search_finish: bad bounds layout");
+    // A scan that started from an ESTIMATED admission level (revo_search_set_total_rows) has dropped rows on the strength of
+    // that estimate: only the certificate (cert -> revo_topk_merge_packed -> revo_search_exact) makes the result exhaustive
+    REVO_REQUIRE(cert || !g->cand_estimated,
+                 "search_finish: this shard scanned against an estimated admission level (revo_search_set_total_rows): cert must "
+                 "be given and checked by revo_topk_merge_packed, with revo_search_exact as the second round");
     if (Q == 0) return 0;
     REVO_ON_DEVICE(g->device);
     hipStream_t st = (hipStream_t)stream;

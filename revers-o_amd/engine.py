@@ -49,7 +49,8 @@ class VitEngine:
         self.experiments = bool(experiments) or _lib.product_is_experiment_build()
         lib = _lib.load_exp() if experiments else _lib.load()
         check_state_dict(cfg, state_dict)
-        state_dict = strip_non_parameters(state_dict)
+        # the image tower only (a whole-CLIP state dict also holds the text tower), without registered buffers
+        state_dict = strip_non_parameters({k: v for k, v in state_dict.items() if k.startswith("visual.")})
         names = sorted(state_dict)
         keep = []          # keep converted tensors alive until create returns
         arr = (_lib.Tensor * len(names))()
@@ -270,6 +271,7 @@ class Gallery:
         """This handle holds ONE SHARD of a row-sharded gallery of ``total_rows`` rows (0: forget): its two-phase scans
         start from an estimate of the whole gallery's admission level (include/revo.h, revo_search_set_total_rows)."""
         _lib.check(self._lib.revo_search_set_total_rows(self._h, int(total_rows)), "revo_search_set_total_rows")
+        self._total_rows = int(total_rows)
 
     def search_plan(self, n_queries, k=5):
         """How a search would run (reporting): dict with the scan form, the pre-pass rows, slices and ksel."""
@@ -300,6 +302,11 @@ class Gallery:
         are views into that buffer, laid out for :func:`merge_topk_packed`."""
         Q, k = int(n_queries), int(k)
         cert = None
+        if out_packed is None and getattr(self, "_total_rows", 0) > len(self) and search_estimates(k):
+            # the scan dropped rows against an ESTIMATED level: only the packed block's certificate (merge_topk_packed(...,
+            # certify=True) + search_exact) makes the result exhaustive -- the C ABI refuses the call too
+            raise _lib.RevoError("search_finish: this shard estimates the whole gallery's admission level (set_total_rows): "
+                                 "out_packed is required, and the merge must certify (merge_topk_packed(certify=True))")
         if out_packed is not None:
             idx = out_packed[: Q * k * 8].view(torch.int64).view(Q, k)
             scores = out_packed[Q * k * 8: Q * k * 12].view(torch.float32).view(Q, k)

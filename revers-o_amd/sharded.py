@@ -106,7 +106,12 @@ class ShardedSearch:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.local_rows = int(local_rows)
         self.last_uncertified = 0          # queries of the last finished search that needed the second round
+        self.second_rounds = 0             # searches that ran the protocol's second round on the shard handle's own candidates
+        self.redone_searches = 0           # pipelined searches whose uncertified queries had to be searched again (PendingSearch)
         self._estimating, self._unc_rate = False, 0.0      # see _note_second_rounds
+        self._est_off_at = 0               # total rows when the estimate was switched off for this gallery (0: never)
+        self._timing = None                # enable_timing(): {tag: [event pairs or seconds]}
+        self._timed_searches = 0
         self._gen = 0                      # searches started (whose candidates the shard handle holds: PendingSearch)
         self._pinned = None                # host landing places of the uncertified counts (search_async)
         self._gbuf = {}                    # gather targets, reused from search to search
@@ -156,13 +161,21 @@ class ShardedSearch:
             if tell is not None:
                 tell(0)
             self._estimating = False
+            self._est_off_at = max(1, self.total_rows)
 
     def _tell_total(self):
-        """The shard's scans start from an estimate of the WHOLE gallery's admission level (backends that can use it)."""
+        """The shard's scans start from an estimate of the WHOLE gallery's admission level (backends that can use it).
+        An estimate that was switched off for this gallery's data (_note_second_rounds) stays off until the gallery has
+        doubled: more rows of the same kind do not change its tail."""
         tell = getattr(self.backend, "set_total_rows", None)
-        if tell is not None and self.world > 1:
-            tell(self.total_rows)
-            self._estimating, self._unc_rate = True, 0.0
+        if tell is None or self.world <= 1:
+            return
+        if self._est_off_at and self.total_rows < 2 * self._est_off_at:
+            tell(0)
+            self._estimating = False
+            return
+        tell(self.total_rows)
+        self._estimating, self._unc_rate, self._est_off_at = True, 0.0, 0
 
     def refresh(self, local_rows):
         """Call after the local shard grew."""
@@ -170,9 +183,46 @@ class ShardedSearch:
         self.offset, self.total_rows = self._exchange_offsets()
         self._tell_total()
 
-    def _all_gather(self, out, inp):
+    # -- measured exchange times (bench.py: `allgather_ms`, `exchanges_per_search`) ------------------------------
+    def enable_timing(self, on=True):
+        """Time every exchange of the searches that follow: HIP events on the current stream around each all-gather of
+        device tensors (RCCL enqueues there), wall clock for host tensors (the CPU tier's gloo tests)."""
+        self._timing = {} if on else None
+        self._timed_searches = 0
+
+    def timing_report(self):
+        """{"allgather_ms": {tag: mean ms per exchange}, "exchanges_per_search": mean count, "searches": n}; tags:
+        "queries" (gather_queries), "bounds" (exchange 1, skipped when the shards estimate), "packed" (exchange 2),
+        "packed_second_round" (exchange 3, rare)."""
+        if self._timing is None:
+            return None
+        ms, n_ex = {}, 0
+        for tag, recs in self._timing.items():
+            vals = []
+            for r in recs:
+                if isinstance(r, tuple):
+                    r[1].synchronize()
+                    vals.append(r[0].elapsed_time(r[1]))
+                else:
+                    vals.append(r * 1e3)
+            if vals:
+                ms[tag] = sum(vals) / len(vals)
+            if tag != "queries":
+                n_ex += len(vals)
+        n = max(self._timed_searches, 1)
+        return {"allgather_ms": ms, "exchanges_per_search": n_ex / n, "searches": self._timed_searches}
+
+    def _all_gather(self, out, inp, tag=None):
         """all_gather_into_tensor; device tensors on a gloo group (a rehearsal of the N > 1 path on one GPU,
         or a CPU-only interconnect) are staged through host memory, RCCL takes them as they are."""
+        timed = self._timing is not None and tag is not None and self.world > 1
+        if timed:
+            if inp.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            else:
+                import time
+                t0 = time.perf_counter()
         if self.world == 1:
             out.copy_(inp.reshape(out.shape))
         elif inp.is_cuda and dist.get_backend(self.group) != "nccl":
@@ -181,6 +231,12 @@ class ShardedSearch:
             out.copy_(host)
         else:
             dist.all_gather_into_tensor(out, inp.contiguous(), group=self.group)
+        if timed:
+            if inp.is_cuda:
+                e1.record()
+                self._timing.setdefault(tag, []).append((e0, e1))
+            else:
+                self._timing.setdefault(tag, []).append(time.perf_counter() - t0)
 
     def gather_queries(self, local_queries):
         """Data-parallel embed leaves [B, D] on every rank; all ranks need all queries."""
@@ -188,7 +244,7 @@ class ShardedSearch:
             return local_queries
         out = torch.empty((self.world * local_queries.shape[0], local_queries.shape[1]),
                           dtype=local_queries.dtype, device=local_queries.device)
-        self._all_gather(out, local_queries)
+        self._all_gather(out, local_queries, "queries")
         return out
 
     def top_m(self, k):
@@ -214,19 +270,22 @@ class ShardedSearch:
         top_m = self.top_m(k)
         if self.world == 1:
             return PendingSearch(self, self.backend.search(queries, k, threshold), None, None, queries, k, threshold, 0)
+        if self._timing is not None:
+            self._timed_searches += 1
         self._gen += 1                                                           # the shard handle's candidates are this search's now
         mine = self.backend.candidates(queries, k, top_m)                        # [Q, top_m] int32
-        if self._estimating and self.backend.estimates(k):
+        estimated = bool(self._estimating and self.backend.estimates(k))
+        if estimated:
             # the shard scanned against an estimate of the whole gallery's admission level and its finish step cuts its list
             # there: that is what exchange 1 would have told it, so the exchange is left out (measured: the fp32 re-score is
             # no dearer without it -- 0.075 against 0.081 ms at 10 000 queries on a 125 k-row shard)
             packed = self.backend.finish(Q, k, None, self.offset)
         else:
             allb = self._gather_buf("bounds", (self.world * Q, top_m), mine.dtype, mine.device)
-            self._all_gather(allb, mine)                                         # exchange 1: admission scores
+            self._all_gather(allb, mine, "bounds")                               # exchange 1: admission scores
             packed = self.backend.finish(Q, k, allb.view(self.world, Q, top_m), self.offset)
         allp = self._gather_buf("packed", (self.world * packed.numel(),), torch.uint8, packed.device)
-        self._all_gather(allp, packed)                                           # exchange 2: packed per-rank top-k
+        self._all_gather(allp, packed, "packed")                                 # exchange 2: packed per-rank top-k
         scores, idx, counts, unc = self.backend.merge(allp, self.world, Q, k, threshold, certify=True)
         host_n, ev = None, None
         if unc[0].is_cuda:
@@ -239,9 +298,12 @@ class ShardedSearch:
             ev = torch.cuda.Event()
             ev.record()
             p = PendingSearch(self, (scores, idx, counts), unc, (host_n, ev), queries, k, threshold, self._gen)
+            p._estimated = estimated
             self._inflight[slot] = p
             return p
-        return PendingSearch(self, (scores, idx, counts), unc, (host_n, ev), queries, k, threshold, self._gen)
+        p = PendingSearch(self, (scores, idx, counts), unc, (host_n, ev), queries, k, threshold, self._gen)
+        p._estimated = estimated
+        return p
 
     def _second_round(self, res, unc, n, k, threshold):
         """The uncertified queries (identical on every rank: same merged data), in one canonical order, exactly on every shard."""
@@ -250,7 +312,7 @@ class ShardedSearch:
         need = unc[2][:n][order].contiguous()
         packed2 = self.backend.exact(qs.contiguous(), need, k, self.offset)
         allp2 = torch.empty((self.world * packed2.numel(),), dtype=torch.uint8, device=packed2.device)
-        self._all_gather(allp2, packed2)                                         # exchange 3 (rare)
+        self._all_gather(allp2, packed2, "packed_second_round")                  # exchange 3 (rare)
         s2, i2, c2 = self.backend.merge(allp2, self.world, n, k, threshold)
         rows = qs.long()
         scores[rows] = s2
@@ -265,6 +327,8 @@ class PendingSearch:
     def __init__(self, owner, res, unc, host, queries, k, threshold, gen):
         self._owner, self._res, self._unc, self._host = owner, res, unc, host
         self._queries, self._k, self._thr, self._gen = queries, k, threshold, gen
+        self._note = True
+        self._estimated = False                     # this search's scans started from the estimated admission level
         self._done = unc is None
 
     def result(self):
@@ -279,13 +343,29 @@ class PendingSearch:
         else:
             n = int(self._unc[0][0])                                             # CPU backends (tests)
         o.last_uncertified = n
-        o._note_second_rounds(n, int(self._queries.shape[0]))
+        if self._note and self._estimated:          # (a limit-50 search's second rounds say nothing about the estimate)
+            o._note_second_rounds(n, int(self._queries.shape[0]))
         if n > 0:
             if o._gen == self._gen:
+                o.second_rounds += 1
                 self._res = o._second_round(self._res, self._unc, n, self._k, self._thr)
             else:
-                # another search has used the shard handle since (its candidates are gone): the whole search again, in step
-                self._res = o.search(self._queries, self._k, self._thr)
+                # Another search has used the shard handle since (its candidates are gone).  Only the n uncertified queries
+                # are searched again -- a search of their own, in step on every rank (the list is the same everywhere),
+                # whose own second round finds its candidates in place.  Exact results do not depend on the batch a query
+                # is searched in, so the patched rows are the rows a second round would have given.  (Searching the whole
+                # batch again, as this did before, also made every search enqueued behind it stale: a cascade.)
+                o.redone_searches += 1
+                scores, idx, counts = self._res
+                rows = torch.sort(self._unc[1][:n])[0].long()
+                sub = o.search_async(self._queries[rows].contiguous(), self._k, self._thr)
+                sub._note = False                       # the rate of uncertified queries is counted once per query
+                s2, i2, c2 = sub.result()
+                scores[rows] = s2
+                idx[rows] = i2
+                counts[rows] = c2
+                o.last_uncertified = n
+                self._res = (scores, idx, counts)
         self._done = True
         if ev is not None:
             slot = self._gen % len(o._inflight)
@@ -304,29 +384,77 @@ class LocalShards:
         self.offsets = [int(o) for o in offsets]
         self.last_uncertified = 0
         self.estimating = bool(estimating)       # the shards scan against the whole gallery's estimated level: no bound exchange
+        self._galleries = None                   # from_galleries: the handles whose total-row setting this object owns
+        self._told = 0
+        self._unc_rate = 0.0
 
     @classmethod
     def from_galleries(cls, galleries):
+        """Shards held as engine.Gallery handles.  While this object lives the handles estimate the whole gallery's
+        admission level (set_total_rows); close() -- or dropping the object -- puts them back to searching on their own."""
+        self = cls([GalleryBackend(g) for g in galleries], [0] * len(galleries), estimating=len(galleries) > 1)
+        self._galleries = list(galleries)
+        self._retell()
+        return self
+
+    def _retell(self):
+        """Offsets and the total follow the shards' current sizes (a shard may have grown since the last search)."""
+        if self._galleries is None:
+            return
         offs, tot = [], 0
-        for g in galleries:
+        for g in self._galleries:
             offs.append(tot)
             tot += len(g)
-        if len(galleries) > 1:
-            for g in galleries:
+        self.offsets = offs
+        if self.estimating and tot != self._told:
+            for g in self._galleries:
                 g.set_total_rows(tot)
-        return cls([GalleryBackend(g) for g in galleries], offs, estimating=len(galleries) > 1)
+            self._told = tot
+
+    def _note_second_rounds(self, n, n_queries):
+        """ShardedSearch._note_second_rounds' rule: above 2 % uncertified queries (running mean) the estimate is off."""
+        if not self.estimating or n_queries <= 0:
+            return
+        self._unc_rate = 0.8 * self._unc_rate + 0.2 * (n / n_queries)
+        if self._unc_rate > 0.02:
+            self.estimating = False
+            for b in self.backends:
+                tell = getattr(b, "set_total_rows", None)
+                if tell is not None:
+                    tell(0)
+            self._told = 0
+
+    def close(self):
+        """Give the handles back: they no longer belong to a sharded gallery."""
+        if self._galleries is not None:
+            for g in self._galleries:
+                try:
+                    g.set_total_rows(0)
+                except Exception:
+                    pass
+            self._galleries, self._told = None, 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def search(self, queries, k, threshold=None):
+        self._retell()
         P, Q = len(self.backends), queries.shape[0]
         ksel = self.backends[0].ksel(k)
         top_m = min(ksel, max(8, -(-min(64, 2 * ksel) // P)))
         allb = torch.stack([b.candidates(queries, k, top_m) for b in self.backends])            # [P, Q, top_m]
-        if self.estimating and self.backends[0].estimates(k):
+        estimated = bool(self.estimating and self.backends[0].estimates(k))
+        if estimated:
             allb = None                                                                          # (see ShardedSearch.search_async)
         allp = torch.cat([b.finish(Q, k, allb, off) for b, off in zip(self.backends, self.offsets)])
         scores, idx, counts, unc = self.backends[0].merge(allp, P, Q, k, threshold, certify=True)
         n = int(unc[0].item())
         self.last_uncertified = n
+        if estimated:
+            self._note_second_rounds(n, Q)
         if n > 0:
             qs, order = torch.sort(unc[1][:n])
             need = unc[2][:n][order].contiguous()

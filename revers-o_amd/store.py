@@ -45,11 +45,26 @@ def _fsync_dir(path):
         os.close(fd)
 
 
+OLD = ".revo-old"          # the set-aside previous database during a swap (a suffix no user database name is likely to end in)
+
+
+def _is_complete(path):
+    man = os.path.join(path, MANIFEST)
+    try:
+        return os.path.isfile(man) and bool(read_manifest(man)[2])
+    except (OSError, ValueError):
+        return False
+
+
 def swap_in(build_path, db_path):
     """Replace the database directory by the finished build without a moment in which neither exists under a name
-    list_databases / load_database look at: old -> <db>.old, build -> <db>, then the old one is removed.  A crash in
-    between leaves <db>.old (complete) and possibly <db>.building (complete): recover() puts things right."""
-    old = db_path + ".old"
+    list_databases / load_database look at: old -> <db>.revo-old, build -> <db>, then the old one is removed.  A crash in
+    between leaves <db>.revo-old (complete) and possibly <db>.building (complete): recover() puts things right.
+    If another process's recover() has already adopted the (complete) build under the database's name -- it can, between
+    this build's last manifest line and this call -- there is nothing left to do."""
+    old = db_path + OLD
+    if not os.path.isdir(build_path) and _is_complete(db_path):
+        return
     if os.path.isdir(old):
         shutil.rmtree(old)
     had = os.path.isdir(db_path)
@@ -66,7 +81,7 @@ def recover(db_path, building_suffix=".building"):
     next to it is put back under its name.  Returns what was adopted, or None."""
     if os.path.isdir(db_path):
         return None
-    for cand, what in ((db_path + building_suffix, "build"), (db_path + ".old", "old")):
+    for cand, what in ((db_path + building_suffix, "build"), (db_path + OLD, "old")):
         man = os.path.join(cand, MANIFEST)
         if os.path.isfile(man):
             try:

@@ -114,7 +114,15 @@ def resolve_config(cfg: PEConfig, sd) -> PEConfig:
     ``visual.transformer.resblocks.{i}.ls_{1,2}.gamma`` -- for every block, or the checkpoint is rejected."""
     have = sorted((int(m.group(1)), int(m.group(2))) for m in map(_LS.match, sd) if m)
     if not have:
-        return replace(cfg, use_ls=False) if cfg.use_ls else cfg
+        if cfg.use_ls:
+            # SURVEY.md 8(a): LayerScale follows the checkpoint -- but a config that declares it and a checkpoint without a
+            # single gain is more likely a truncated or wrong file than a LayerScale-less model: say so, loudly
+            import warnings
+            warnings.warn(f"{cfg.name} declares LayerScale but the checkpoint has no visual.transformer.resblocks.*.ls_*.gamma "
+                          "tensors: running WITHOUT LayerScale (a different model if the checkpoint is truncated or of another variant)",
+                          RuntimeWarning, stacklevel=2)
+            return replace(cfg, use_ls=False)
+        return cfg
     want = [(i, j) for i in range(cfg.layers) for j in (1, 2)]
     if have != want:
         lacking = sorted(set(want) - set(have))
@@ -136,7 +144,9 @@ def check_state_dict(cfg: PEConfig, sd):
     missing = [k for k in exp if k not in sd]
     if missing:
         raise KeyError(f"checkpoint lacks {len(missing)} tensors, e.g. {missing[:3]}")
-    unexpected = [k for k in sd if k not in exp and not _NON_PARAMETER.search(k)]
+    # (only the image tower's namespace is this architecture's to judge: a whole-CLIP state dict also carries `text.*`,
+    #  `logit_scale` ...; VitEngine hands the library the `visual.*` entries only)
+    unexpected = [k for k in sd if k.startswith("visual.") and k not in exp and not _NON_PARAMETER.search(k)]
     if unexpected:
         raise KeyError(f"checkpoint has {len(unexpected)} tensors {cfg.name} does not use, e.g. {sorted(unexpected)[:3]}: "
                        "refusing to ignore them (a tensor the forward skips is a different model)")

@@ -20,7 +20,7 @@ def _run_parent(tmp_path, argv, extra_env=None):
                 with open(os.environ["REC"], "w") as f:
                     json.dump({"cmd": cmd, "env": {k: kw.get("env", {}).get(k) for k in
                                ("HSA_ENABLE_IPC_MODE_LEGACY", "WORLD_SIZE")}, "loaded": mods}, f)
-            def wait(self):
+            def wait(self, timeout=None):
                 return 7
         subprocess.Popen = _P
     """))
@@ -54,3 +54,59 @@ def test_gpus_equals_form_and_launcher_environment(tmp_path):
     rec.unlink()
     p, rec = _run_parent(tmp_path, ["--gpus", "2", "--help"], {"WORLD_SIZE": "2", "RANK": "0"})
     assert not rec.exists() and p.returncode == 0 and "--gpus" in p.stdout
+
+
+def test_parent_guard_ends_hung_ranks_and_exits_nonzero(tmp_path):
+    """A rank that never finishes (a collective that does not complete) must not hang the caller: after REVO_BENCH_WALL_S
+    the parent ends the process group IT started -- a fresh child was started, nothing is re-executed -- and exits 124."""
+    import json
+    import time
+    (tmp_path / "sitecustomize.py").write_text(textwrap.dedent("""
+        import json, os, subprocess, sys
+        _real = subprocess.Popen
+        def _P(cmd, **kw):
+            if "torch.distributed.run" not in cmd:
+                return _real(cmd, **kw)
+            p = _real([sys.executable, "-S", "-c", "import time; time.sleep(600)"], **kw)      # the 'ranks' hang
+            with open(os.environ["REC"], "w") as f:
+                json.dump({"pid": p.pid, "new_session": bool(kw.get("start_new_session"))}, f)
+            return p
+        subprocess.Popen = _P
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PYTHONPATH=str(tmp_path), REC=str(tmp_path / "rec.json"), REVO_BENCH_WALL_S="2")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 124, (p.returncode, p.stderr[-1000:])
+    assert time.time() - t0 < 60 and "did not finish within" in p.stderr
+    rec = json.loads((tmp_path / "rec.json").read_text())
+    assert rec["new_session"]                                       # the children have a process group of their own
+    for _ in range(50):
+        try:
+            os.kill(rec["pid"], 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("the hung child is still alive")
+
+
+def test_rccl_ranks_without_a_device_each_fail_in_one_line(tmp_path):
+    """Under a launcher with the nccl backend and fewer visible devices than ranks (here: none) a rank stops with one
+    readable line before any process group exists -- it does not double ranks up on a device for RCCL to reject."""
+    env = {k: v for k, v in os.environ.items()}
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    last = [ln for ln in p.stderr.strip().splitlines() if ln.strip()][-1]
+    assert "needs one GPU per rank" in last and "--one-gpu --backend gloo" in last, p.stderr[-1500:]
+    assert "Traceback" not in p.stderr
+
+
+def test_process_group_timeout_and_ipc_mode_are_set_on_both_launch_paths():
+    """bench.py sets the dmabuf IPC mode at import (before torch): a torchrun-started rank gets it like a self-launched one;
+    the process group is created with a finite timeout."""
+    src = open(BENCH).read()
+    head = src[: src.index("import torch")]
+    assert 'os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")' in head
+    assert src.count("init_process_group(") == 2 and src.count("timeout=tmo") == 2

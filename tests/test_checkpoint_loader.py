@@ -29,9 +29,16 @@ def test_layerscale_is_detected_from_the_checkpoint():
     weights.check_state_dict(cfg, sd)                                      # and the LS-bearing dict is complete for it
     with pytest.raises(KeyError, match=r"ls_1\.gamma"):                    # against the LS-less table they are unexpected
         weights.check_state_dict(l14, sd)
-    # a config that says LayerScale with a checkpoint that has none: the checkpoint decides
+    # a config that says LayerScale with a checkpoint that has none: the checkpoint decides -- and says so loudly (a
+    # truncated or wrong checkpoint of an LS variant would otherwise run as a different model without a word)
     tiny_ls = reverso_amd.get_config("PE-Tiny-T14-56-LS")
-    assert not weights.resolve_config(tiny_ls, _meta_sd(reverso_amd.get_config("PE-Tiny-T14-56"))).use_ls
+    with pytest.warns(RuntimeWarning, match="declares LayerScale"):
+        assert not weights.resolve_config(tiny_ls, _meta_sd(reverso_amd.get_config("PE-Tiny-T14-56"))).use_ls
+    # tensors outside the image tower (a whole-CLIP state dict) are not this table's business
+    sd2 = _meta_sd(l14)
+    sd2["text.token_embedding.weight"] = torch.empty((8, 8), device="meta")
+    sd2["logit_scale"] = torch.empty((), device="meta")
+    weights.check_state_dict(l14, sd2)
 
 
 def test_partial_layerscale_is_rejected():

@@ -187,12 +187,28 @@ def _shard_worker(rank, world, port, tmp, N, D, Q, k, noise=0.0):
     # pipelined form: the next search is started before the previous one's result is asked for (no host wait between
     # searches).  A pending search whose shard state has been overwritten meanwhile re-does itself in step on every
     # rank if it needs the second round; same answers either way.
+    ss.enable_timing(True)                                       # bench.py's `allgather_ms` / `exchanges_per_search`
+    redone0, second0 = ss.redone_searches, ss.second_rounds
     pend = [ss.search_async(allq, k, thr) for thr in (None, 0.05)]
     for thr, p in zip((None, 0.05), pend):
         s, i, c = p.result()
         assert np.array_equal(i.numpy(), out[str(thr)][1]) and np.array_equal(c.numpy(), out[str(thr)][2])
         assert np.array_equal(s.numpy(), out[str(thr)][0])
         assert p.result()[1] is i                                # a finished search hands back the same tensors
+    rep = ss.timing_report()
+    ss.enable_timing(False)
+    assert ss.timing_report() is None
+    # this backend does not estimate: bounds + packed per search; a stale pending search (noisy scan: both are -- the
+    # second search overwrote the first one's candidates, the first one's repair the second one's) searches only its
+    # uncertified queries again, a small search of its own with ITS second round: never the whole batch, no cascade
+    assert rep["allgather_ms"]["bounds"] > 0 and rep["allgather_ms"]["packed"] > 0
+    if noise > 0:
+        redone = ss.redone_searches - redone0
+        assert redone == 2 and ss.second_rounds - second0 == 2, (ss.redone_searches, ss.second_rounds)
+        assert rep["searches"] == 2 + redone and "packed_second_round" in rep["allgather_ms"]
+        assert 2.0 < rep["exchanges_per_search"] <= 3.0
+    else:
+        assert ss.redone_searches == redone0 and rep["searches"] == 2 and rep["exchanges_per_search"] == 2.0
     np.savez(os.path.join(tmp, f"rank{rank}.npz"), **{f"{t}_{n}": v for t, (a, b, c) in out.items()
                                                         for n, v in (("s", a), ("i", b), ("c", c))})
     dist.barrier()
@@ -246,9 +262,11 @@ def test_local_shards_protocol_on_cpu(noise, shards):
 
 
 def test_swap_in_and_recover_after_a_crash_in_the_final_swap(tmp_path):
-    """The finished build replaces the database by two renames (old -> <db>.old, build -> <db>); whatever a crash between
+    """The finished build replaces the database by two renames (old -> <db>.revo-old, build -> <db>); whatever a crash between
     them leaves behind, recover() -- run by list_databases / load_database -- puts a COMPLETE directory back under the
     database's name, and never adopts an unfinished build."""
+    import shutil
+
     def make(path, complete, tag):
         os.makedirs(path)
         with open(os.path.join(path, st.MANIFEST), "w") as f:
@@ -263,15 +281,22 @@ def test_swap_in_and_recover_after_a_crash_in_the_final_swap(tmp_path):
     make(db + ".building", True, "new2")
     st.swap_in(db + ".building", db)
     assert st.read_manifest(os.path.join(db, st.MANIFEST))[0]["collection"] == "new2"
-    assert not os.path.exists(db + ".old") and not os.path.exists(db + ".building")
-    # crash after "old -> .old", before "build -> db": the complete build is adopted
+    assert not os.path.exists(db + st.OLD) and not os.path.exists(db + ".building")
+    # a build that another process's recover() adopted between the last manifest line and the swap: nothing left to do
+    make(db + ".building", True, "adopted")
+    shutil.rmtree(db)
+    assert st.recover(db) == "build"
+    st.swap_in(db + ".building", db)                              # (used to fail with FileNotFoundError)
+    assert st.read_manifest(os.path.join(db, st.MANIFEST))[0]["collection"] == "adopted"
+    make(db + ".building", True, "new2")
+    st.swap_in(db + ".building", db)
+    # crash after "old -> .revo-old", before "build -> db": the complete build is adopted
     make(db + ".building", True, "new3")
-    os.replace(db, db + ".old")
+    os.replace(db, db + st.OLD)
     assert st.recover(db) == "build"
     assert st.read_manifest(os.path.join(db, st.MANIFEST))[0]["collection"] == "new3"
     assert st.recover(db) is None                                # nothing to do when the database is there
     # the database is gone and only an UNFINISHED build and the set-aside old one exist: the old one comes back
-    import shutil
     shutil.rmtree(db)
     make(db + ".building", False, "half")
     assert st.recover(db) == "old"
