@@ -181,6 +181,20 @@ int32_t revo_op_gemm(int32_t epilogue, const void* a_bf16, int64_t lda, const vo
 int32_t revo_op_gemm_rope(const void* a_bf16, int64_t lda, const void* b_bf16, int64_t ldb, int32_t m, int32_t n, int32_t k,
                           void* c_bf16, int64_t ldc, const float* bias, const float* cos_sin, int32_t seq,
                           int32_t head_dim, int32_t rope_cols, void* stream);
+/* The two halves of a LayerNorm folded into the GEMMs around it (how the forward runs ln_1 / ln_2 of batch-sized calls; the
+ * gain and shift live in the consuming GEMM's weights: W' = bf16(gamma . W), bias' = bias + W beta, csum_j = sum_k W'_jk):
+ *  - revo_op_gemm_resid_ln: the residual GEMM  C f32 [m][n] += gamma * (A . B^T + bias)  which, where its launch form covers all
+ *    rows with the persistent 256 x 256 kernel (then *done = 1; else only C is written and *done = 0), also writes
+ *    xb bf16 [m][ldxb] = bf16(new C) and stats [m][n / 256] pairs of float (mean, sum of squared deviations) of every
+ *    256-column slice of the new row;
+ *  - revo_op_gemm_ln_in: C bf16 = epilogue(rstd * (A . B^T - mean * csum) + bias), epilogue 0 = plain, 1 = exact-erf GELU, the
+ *    row's mean and rstd = 1 / sqrt(var + eps) merged from `parts` slices of `stats` as written above. */
+int32_t revo_op_gemm_resid_ln(const void* a_bf16, int64_t lda, const void* b_bf16, int64_t ldb, int32_t m, int32_t n, int32_t k,
+                              float* c, int64_t ldc, const float* bias, const float* gamma, void* xb_bf16, int64_t ldxb,
+                              void* stats, int32_t* done, void* stream);
+int32_t revo_op_gemm_ln_in(int32_t epilogue, const void* a_bf16, int64_t lda, const void* b_bf16, int64_t ldb, int32_t m, int32_t n,
+                           int32_t k, void* c_bf16, int64_t ldc, const float* bias, const float* csum, const void* stats,
+                           int32_t parts, float eps, void* stream);
 #ifdef REVO_EXPERIMENTS
 /* Kernel-variant selection and timing experiments: compiled only into librevo_exp.so (`make exp`: the same sources
  * with -DREVO_EXPERIMENTS; used by scripts/ and by the forced-tile runs of tests/test_gpu_kernels.py), never into
@@ -200,6 +214,13 @@ int32_t revo_vit_read_tap(revo_vit* vit, int32_t which, int32_t batch, void* dst
  * 1 = every query takes the collecting pass, 2 = every query takes the brute-force pass (1 and 2: parity tests of the
  * fallback against the fast path), 3 = certificate evaluated and counted but no fallback (timing only: NOT exact) */
 int32_t revo_search_set_mode(revo_gallery* g, int32_t mode);
+/* phase groups of the persistent 256 x 256 GEMM (an experiment, measured in round 5 and not adopted): 0 / 1 = off (all
+ * workgroups in step), 2..4 = that many groups, a workgroup of group g doing the first (g + 1) / groups of its first tile at the start and the
+ * rest of that tile last.  Result-preserving (bit-identical). */
+int32_t revo_op_set_phase_groups(int32_t groups);
+/* diagnostic: device array [workgroups][items][4] of uint64 the phased kernel fills with 100 MHz time stamps (main loop
+ * begin, main loop end, epilogue issued) and the piece's rows, for its first `items` pieces per workgroup; NULL = off */
+int32_t revo_debug_gemm_stamps(void* buf, int32_t items);
 /* 0 = size heuristic (default), 128 or 256 = force that GEMM tile */
 int32_t revo_op_set_gemm_tile(int32_t tile);
 /* bits 4-7 = force the XCD arrangement (N-stripes 1, 2, 4 or 8; 0 = heuristic), bits 8-11 = force the attention
@@ -208,6 +229,9 @@ int32_t revo_op_set_gemm_tile(int32_t tile);
  * problems with fewer than 100 of them, bit 19 = the two-buffer 128 x 64 kernel instead of its six-deep-ring form;
  * 0 = normal */
 int32_t revo_op_set_variant(int32_t flags);
+/* 0 = ln_1 / ln_2 as LayerNorm kernels in front of their GEMMs instead of the folded form (A/B timing, parity of one
+ * against the other); 1 = default */
+int32_t revo_op_set_ln_fold(int32_t on);
 /* Timing experiments.  The variant bits above plus: bit 0 = skip the GEMM epilogue stores, bit 1 = skip the GEMM main loop,
  * bit 13 = skip the scan's selection, bit 15 = skip the scan's slow path (all four: WRONG RESULTS),
  * bit 14 = count scan events for revo_debug_scan_stats. */

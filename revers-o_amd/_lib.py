@@ -60,6 +60,8 @@ SIGNATURES = {
     "revo_topk_packed_bytes": (_i64, [_i32, _i32]),
     "revo_topk_merge_packed": (_i32, [_p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p, _p, _p, _p]),
     "revo_op_gemm": (_i32, [_i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p]),
+    "revo_op_gemm_resid_ln": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p, C.POINTER(C.c_int32), _p]),
+    "revo_op_gemm_ln_in": (_i32, [_i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _f32, _p]),
     "revo_op_gemm_rope": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
     "revo_op_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i64, _i32, _p]),
     "revo_op_rope": (_i32, [_p, _i64, _p, _i32, _i32, _i32, _i32, _p]),
@@ -78,7 +80,10 @@ EXPERIMENT_SIGNATURES = {
     "revo_vit_read_tap": (_i32, [_p, _i32, _i32, _p, _p]),
     "revo_search_set_mode": (_i32, [_p, _i32]),
     "revo_op_set_gemm_tile": (_i32, [_i32]),
+    "revo_op_set_phase_groups": (_i32, [_i32]),
+    "revo_debug_gemm_stamps": (_i32, [_p, _i32]),
     "revo_op_set_variant": (_i32, [_i32]),
+    "revo_op_set_ln_fold": (_i32, [_i32]),
     "revo_op_set_gemm_debug": (_i32, [_i32]),
     "revo_debug_scan_stats": (_i32, [C.POINTER(C.c_int64)]),
     "revo_debug_seed_bounds": (_i32, [_p, _p]),
@@ -136,7 +141,12 @@ def load():
             "(or `make -C revers-o_amd/csrc`).  There is no CPU fallback for the hot path.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        try:
+            fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        except AttributeError:
+            if os.environ.get("REVO_LIBRARY_PATH"):     # an older build in an A/B run (scripts/step_regression_ab.sh): it simply lacks the newer entry points
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     _lib = lib

@@ -163,9 +163,12 @@ struct DevBuf {
     void release() { if (p) { (void)hipFree(p); p = nullptr; } }
 };
 
+// ln_1 / ln_2 are folded into the weights of the GEMM that follows them: w_qkv = bf16(ln_1.weight . W),
+// b_qkv = b + W ln_1.bias, c_qkv[j] = sum_k w_qkv[j][k]; the same for fc1 with ln_2.  The forward feeds those GEMMs either
+// bf16(x) with the row statistics (folded form) or the normalised row without gain and shift (LayerNorm kernel).
 struct LayerW {
     bf16_t *w_qkv, *w_o, *w_fc1, *w_fc2;
-    float *b_qkv, *b_o, *b_fc1, *b_fc2, *ln1w, *ln1b, *ln2w, *ln2b, *ls1, *ls2;
+    float *b_qkv, *b_o, *b_fc1, *b_fc2, *c_qkv, *c_fc1, *ls1, *ls2;
 };
 
 constexpr size_t SPLITK_WS_ELEMS = 16u << 20;     // 64 MiB of fp32
@@ -188,6 +191,8 @@ struct revo_vit {
     float *x = nullptr, *pool_logits = nullptr, *pool_u = nullptr, *pool_att = nullptr, *pool_o = nullptr, *pool_h = nullptr,
           *pool_m = nullptr, *feat = nullptr;
     float* splitk_ws = nullptr;        // fp32 partial planes of the split-K residual GEMMs
+    float2* ln_stats = nullptr;        // [rows][width / 256] (mean, M2) per 256-column slice: the folded LayerNorm's row statistics
+    int ln_parts = 0;                  // width / 256 when the fold applies (width % 256 == 0, <= 6 slices), else 0
 
     template <class T> int dalloc(T** out, size_t count) {
         void* p = nullptr;
@@ -224,6 +229,24 @@ int up_f32(revo_vit* v, WeightMap& wm, const std::string& name, int64_t numel, f
     REVO_HIP_CHECK(hipMemcpy(*out, t->data, (size_t)numel * 4, hipMemcpyDefault));
     return 0;
 }
+// linear layer behind a LayerNorm: fp32 [rows][cols] weights, [cols] gain / shift, [rows] bias (host or device) ->
+// bf16(gamma . W), column sums of the rounded weights, bias + W beta
+int up_folded(revo_vit* v, WeightMap& wm, float* stage, float* gb, const std::string& wname, const std::string& bname,
+              const std::string& ln, int64_t rows, int64_t cols, bf16_t** w_out, float** c_out, float** b_out) {
+    const revo_tensor *tw = wm.get(wname, rows * cols), *tb = wm.get(bname, rows), *tg = wm.get(ln + ".weight", cols),
+                      *te = wm.get(ln + ".bias", cols);
+    if (!tw || !tb || !tg || !te) return -2;
+    CHECK_RC(v->dalloc(w_out, (size_t)(rows * cols)));
+    CHECK_RC(v->dalloc(c_out, (size_t)rows));
+    CHECK_RC(v->dalloc(b_out, (size_t)rows));
+    REVO_HIP_CHECK(hipMemcpy(stage, tw->data, (size_t)(rows * cols) * 4, hipMemcpyDefault));
+    REVO_HIP_CHECK(hipMemcpy(gb, tg->data, (size_t)cols * 4, hipMemcpyDefault));
+    REVO_HIP_CHECK(hipMemcpy(gb + cols, te->data, (size_t)cols * 4, hipMemcpyDefault));
+    REVO_HIP_CHECK(hipMemcpy(gb + 2 * cols, tb->data, (size_t)rows * 4, hipMemcpyDefault));
+    CHECK_RC(revo::launch_fold_ln_linear(stage, gb, gb + cols, gb + 2 * cols, (int)rows, (int)cols, *w_out, cols, *c_out, *b_out, 0));
+    REVO_HIP_CHECK(hipStreamSynchronize(0));
+    return 0;
+}
 // fp32 [rows][cols] (host or device) -> device bf16 [rows][ld] zero padded
 int up_bf16(revo_vit* v, float* stage, const float* src, int64_t rows, int64_t cols, int64_t ld, bf16_t** out) {
     CHECK_RC(v->dalloc(out, (size_t)(rows * ld)));
@@ -250,6 +273,9 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
                  "vit_create: sizes must be positive");
     std::unique_ptr<revo_vit> v(new revo_vit());
     v->cfg = c; v->device = device; v->max_batch = max_batch;
+#ifdef REVO_EXPERIMENTS
+    if (const char* e = getenv("REVO_LN_FOLD")) revo::gemm_set_ln_fold(atoi(e) ? 1 : 0);     // A/B runs of bench.py (scripts/)
+#endif
     const int W = c.width, M = c.mlp_dim, D = c.out_dim, P = c.patch_size, G = c.image_size / P;
     v->G2 = G * G; v->S = v->G2 + (c.use_cls ? 1 : 0);
     v->hd = W / c.heads; v->phd = W / c.pool_heads;
@@ -313,6 +339,9 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
     float* stage = nullptr;
     REVO_HIP_CHECK(hipMalloc((void**)&stage, stage_elems * 4));
     struct StageGuard { float* p; ~StageGuard() { (void)hipFree(p); } } sg{stage};
+    float* gb = nullptr;               // gain | shift | bias of the layer being folded
+    REVO_HIP_CHECK(hipMalloc((void**)&gb, (size_t)(2 * W + std::max(3 * W, M)) * 4));
+    StageGuard sg2{gb};
 
     const revo_tensor* t;
     if (!(t = wm.get("visual.conv1.weight", (int64_t)W * Kreal))) return -2;
@@ -332,19 +361,13 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
         const std::string p = "visual.transformer.resblocks." + std::to_string(i) + ".";
         LayerW& L = v->layers[i];
         memset(&L, 0, sizeof(L));
-        CHECK_RC(up_f32(v.get(), wm, p + "ln_1.weight", W, &L.ln1w));
-        CHECK_RC(up_f32(v.get(), wm, p + "ln_1.bias", W, &L.ln1b));
-        CHECK_RC(up_f32(v.get(), wm, p + "ln_2.weight", W, &L.ln2w));
-        CHECK_RC(up_f32(v.get(), wm, p + "ln_2.bias", W, &L.ln2b));
-        if (!(t = wm.get(p + "attn.in_proj_weight", (int64_t)3 * W * W))) return -2;
-        CHECK_RC(up_bf16(v.get(), stage, t->data, 3 * W, W, W, &L.w_qkv));
-        CHECK_RC(up_f32(v.get(), wm, p + "attn.in_proj_bias", 3 * W, &L.b_qkv));
+        CHECK_RC(up_folded(v.get(), wm, stage, gb, p + "attn.in_proj_weight", p + "attn.in_proj_bias", p + "ln_1", 3 * W, W,
+                           &L.w_qkv, &L.c_qkv, &L.b_qkv));
         if (!(t = wm.get(p + "attn.out_proj.weight", (int64_t)W * W))) return -2;
         CHECK_RC(up_bf16(v.get(), stage, t->data, W, W, W, &L.w_o));
         CHECK_RC(up_f32(v.get(), wm, p + "attn.out_proj.bias", W, &L.b_o));
-        if (!(t = wm.get(p + "mlp.c_fc.weight", (int64_t)M * W))) return -2;
-        CHECK_RC(up_bf16(v.get(), stage, t->data, M, W, W, &L.w_fc1));
-        CHECK_RC(up_f32(v.get(), wm, p + "mlp.c_fc.bias", M, &L.b_fc1));
+        CHECK_RC(up_folded(v.get(), wm, stage, gb, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", p + "ln_2", M, W,
+                           &L.w_fc1, &L.c_fc1, &L.b_fc1));
         if (!(t = wm.get(p + "mlp.c_proj.weight", (int64_t)W * M))) return -2;
         CHECK_RC(up_bf16(v.get(), stage, t->data, W, M, M, &L.w_fc2));
         CHECK_RC(up_f32(v.get(), wm, p + "mlp.c_proj.bias", W, &L.b_fc2));
@@ -424,6 +447,8 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
     CHECK_RC(v->dalloc(&v->pool_m, B * PM));
     CHECK_RC(v->dalloc(&v->feat, B * D));
     CHECK_RC(v->dalloc(&v->splitk_ws, SPLITK_WS_ELEMS));
+    v->ln_parts = (W % 256 == 0 && W / 256 <= 6) ? W / 256 : 0;
+    if (v->ln_parts) CHECK_RC(v->dalloc(&v->ln_stats, rows * (size_t)v->ln_parts));
     REVO_HIP_CHECK(hipDeviceSynchronize());
     *out = v.release();
     return 0;
@@ -470,14 +495,23 @@ extern "C" int32_t revo_vit_read_tap(revo_vit* vit, int32_t which, int32_t batch
 
 namespace {
 // ln (optional, residual epilogue): the LayerNorm that follows; *ln_fused = 1 if the GEMM's launch form did it (kernels.h)
-struct LnAfter { const float* w; const float* b; float eps; bf16_t* out; long ldo; int* fused; };
+// The LayerNorm behind a residual GEMM, without gain and shift (those live in the next GEMM's weights).  Whichever the
+// launch form can do: *fused = 1: `out` holds the normalised rows (one-image forms: the split-K reduce does it);
+// *folded = 1: `out` holds bf16(x) and `stats` the rows' partial statistics (folded form, kernels.h GemmArgs::lnf_*);
+// neither: the caller runs the LayerNorm kernel.
+struct LnAfter { float eps; bf16_t* out; long ldo; int* fused; float2* stats; int* folded; };
+// consumer side of the folded form: A = bf16(x), the epilogue applies rstd (acc - mean c) + bias
+struct LnBefore { const float2* stats; int parts; const float* c; float eps; };
 int gemm(const char* cls, int epi, const bf16_t* A, long lda, const bf16_t* B, long ldb, int M, int N, int K, void* C,
          long ldc, const float* bias, const float* gamma, hipStream_t st, float* ws = nullptr, long ws_elems = 0,
          const LnAfter* ln = nullptr) {
     revo::GemmArgs a{};
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
     a.bias = bias; a.gamma = gamma; a.ws = ws; a.ws_elems = ws_elems;
-    if (ln) { a.ln_w = ln->w; a.ln_b = ln->b; a.ln_eps = ln->eps; a.ln_out = ln->out; a.ln_ldo = ln->ldo; a.ln_fused = ln->fused; }
+    if (ln) {
+        a.ln_eps = ln->eps; a.ln_out = ln->out; a.ln_ldo = ln->ldo; a.ln_fused = ln->fused;
+        if (ln->stats) { a.lnf_xb = ln->out; a.lnf_ldxb = ln->ldo; a.lnf_stats = ln->stats; a.lnf_done = ln->folded; }
+    }
     ProfScope ps(cls, st);
     return revo::launch_gemm(epi, a, st);
 }
@@ -540,41 +574,73 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
       CHECK_RC(launch_layernorm(v->x, W, v->lnpre_w, v->lnpre_b, c.ln_eps, rows, W, v->x, W, 0, st)); }
 
     const int nl = v->debug_layers < 0 ? c.layers : std::min(v->debug_layers, c.layers);
-    // One-image forwards: the residual GEMMs run as K parts + one reduce, and that reduce also does the LayerNorm that
-    // follows (ln_2 after out-proj, the next block's ln_1 after fc2): h_ready says the rows in h are already normalised.
-    int h_ready = 0;
+    // ln_1 / ln_2 live in the weights of qkv / fc1 (LayerW): what those GEMMs read from `h` is, depending on what the
+    // residual GEMM in front of them could do,
+    //   H_XB    bf16(x) + the rows' partial statistics in ln_stats: the folded form (batch-sized forwards: the residual
+    //           epilogue that holds the new row writes both; the consuming epilogue applies rstd (acc - mean c) + b'),
+    //   H_NORM  the normalised rows (one-image forwards: the split-K reduce of the residual GEMM normalises its rows;
+    //           otherwise the LayerNorm kernel, which is also what block 0's ln_1 takes behind ln_pre).
+    enum { H_NONE = 0, H_NORM = 1, H_XB = 2 };
+    int h_state = H_NONE;
+    float2* stats = vv->ln_parts ? vv->ln_stats + r0 * vv->ln_parts : nullptr;
+    auto ln_before = [&](const float* csum, GemmArgs& a) {
+        if (h_state == H_XB) { a.lnc_stats = stats; a.lnc_parts = vv->ln_parts; a.lnc_c = csum; a.lnc_eps = c.ln_eps; }
+    };
+    auto normalise_if_needed = [&]() -> int {
+        if (h_state != H_NONE) return 0;
+        ProfScope ps("layernorm", st);
+        CHECK_RC(launch_layernorm(v->x, W, nullptr, nullptr, c.ln_eps, rows, W, v->h, W, 1, st));
+        h_state = H_NORM;
+        return 0;
+    };
     for (int i = 0; i < nl; ++i) {
         const LayerW& L = v->layers[i];
-        if (!h_ready) {
-            ProfScope ps("layernorm", st);
-            CHECK_RC(launch_layernorm(v->x, W, L.ln1w, L.ln1b, c.ln_eps, rows, W, v->h, W, 1, st));
-        }
+        CHECK_RC(normalise_if_needed());
         {
             // K4 + K5: bias and the 2-D rotary embedding of q and k in the GEMM epilogue (every tile shape)
             GemmArgs a{};
             a.A = v->h; a.lda = W; a.B = L.w_qkv; a.ldb = W; a.M = rows; a.N = 3 * W; a.K = W; a.C = v->qkv;
             a.ldc = 3 * W; a.bias = L.b_qkv; a.rope_cs = v->rope_cs; a.rope_S = S; a.rope_hd = v->hd;
             a.rope_cols = 2 * W;
+            ln_before(L.c_qkv, a);
             ProfScope ps("gemm_qkv", st);
             CHECK_RC(launch_gemm(EPI_BF16_ROPE, a, st));
         }
         { ProfScope ps("attention", st);
           CHECK_RC(launch_attention_ex(v->qkv, 3 * W, v->att, W, B, S, c.heads, v->hd, c.use_cls, st)); }
-        int fused = 0;
-        const LnAfter ln2{L.ln2w, L.ln2b, c.ln_eps, v->h, W, &fused};
+        int fused = 0, folded = 0;
+        const LnAfter ln2{c.ln_eps, v->h, W, &fused, stats, &folded};
         CHECK_RC(gemm("gemm_out", EPI_RESID_F32, v->att, W, L.w_o, W, rows, W, W, v->x, W, L.b_o, L.ls1, st, vv->splitk_ws,
                       (long)SPLITK_WS_ELEMS, &ln2));
-        if (!fused) {
-            ProfScope ps("layernorm", st);
-            CHECK_RC(launch_layernorm(v->x, W, L.ln2w, L.ln2b, c.ln_eps, rows, W, v->h, W, 1, st));
+        h_state = folded ? H_XB : (fused ? H_NORM : H_NONE);
+#ifdef REVO_EXPERIMENTS
+        // cache-state experiment: re-touch bf16(x) (a device copy into the dead qkv buffer) before the GEMM that streams it
+        if (folded && getenv("REVO_LNFOLD_TOUCH")) {
+            ProfScope ps("touch", st);
+            REVO_HIP_CHECK(hipMemcpyAsync(v->qkv, v->h, (size_t)rows * W * 2, hipMemcpyDeviceToDevice, st));
         }
-        CHECK_RC(gemm("gemm_fc1", EPI_BF16_GELU, v->h, W, L.w_fc1, W, rows, Md, W, v->mlp, Md, L.b_fc1, nullptr, st));
-        // scratch for the split-K forms of fc2 (leftover rows at large batch, the whole GEMM at small batch)
-        h_ready = 0;
-        LnAfter ln1n{nullptr, nullptr, c.ln_eps, v->h, W, &h_ready};
-        if (i + 1 < nl) { ln1n.w = v->layers[i + 1].ln1w; ln1n.b = v->layers[i + 1].ln1b; }
+#endif
+        CHECK_RC(normalise_if_needed());
+        {
+            GemmArgs a{};
+            a.A = v->h; a.lda = W; a.B = L.w_fc1; a.ldb = W; a.M = rows; a.N = Md; a.K = W; a.C = v->mlp; a.ldc = Md;
+            a.bias = L.b_fc1;
+            ln_before(L.c_fc1, a);
+            ProfScope ps("gemm_fc1", st);
+            CHECK_RC(launch_gemm(EPI_BF16_GELU, a, st));
+        }
+        // (splitk_ws: scratch for the split-K forms of fc2 -- leftover rows at large batch, the whole GEMM at small batch)
+        fused = 0; folded = 0;
+        const LnAfter ln1n{c.ln_eps, v->h, W, &fused, stats, &folded};
         CHECK_RC(gemm("gemm_fc2", EPI_RESID_F32, v->mlp, Md, L.w_fc2, Md, rows, W, Md, v->x, W, L.b_fc2, L.ls2, st,
                       vv->splitk_ws, (long)SPLITK_WS_ELEMS, i + 1 < nl ? &ln1n : nullptr));
+        h_state = (i + 1 < nl) ? (folded ? H_XB : (fused ? H_NORM : H_NONE)) : H_NONE;
+#ifdef REVO_EXPERIMENTS
+        if (folded && i + 1 < nl && getenv("REVO_LNFOLD_TOUCH")) {
+            ProfScope ps("touch", st);
+            REVO_HIP_CHECK(hipMemcpyAsync(v->qkv, v->h, (size_t)rows * W * 2, hipMemcpyDeviceToDevice, st));
+        }
+#endif
     }
     if (v->debug_layers >= 0) return 0;   // parity hook: residual stream only
 
@@ -1157,6 +1223,39 @@ extern "C" int32_t revo_op_gemm(int32_t epi, const void* a, int64_t lda, const v
     return rc;
     API_END
 }
+// The two halves of a LayerNorm folded into the GEMMs around it (kernels.h GemmArgs::lnf_* / lnc_*), one kernel each
+extern "C" int32_t revo_op_gemm_resid_ln(const void* a, int64_t lda, const void* b, int64_t ldb, int32_t m, int32_t n, int32_t k,
+                                         float* c, int64_t ldc, const float* bias, const float* gamma, void* xb, int64_t ldxb,
+                                         void* stats, int32_t* done, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(a && b && c && xb && stats && done, "op_gemm_resid_ln: null argument");
+    constexpr long OP_WS_ELEMS = 16l << 20;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = nullptr;
+    REVO_HIP_CHECK(hipMallocAsync((void**)&ws, OP_WS_ELEMS * 4, st));
+    revo::GemmArgs g{};
+    g.A = (const bf16_t*)a; g.lda = lda; g.B = (const bf16_t*)b; g.ldb = ldb; g.M = m; g.N = n; g.K = k; g.C = c; g.ldc = ldc;
+    g.bias = bias; g.gamma = gamma; g.ws = ws; g.ws_elems = OP_WS_ELEMS;
+    int flag = 0;
+    g.lnf_xb = (bf16_t*)xb; g.lnf_ldxb = ldxb; g.lnf_stats = (float2*)stats; g.lnf_done = &flag;
+    const int rc = revo::launch_gemm(revo::EPI_RESID_F32, g, st);
+    REVO_HIP_CHECK(hipFreeAsync(ws, st));
+    *done = flag;
+    return rc;
+    API_END
+}
+extern "C" int32_t revo_op_gemm_ln_in(int32_t epi, const void* a, int64_t lda, const void* b, int64_t ldb, int32_t m, int32_t n,
+                                      int32_t k, void* c, int64_t ldc, const float* bias, const float* csum, const void* stats,
+                                      int32_t parts, float eps, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(epi == revo::EPI_BF16 || epi == revo::EPI_BF16_GELU, "op_gemm_ln_in: epilogue must be 0 (bf16) or 1 (bf16 + GELU)");
+    REVO_REQUIRE(a && b && c && csum && stats, "op_gemm_ln_in: null argument");
+    revo::GemmArgs g{};
+    g.A = (const bf16_t*)a; g.lda = lda; g.B = (const bf16_t*)b; g.ldb = ldb; g.M = m; g.N = n; g.K = k; g.C = c; g.ldc = ldc;
+    g.bias = bias; g.lnc_stats = (const float2*)stats; g.lnc_parts = parts; g.lnc_c = csum; g.lnc_eps = eps;
+    return revo::launch_gemm(epi, g, (hipStream_t)stream);
+    API_END
+}
 extern "C" int32_t revo_op_gemm_rope(const void* a, int64_t lda, const void* b, int64_t ldb, int32_t m, int32_t n,
                                      int32_t k, void* c, int64_t ldc, const float* bias, const float* cos_sin,
                                      int32_t seq, int32_t head_dim, int32_t rope_cols, void* stream) {
@@ -1178,6 +1277,23 @@ extern "C" int32_t revo_op_set_variant(int32_t flags) {
     revo::gemm_set_min_tiles256(((flags >> 18) & 1) ? 0 : 100);
     revo::gemm_set_ring(((flags >> 19) & 1) ? 0 : 1, 0);
     revo::gemm_set_rows192(((flags >> 3) & 1) ? 0 : 1);
+    return 0;
+}
+// 0: every ln_1 / ln_2 runs as its own LayerNorm kernel (A/B timing and parity of the folded form against it); 1: default
+extern "C" int32_t revo_op_set_ln_fold(int32_t on) {
+    revo::gemm_set_ln_fold(on ? 1 : 0);
+    return 0;
+}
+// phase groups of the persistent 256 x 256 GEMM (gemm.hip gemm256pp_kernel): 0 = the launcher's choice, 1 = off, 2..4 forced
+extern "C" int32_t revo_op_set_phase_groups(int32_t groups) {
+    REVO_REQUIRE(groups >= 0 && groups <= 4, "set_phase_groups: 0 (heuristic), 1 (off) or 2..4");
+    revo::gemm_set_phase_groups(groups);
+    return 0;
+}
+// diagnostic: buf = device array [workgroups][items][4] of u64 (100 MHz stamps: main loop begin, main loop end, epilogue
+// issued, rows of the piece) that the phased persistent kernel fills for its first `items` pieces; NULL = off
+extern "C" int32_t revo_debug_gemm_stamps(void* buf, int32_t items) {
+    revo::gemm_set_stamps((unsigned long long*)buf, buf ? items : 0);
     return 0;
 }
 extern "C" int32_t revo_op_set_gemm_tile(int32_t tile) {

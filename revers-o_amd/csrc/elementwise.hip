@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            const f32x4 g = *(const f32x4*)(w + c * 4);
-            const f32x4 be = *(const f32x4*)(b + c * 4);
+            const f32x4 g = w ? *(const f32x4*)(w + c * 4) : (f32x4){1.f, 1.f, 1.f, 1.f};          // (null: no affine)
+            const f32x4 be = b ? *(const f32x4*)(b + c * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 y;
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = fmaf((v[i][j] - mean) * rstd, g[j], be[j]);
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256) void layernorm8_kernel(const float* __restrict
             float y[8];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const f32x4 gm = *(const f32x4*)(w + g * 8 + h * 4);
-                const f32x4 be = *(const f32x4*)(b + g * 8 + h * 4);
+                const f32x4 gm = w ? *(const f32x4*)(w + g * 8 + h * 4) : (f32x4){1.f, 1.f, 1.f, 1.f};    // (null: no affine)
+                const f32x4 be = b ? *(const f32x4*)(b + g * 8 + h * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[h * 4 + j] = fmaf((v[i][h][j] - mean) * rstd, gm[j], be[j]);
             }
@@ -187,6 +187,39 @@ int launch_layernorm(const float* x, long ldx, const float* w, const float* b, f
     else if (chunks <= 6) { LN_LAUNCH(6) }
     else { LN_LAUNCH(8) }
 #undef LN_LAUNCH
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------- LayerNorm folded into a linear ----
+// y = LayerNorm(x; gamma, beta) . W^T + b  ==  ((x - mean) rstd) . (gamma . W)^T + (b + W beta).  One wave per output row j:
+//   out[j][k] = bf16(gamma[k] W[j][k]),   csum[j] = sum_k float(out[j][k])  (the ROUNDED weights: what the MFMA multiplies;
+//   the GEMM epilogue subtracts mean * csum[j]),   bias_out[j] = bias[j] + sum_k beta[k] W[j][k].   Sums in fp64.
+__global__ __launch_bounds__(256) void fold_ln_linear_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ bias,
+                                                             int rows, int cols, bf16_t* __restrict__ out, long ld,
+                                                             float* __restrict__ csum, float* __restrict__ bias_out) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= rows) return;
+    double cs = 0.0, bs = 0.0;
+    for (int k = lane; k < cols; k += 64) {
+        const float wv = w[(long)j * cols + k];
+        const bf16_t r = f32_to_bf16(wv * gamma[k]);
+        out[(long)j * ld + k] = r;
+        cs += (double)bf16_to_f32(r);
+        bs += (double)beta[k] * (double)wv;
+    }
+    for (int k = cols + lane; k < ld; k += 64) out[(long)j * ld + k] = 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cs += __shfl_xor(cs, o, 64); bs += __shfl_xor(bs, o, 64); }
+    if (lane == 0) { csum[j] = (float)cs; bias_out[j] = (float)((double)bias[j] + bs); }
+}
+int launch_fold_ln_linear(const float* w, const float* gamma, const float* beta, const float* bias, int rows, int cols,
+                          bf16_t* out, long ld, float* csum, float* bias_out, hipStream_t st) {
+    REVO_REQUIRE(rows > 0 && cols > 0 && ld >= cols, "fold_ln_linear: bad sizes");
+    hipLaunchKernelGGL(fold_ln_linear_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, w, gamma, beta, bias, rows, cols, out, ld,
+                       csum, bias_out);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -3,6 +3,7 @@
 // the fp32 residual stream, patch-embed position add).  K2/K4/K7/K8/K10 of
 // SURVEY.md §2b; replaces the F.linear / conv2d calls the upstream PE module
 // dispatches from encode_image (reference call site core_system.py:442).
+#include <type_traits>
 #include "gemm_core.h"
 #include "gemm256_core.h"
 #include "kernels.h"
@@ -35,15 +36,92 @@ __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
     const f32x2 lo = gelu_erf2((f32x2){v[0], v[1]}), hi = gelu_erf2((f32x2){v[2], v[3]});
     return (f32x4){lo.x, lo.y, hi.x, hi.y};
 }
+// The same function on four f32x4 at once, written stage by stage over the eight register pairs: one element's GELU is a
+// chain of ~15 DEPENDENT packed operations (hipcc 7.2 puts an s_nop between each two of them), and fed one f32x4 after
+// the other the epilogue of fc1 is bound by that chain's latency, not by the VALU's rate -- 6.75 us per 256 x 256 tile
+// of which 5 are this function (profiles/r05_gemm_phase_groups.json).  Eight independent chains side by side fill each
+// other's gaps.  Per element the operations and their order are gelu_erf2's: same bits.
+#ifndef REVO_LNC_ABLATE       // timing-only ablations of the folded consumer (var build): 1 no merge, 2 no epilogue math, 4 no statistics DMA
+#define REVO_LNC_ABLATE 0
+#endif
+#ifndef REVO_GELU_WIDTH
+#define REVO_GELU_WIDTH 2
+#endif
+template <int NV>
+__device__ __forceinline__ void gelu_erf4xn(f32x4 (&v)[NV]) {
+    constexpr int NP = 2 * NV;
+    f32x2 x[NP], ax[NP], z[NP], q[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        x[i] = (f32x2){v[i >> 1][(i & 1) * 2], v[i >> 1][(i & 1) * 2 + 1]};
+        ax[i] = (f32x2){__builtin_fabsf(x[i].x), __builtin_fabsf(x[i].y)};
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) z[i] = ax[i] * 0.70710678118654752f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = z[i] * 0.0000430638f + 0.0002765672f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = q[i] * z[i] + 0.0001520143f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = q[i] * z[i] + 0.0092705272f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = q[i] * z[i] + 0.0422820123f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = q[i] * z[i] + 0.0705230784f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = q[i] * z[i] + 1.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) q[i] = q[i] * q[i];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = (f32x2){__builtin_amdgcn_rcpf(q[i].x), __builtin_amdgcn_rcpf(q[i].y)};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = 1.0f - q[i];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) x[i] = x[i] + ax[i] * q[i];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) x[i] = x[i] * 0.5f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = (f32x4){x[2 * i].x, x[2 * i].y, x[2 * i + 1].x, x[2 * i + 1].y};
+}
+
+// ---- LayerNorm folded into the GEMMs around it (kernels.h GemmArgs::lnf_* / lnc_*) ----------
+// sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15): quad butterflies, then the two mirrors; every lane gets a sum
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+    return v;
+}
+// P partial (mean, M2) pairs of equal-sized column slices of one row, in slot order -> (rstd, -mean * rstd).  One fixed
+// order of operations wherever a row's statistics are merged (every consumer form gives a row the same bits).
+constexpr int LNF_SLICE = 256;      // columns per partial = one column tile of the 256 x 256 kernel
+// (`part` is read twice -- LDS or L1-resident global memory -- rather than copied: a run-time-indexed local array would live in scratch)
+__device__ __forceinline__ void lnf_merge(const float2* part, int P, float eps, float& rstd, float& mr) {
+    float sm = 0.f, sq = 0.f;
+    for (int i = 0; i < P; ++i) { const float2 t = part[i]; sm += t.x; sq += t.y; }
+    const float mean = sm / (float)P;
+    float dd = 0.f;
+    for (int i = 0; i < P; ++i) { const float d = part[i].x - mean; dd = fmaf(d, d, dd); }
+    const float var = fmaf((float)LNF_SLICE, dd, sq) / (float)(LNF_SLICE * P);
+    rstd = rsqrtf(var + eps);
+    mr = -mean * rstd;
+}
 
 template <int EPI, int MF, int NF>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int m_base, int n_base, int lane,
                                               f32x4 (&acc)[MF][NF]) {
     const int lr = lane & 15, lq = lane >> 4;
+    const bool lnc = (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE) && p.lnc_stats != nullptr;
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
         const int row = m_base + m * 16 + lr;
         if (row >= p.M) continue;
+        float ln_rstd = 1.f, ln_mr = 0.f;
+        if (lnc)        // the row's statistics straight from global memory (the small-tile kernels: a few leftover rows)
+            lnf_merge(p.lnc_stats + (long)row * p.lnc_parts, p.lnc_parts, p.lnc_eps, ln_rstd, ln_mr);
         long orow = row;
         int prow = 0;
         if (EPI == EPI_PATCH) {
@@ -56,6 +134,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int m_base, int
             const int col = n_base + n * 16 + lq * 4;
             if (col >= p.N) continue;
             f32x4 v = acc[m][n];
+            if (lnc) {
+                const f32x4 c = *(const f32x4*)(p.lnc_c + col);
+                const f32x4 b = p.bias ? *(const f32x4*)(p.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                v = v * ln_rstd + (c * ln_mr + b);          // rstd (acc - mean c) + b', the 256 x 256 epilogue's operation order
+            } else
             if (p.bias) {
                 const f32x4 b = *(const f32x4*)(p.bias + col);
                 v += b;
@@ -114,21 +197,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int m_base, int
 // stored).  With the loads inside per-lane branches the waitcnt pass lost track of which load a register came from
 // and put s_waitcnt vmcnt(0) in front of every one of the 16 store steps of the second half of a tile -- each of
 // them then waited for the previous step's store to be acknowledged by L2.
+// nt: non-temporal (the folded-LayerNorm form: nothing reads the fp32 rows before the next residual GEMM, a whole GEMM
+// later -- the bf16 copy written beside them is what the next kernel streams, and should be what stays in the caches)
 template <int QT>
-__device__ __forceinline__ void gemm256_load_resid(const GemmArgs& p, int m_base, int n_base, int lane, f32x4 (&res)[8]) {
+__device__ __forceinline__ void gemm256_load_resid(const GemmArgs& p, int m_base, int n_base, int lane, f32x4 (&res)[8],
+                                                   bool nt = false) {
     int gcol = n_base + (lane & 15) * 4;
     gcol = gcol < p.N ? gcol : p.N - 4;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         int grow = m_base + QT * 32 + it * 4 + (lane >> 4);
         grow = grow < p.M ? grow : p.M - 1;
-        res[it] = *(const f32x4*)((const float*)p.C + (long)grow * p.ldc + gcol);
+        const f32x4* src = (const f32x4*)((const float*)p.C + (long)grow * p.ldc + gcol);
+        res[it] = nt ? __builtin_nontemporal_load(src) : *src;
     }
 }
+// lnst (EPI_RESID_F32, optional; LDS): the LayerNorm that follows is folded into the GEMMs around it -- every new row
+// segment is also stored as bf16 (the next GEMM's A operand) and its (mean, M2) over this wave's 64 columns goes to
+// lnst[row in the wave's 128 rows * 4] (the workgroup merges the four waves' slices behind its next barrier).
 template <int EPI, int QT>
 __device__ __forceinline__ void gemm256_epilogue_f32_quarter(const GemmArgs& p, char* slab, int m_base, int n_base,
                                                              int lane, f32x4 (&acc)[8][4], const f32x4 (&bias4)[4],
-                                                             const f32x4 (&gamma4)[4], const f32x4 (&res)[8]) {
+                                                             const f32x4 (&gamma4)[4], const f32x4 (&res)[8],
+                                                             float2* lnst = nullptr) {
     constexpr int RS = 272;   // 64 fp32 + 16 bytes of padding per slab row
     asm volatile("" : "+v"(lane) :: "memory");   // keep this quarter's address arithmetic inside it
     const int lr = lane & 15, lq = lane >> 4;
@@ -141,17 +232,34 @@ __device__ __forceinline__ void gemm256_epilogue_f32_quarter(const GemmArgs& p, 
             *(f32x4*)(slab + (m * 16 + lr) * RS + (n * 16 + lq * 4) * 4) = v;
         }
     const int gcol = n_base + (lane & 15) * 4;
+    float keep_m = 0.f, keep_q = 0.f;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int rl = it * 4 + (lane >> 4);
         f32x4 v = *(const f32x4*)(slab + rl * RS + (lane & 15) * 16);
         const int grow = m_base + QT * 32 + rl;
+        if (EPI == EPI_RESID_F32) v += res[it];
         if (grow < p.M && gcol < p.N) {
             float* dst = (float*)p.C + (long)grow * p.ldc + gcol;
-            if (EPI == EPI_RESID_F32) v += res[it];
-            *(f32x4*)dst = v;
+            if (EPI == EPI_RESID_F32 && lnst) __builtin_nontemporal_store(v, (f32x4*)dst);
+            else *(f32x4*)dst = v;
+            if (EPI == EPI_RESID_F32 && lnst) {
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *(uint2*)(p.lnf_xb + (long)grow * p.lnf_ldxb + gcol) = o;
+            }
+        }
+        if (EPI == EPI_RESID_F32 && lnst) {           // wave-uniform
+            // two-pass statistics of the row's 64 columns held by its 16 lanes (rows past the edge: never read back)
+            const float mean = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
+            const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+            const float q = row16_sum(fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3));
+            if ((lane & 15) == it) { keep_m = mean; keep_q = q; }      // lane (it, lq) keeps row it * 4 + lq of this quarter
         }
     }
+    if (EPI == EPI_RESID_F32 && lnst && (lane & 15) < 8)
+        lnst[(QT * 32 + (lane & 15) * 4 + (lane >> 4)) * 4] = make_float2(keep_m, keep_q);
     asm volatile("" ::: "memory");
 }
 
@@ -164,9 +272,11 @@ __device__ __forceinline__ void gemm256_epilogue_f32_quarter(const GemmArgs& p, 
 // residual add after it (on the coalesced rows).
 // SKIP_DEAD (192-row tiles): a wave whose second 64 rows lie past p.M (the caller passes the tile's row limit as p.M)
 // skips them altogether instead of masking their stores.
+// lnst: gemm256_epilogue_f32_quarter (producer side of a folded LayerNorm).  lnmr (consumer side, bf16 epilogues; LDS):
+// (rstd, -mean rstd) of the tile's 256 rows, indexed from the wave's first row.
 template <int EPI, bool SKIP_DEAD = false>
 __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, int m_base, int n_base, int lane,
-                                                 f32x4 (&acc)[8][4]) {
+                                                 f32x4 (&acc)[8][4], float2* lnst = nullptr, const float2* lnmr = nullptr) {
     static_assert(EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_F32 || EPI == EPI_RESID_F32 ||
                   EPI == EPI_BF16_ROPE, "");
     // The main loop runs at the 256-VGPR limit: keep every epilogue value from being
@@ -183,6 +293,15 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
     }
     if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE) {
         constexpr int RS = 144;   // 64 bf16 + 16 bytes of padding per slab row
+        // folded LayerNorm (consumer side): out = rstd (acc - mean c) + b'  -- column sums of the rounded weights per lane
+        f32x4 c4[4];
+        if (lnmr) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int col = n_base + n * 16 + lq * 4;
+                c4[n] = col < p.N ? *(const f32x4*)(p.lnc_c + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (SKIP_DEAD && m_base + half * 64 >= p.M) break;          // wave-uniform
@@ -204,17 +323,50 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
                     if (tok_ >= p.rope_S) tok_ -= p.rope_S;
                 }
             }
+            // fragment phase: bias (or the folded LayerNorm's rstd (acc - mean c) + b'), GELU, bf16, transpose through the slab.
+            // The folded form is a separate copy of the loop (a per-fragment test of lnmr cut the GELU chains into
+            // one basic block each).
+            auto frag_phase = [&](auto lnc_tag) {
+                constexpr bool LNC = decltype(lnc_tag)::value;
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m) {
+                    float2 st = make_float2(1.f, 0.f);
+                    if (LNC) st = lnmr[half * 64 + m * 16 + lr];
+                    if (EPI == EPI_BF16_GELU) {
+                        constexpr int GV = REVO_GELU_WIDTH;    // fragments side by side: 2 GV independent GELU chains (gelu_erf4xn)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    f32x4 v = acc[half * 4 + m][n] + bias4[n];
-                    if (EPI == EPI_BF16_GELU) v = gelu_erf4(v);
-                    uint2 o;
-                    o.x = pack_bf16x2(v[0], v[1]);
-                    o.y = pack_bf16x2(v[2], v[3]);
-                    *(uint2*)(slab + (m * 16 + lr) * RS + (n * 16 + lq * 4) * 2) = o;
+                        for (int n0 = 0; n0 < 4; n0 += GV) {
+                            f32x4 v[GV];
+#pragma unroll
+                            for (int n = 0; n < GV; ++n) {
+                                if (LNC && !(REVO_LNC_ABLATE & 2)) v[n] = acc[half * 4 + m][n0 + n] * st.x + (c4[n0 + n] * st.y + bias4[n0 + n]);
+                                else v[n] = acc[half * 4 + m][n0 + n] + bias4[n0 + n];
+                            }
+                            gelu_erf4xn<GV>(v);
+#pragma unroll
+                            for (int n = 0; n < GV; ++n) {
+                                uint2 o;
+                                o.x = pack_bf16x2(v[n][0], v[n][1]);
+                                o.y = pack_bf16x2(v[n][2], v[n][3]);
+                                *(uint2*)(slab + (m * 16 + lr) * RS + ((n0 + n) * 16 + lq * 4) * 2) = o;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            f32x4 v;
+                            if (LNC && !(REVO_LNC_ABLATE & 2)) v = acc[half * 4 + m][n] * st.x + (c4[n] * st.y + bias4[n]);
+                            else v = acc[half * 4 + m][n] + bias4[n];
+                            uint2 o;
+                            o.x = pack_bf16x2(v[0], v[1]);
+                            o.y = pack_bf16x2(v[2], v[3]);
+                            *(uint2*)(slab + (m * 16 + lr) * RS + (n * 16 + lq * 4) * 2) = o;
+                        }
+                    }
                 }
+            };
+            if (lnmr) frag_phase(std::true_type{});
+            else frag_phase(std::false_type{});
             const int gcol = n_base + (lane & 7) * 8;
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
@@ -251,15 +403,80 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
         // "one ahead" between the stores of the previous ones made every use such a drain.  Two batches of loads,
         // each issued when no load result is outstanding, leave two drains per tile.
         f32x4 ra[8], rb[8];
-        if (EPI == EPI_RESID_F32) gemm256_load_resid<0>(p, m_base, n_base, lane, ra);
-        if (EPI == EPI_RESID_F32) gemm256_load_resid<1>(p, m_base, n_base, lane, rb);
-        gemm256_epilogue_f32_quarter<EPI, 0>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, ra);
-        gemm256_epilogue_f32_quarter<EPI, 1>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, rb);
+        if (SKIP_DEAD && m_base >= p.M) return;                         // wave-uniform: a short piece's second wave-row
+        const bool nt = lnst != nullptr;
+        if (EPI == EPI_RESID_F32) gemm256_load_resid<0>(p, m_base, n_base, lane, ra, nt);
+        if (EPI == EPI_RESID_F32) gemm256_load_resid<1>(p, m_base, n_base, lane, rb, nt);
+        gemm256_epilogue_f32_quarter<EPI, 0>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, ra, lnst);
+        gemm256_epilogue_f32_quarter<EPI, 1>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, rb, lnst);
         if (SKIP_DEAD && m_base + 64 >= p.M) return;                    // wave-uniform
-        if (EPI == EPI_RESID_F32) gemm256_load_resid<2>(p, m_base, n_base, lane, ra);
-        if (EPI == EPI_RESID_F32) gemm256_load_resid<3>(p, m_base, n_base, lane, rb);
-        gemm256_epilogue_f32_quarter<EPI, 2>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, ra);
-        gemm256_epilogue_f32_quarter<EPI, 3>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, rb);
+        if (EPI == EPI_RESID_F32) gemm256_load_resid<2>(p, m_base, n_base, lane, ra, nt);
+        if (EPI == EPI_RESID_F32) gemm256_load_resid<3>(p, m_base, n_base, lane, rb, nt);
+        gemm256_epilogue_f32_quarter<EPI, 2>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, ra, lnst);
+        gemm256_epilogue_f32_quarter<EPI, 3>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, rb, lnst);
+    }
+}
+
+// ---- folded LayerNorm in the 256 x 256 kernels: LDS beyond the operand image / the slabs
+//   consumer: raw partial statistics of the tile's 256 rows (DMA, [256][parts] float2, <= 12 KiB), then (rstd, -mean rstd) per row
+//   producer: the waves' 64-column partials [256 rows][4] float2 (8 KiB), merged per 256-column tile behind the epilogue
+constexpr int LNC_RAW_BYTES = 256 * 6 * 8, LNC_MR_BYTES = 256 * 8;           // parts <= 6 in these kernels (width <= 1536)
+constexpr int G256P_LN_OFF = 98304 + 5 * 9216;                                // persistent kernel: above the last slab (144384)
+static_assert(G256P_LN_OFF + LNC_RAW_BYTES + LNC_MR_BYTES <= 163840, "");
+constexpr int G256_LDS_LN = G256_LDS + LNC_RAW_BYTES + LNC_MR_BYTES;          // one-tile kernel: above the operand image
+// DMA of the statistics of rows [m0, m0 + 256): one 1-KiB piece per wave-instruction, pieces dealt over the 8 waves.  Issued
+// BEFORE operand DMA the main loop's counted waits cover (vmcnt retires in issue order), read after the main loop's barriers.
+// (lane ids are made opaque in these helpers: the main loop runs at the 256-VGPR limit, and an address the compiler computes
+//  ahead of it is spilled and reloaded behind it -- a scratch load whose wait also drains the DMA queue and every older store)
+__device__ __forceinline__ void lnc_issue_stats(const GemmArgs& p, int m0, char* lds_raw, int wave, int lane) {
+    asm volatile("" : "+v"(lane) :: "memory");
+    const int P = p.lnc_parts;
+    long left = ((long)p.M - m0) * P * 8;
+    const long full = 256l * P * 8;
+    left = left < 0 ? 0 : (left > full ? full : left);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lnc_stats + (long)m0 * P), 0, (int)left, 0x00020000);
+    for (int i = wave; i < 2 * P; i += 8)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds_raw + i * 1024), 16,
+                                                 (uint32_t)(i * 1024 + lane * 16), 0, 0, 0);
+}
+// after the main loop (its last barrier): one thread per tile row merges the row's partials; ends with a workgroup barrier
+__device__ __forceinline__ void lnc_merge_rows(const GemmArgs& p, const char* lds_raw, float2* lds_mr, int wave, int lane) {
+    asm volatile("" : "+v"(lane) :: "memory");
+    const int t = wave * 64 + lane;
+    if (t < 256) {
+        float r, m;
+        if (p.lnc_parts == 4) {
+            // width 1024: two 16-byte reads, no loops (the same operations in the same order as lnf_merge)
+            const f32x4 a = *(const f32x4*)(lds_raw + t * 32), b = *(const f32x4*)(lds_raw + t * 32 + 16);
+            const float sm = ((0.f + a[0]) + a[2]) + b[0] + b[2], sq = ((0.f + a[1]) + a[3]) + b[1] + b[3];
+            const float mean = sm / 4.0f;
+            float dd = 0.f, d;
+            d = a[0] - mean; dd = fmaf(d, d, dd);
+            d = a[2] - mean; dd = fmaf(d, d, dd);
+            d = b[0] - mean; dd = fmaf(d, d, dd);
+            d = b[2] - mean; dd = fmaf(d, d, dd);
+            const float var = fmaf((float)LNF_SLICE, dd, sq) / (float)(LNF_SLICE * 4);
+            r = rsqrtf(var + p.lnc_eps);
+            m = -mean * r;
+        } else {
+            lnf_merge((const float2*)lds_raw + t * p.lnc_parts, p.lnc_parts, p.lnc_eps, r, m);
+        }
+        lds_mr[t] = make_float2(r, m);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+// producer: the four waves' 64-column partials of every row -> one (mean, M2) per row and 256-column tile, slot `tn` of the row
+__device__ __forceinline__ void lnf_store_tile_stats(const GemmArgs& p, const float2* lds_st, int m0, int mend, int tn, int wave,
+                                                     int lane) {
+    asm volatile("" : "+v"(lane) :: "memory");
+    const int t = wave * 64 + lane;
+    if (t < 256 && m0 + t < mend) {
+        const float2 a = lds_st[t * 4], b = lds_st[t * 4 + 1], c = lds_st[t * 4 + 2], d = lds_st[t * 4 + 3];
+        const float mean = ((a.x + b.x) + (c.x + d.x)) * 0.25f;
+        const float da = a.x - mean, db = b.x - mean, dc = c.x - mean, dd = d.x - mean;
+        const float m2 = ((a.y + b.y) + (c.y + d.y)) + 64.0f * (fmaf(da, da, db * db) + fmaf(dc, dc, dd * dd));
+        p.lnf_stats[(long)(m0 + t) * (p.N / LNF_SLICE) + tn] = make_float2(mean, m2);
     }
 }
 
@@ -375,9 +592,13 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const bool lnc = (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE) && p.lnc_stats != nullptr;
+    float2* lds_mr = (float2*)(smem + G256_LDS + LNC_RAW_BYTES);
     if (!(DBG & 2)) {
+        if (lnc) lnc_issue_stats(p, m0, smem + G256_LDS, wave, lane);
         g256_issue_prologue(A, B, smem, p.K, wave);
         gemm256_mainloop(A, B, smem, p.K, wave, lane, acc);
+        if (lnc) lnc_merge_rows(p, smem + G256_LDS, lds_mr, wave, lane);
     }
     if (DBG & 1) {
         if (acc[0][0][0] != 12345.678f) return;     // timing-only build: keep acc live, store nothing
@@ -389,7 +610,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256_kernel(GemmArgs p) {
         // (a runtime condition for every variant: with the direct epilogue compiled out, hipcc 7.2
         //  allocates the fp32 variants' main loop so badly that the accumulators spill)
         const bool wide = (p.N & 7) == 0 && (p.ldc & 7) == 0;
-        if (wide) gemm256_epilogue<EPI>(p, smem + wave * 16384, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, lane, acc);
+        if (wide) gemm256_epilogue<EPI>(p, smem + wave * 16384, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, lane, acc, nullptr,
+                                        lnc ? lds_mr + (wave >> 2) * 128 : nullptr);
         else gemm_epilogue<EPI, 8, 4>(p, m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, lane, acc);
     }
 }
@@ -439,6 +661,13 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
     int mi = m_lo + slot / n_cnt;
     int m0 = tile_row0(mi), n0 = (n_lo + slot % n_cnt) * 256;
     bool tall = BMR != 256 && mi >= tall0;
+    // folded LayerNorm (kernels.h): consumer side of the bf16 epilogues, producer side of the residual epilogue
+    const bool lnc = (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE) && p.lnc_stats != nullptr;
+    const bool lnf = EPI == EPI_RESID_F32 && p.lnf_stats != nullptr;
+    char* lds_raw = smem + G256P_LN_OFF;
+    float2* lds_mr = (float2*)(smem + G256P_LN_OFF + LNC_RAW_BYTES);
+    float2* lds_st = (float2*)(smem + G256P_LN_OFF);
+    if (lnc) lnc_issue_stats(p, m0, lds_raw, wave, lane);
     G256Operand A, B;
     g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane, BMR == 256 ? 256 : (tall ? 208 : 192));
     g256_operand_init(B, p.B, p.ldb, p.N, n0, wave, lane);
@@ -458,6 +687,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
             for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (BMR == 256) gemm256_mainloop(A, B, smem, p.K, wave, lane, acc);
         else gemm256_mainloop<192>(A, B, smem, p.K, wave, lane, acc, tall);
+        if (lnc && !(REVO_LNC_ABLATE & 1)) lnc_merge_rows(p, lds_raw, lds_mr, wave, lane);       // this tile's rows: (rstd, -mean rstd) in LDS; ends with a barrier
 
         const int mb = m0 + (wave >> 2) * 128, nb = n0 + (wave & 3) * 64;
         GemmArgs pe = p;                                   // the epilogue's row limit: the end of this tile
@@ -465,6 +695,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
             const int mend = m0 + (tall ? 208 : 192);
             pe.M = mend < p.M ? mend : p.M;
         }
+        const int m0_done = m0, tn_done = n0 >> 8;
         slot += nslot;
         const bool more = slot < total;
         if (more) {
@@ -472,6 +703,9 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
             m0 = tile_row0(mi);
             n0 = (n_lo + slot % n_cnt) * 256;
             tall = BMR != 256 && mi >= tall0;
+            // the next tile's row statistics travel with its first K-tile: the raw slots are free again (merged above,
+            // behind a barrier) and the DMA has the whole epilogue to land
+            if (lnc && !(REVO_LNC_ABLATE & 4)) lnc_issue_stats(p, m0, lds_raw, wave, lane);
             g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane, BMR == 256 ? 256 : (tall ? 208 : 192));
             g256_operand_init(B, p.B, p.ldb, p.N, n0, wave, lane);
             g256_issue_half(A, 0, 0, G256_A(smem, 0), wave);
@@ -483,13 +717,150 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
             gemm_epilogue<EPI, 8, 4>(pe, mb, nb, lane, acc);
         } else {
             const bool wide = (p.N & 7) == 0 && (p.ldc & 7) == 0;
-            if (wide) gemm256_epilogue<EPI, BMR != 256>(pe, slab, mb, nb, lane, acc);
+            if (wide) gemm256_epilogue<EPI, BMR != 256>(pe, slab, mb, nb, lane, acc,
+                                                        lnf ? lds_st + (wave >> 2) * 128 * 4 + (wave & 3) : nullptr,
+                                                        lnc ? lds_mr + (wave >> 2) * 128 : nullptr);
             else gemm_epilogue<EPI, 8, 4>(pe, mb, nb, lane, acc);
+        }
+        if (lnf) {
+            // the four waves' 64-column partials of every row of this tile are in LDS: one slot per row and column tile
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // (also: every wave is out of its slab)
+            lnf_store_tile_stats(pe, lds_st, m0_done, pe.M, tn_done, wave, lane);
+            if (!more) break;
+            continue;                                      // the main loop's barriers separate these reads from the next tile's writes
         }
         if (!more) break;
         __builtin_amdgcn_s_barrier();      // every wave is out of its slab before A stage 1 is refilled
     }
 }
+
+#ifdef REVO_EXPERIMENTS
+// Phased form of the persistent kernel -- EXPERIMENT LIBRARY ONLY: measured in round 5 and not adopted (DESIGN_HISTORY.md,
+// profiles/r05_gemm_phase_groups.json: bit-identical, 5-12 % slower on three of the four body GEMMs, +-0 on out-proj).
+// All 256 workgroups of gemm256p_kernel run their main loops and their
+// epilogues at the same moments: the epilogues' HBM traffic (stores of bf16 tiles, read-modify-write of the fp32
+// residual stream) is paid while no MFMA runs, and the main loops run while HBM idles ("phases in series").
+// Starting some workgroups late de-phases them, but costs exactly the delay.  Here the shift is free: a workgroup of
+// phase group g does the first h_g rows of its FIRST tile at the start and the remaining rows of that tile at the very
+// end (h_g = 64, 128, 192, 256 for four groups), whole tiles in between.  Every group does the same total work; through
+// all middle rounds the groups sit a quarter of a tile apart, so at any moment only a fraction of the CUs is in its
+// epilogue.  Tile -> workgroup mapping and every row's arithmetic are those of gemm256p_kernel (a row's result does
+// not depend on which piece computed it: same K order, same epilogue), so the output is bit-identical.
+// The piece heights are run-time, wave-uniform row modes of ONE main-loop instantiation (gemm256_mainloop<0, true>).
+template <int EPI, int BMR = 256>
+__global__ __launch_bounds__(G256_THREADS, 2) void gemm256pp_kernel(GemmArgs p, int nslot, int groups) {
+    static_assert(BMR == 256 || BMR == 192, "");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = (p.N + 255) / 256;
+    const int tiles_m = BMR == 256 ? (p.M + 255) / 256 : p.t192_tiles;
+    const int tall0 = tiles_m - (BMR == 256 ? 0 : p.t192_tall);
+    const int gy = p.gy, gx = 8 / gy;
+    const int xcd = blockIdx.x & 7;
+    const int xi = xcd / gy, xj = xcd - xi * gy;
+    const int pm = (tiles_m + gx - 1) / gx, pn = (tiles_n + gy - 1) / gy;
+    const int m_lo = xi * pm, n_lo = xj * pn;
+    const int m_cnt = (tiles_m - m_lo) < pm ? (tiles_m - m_lo) : pm;
+    const int n_cnt = (tiles_n - n_lo) < pn ? (tiles_n - n_lo) : pn;
+    const int total = (m_cnt > 0 && n_cnt > 0) ? m_cnt * n_cnt : 0;
+    const int slot0 = blockIdx.x >> 3;
+    if (slot0 >= total) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wr = wave >> 2;
+    char* slab = smem + (wave < 3 ? 32768 + wave * 9216 : 98304 + (wave - 3) * 9216);
+
+    auto tile_row0 = [&](int mi) { return BMR == 256 ? mi * 256 : mi * 192 + (mi > tall0 ? (mi - tall0) * 16 : 0); };
+    // this workgroup's tiles: slots slot0, slot0 + nslot, ...; phase group by the tile ROW of the first one (the
+    // workgroups that share an A stripe stay in step and keep meeting in L2)
+    const int ntiles = (total - slot0 + nslot - 1) / nslot;
+    const int grp = (slot0 / n_cnt) % groups;
+    const int h = 64 * (((grp + 1) * (BMR / 64) + groups - 1) / groups);        // 64 .. BMR
+    const bool first_tall = BMR != 256 && (m_lo + slot0 / n_cnt) >= tall0;
+    const bool split = h < BMR && ntiles >= 2 && !first_tall;
+    const int nitems = ntiles + (split ? 1 : 0);
+
+    int m0, n0, rows;
+    auto item = [&](int it) {
+        const bool last_piece = split && it == nitems - 1;
+        const int s = last_piece ? slot0 : slot0 + it * nslot;
+        const int mi = m_lo + s / n_cnt;
+        n0 = (n_lo + s % n_cnt) * 256;
+        m0 = tile_row0(mi);
+        rows = BMR == 256 ? 256 : (mi >= tall0 ? 208 : 192);
+        if (split && it == 0) rows = h;
+        if (last_piece) { m0 += h; rows = BMR - h; }
+    };
+    item(0);
+    G256Operand A, B;
+    g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane, rows);
+    g256_operand_init(B, p.B, p.ldb, p.N, n0, wave, lane);
+    g256_issue_half(A, 0, 0, G256_A(smem, 0), wave);
+    g256_issue_half(A, 1, 0, G256_A(smem, 0), wave);
+    g256_issue_half(B, 0, 0, G256_B(smem, 0), wave);
+    g256_issue_half(B, 1, 0, G256_B(smem, 0), wave);
+    for (int it = 0;;) {
+        if (p.K > 64) {
+            g256_issue_half(A, 0, 128, G256_A(smem, 1), wave);
+            g256_issue_half(A, 1, 128, G256_A(smem, 1), wave);
+        }
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // row mode of this piece: which 64-row halves of its 128 rows this wave computes
+        const bool do_lo = wr == 0 ? true : rows > 128;
+        const bool do_hi = wr == 0 ? rows > 64 : rows >= 256;
+        const bool do_ht = wr == 1 && rows == 208;
+#ifdef REVO_EXPERIMENTS
+        unsigned long long t_a = 0, t_b = 0;
+        if (p.stamps) t_a = __builtin_amdgcn_s_memrealtime();
+#endif
+        gemm256_mainloop<0, true>(A, B, smem, p.K, wave, lane, acc, do_ht, do_lo, do_hi);
+#ifdef REVO_EXPERIMENTS
+        if (p.stamps) t_b = __builtin_amdgcn_s_memrealtime();
+#endif
+
+        const int mb = m0 + wr * 128, nb = n0 + (wave & 3) * 64;
+        GemmArgs pe = p;                                   // the epilogue's row limit: the end of this piece
+        {
+            const int mend = m0 + rows;
+            pe.M = mend < p.M ? mend : p.M;
+        }
+#ifdef REVO_EXPERIMENTS
+        const int it_done = it, rows_done = rows;
+#endif
+        ++it;
+        const bool more = it < nitems;
+        if (more) {
+            item(it);
+            g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane, rows);
+            g256_operand_init(B, p.B, p.ldb, p.N, n0, wave, lane);
+            g256_issue_half(A, 0, 0, G256_A(smem, 0), wave);
+            g256_issue_half(A, 1, 0, G256_A(smem, 0), wave);
+            g256_issue_half(B, 0, 0, G256_B(smem, 0), wave);
+            g256_issue_half(B, 1, 0, G256_B(smem, 0), wave);
+        }
+        if constexpr (EPI == EPI_PATCH) {
+            gemm_epilogue<EPI, 8, 4>(pe, mb, nb, lane, acc);
+        } else {
+            const bool wide = (p.N & 7) == 0 && (p.ldc & 7) == 0;
+            if (wide) gemm256_epilogue<EPI, true>(pe, slab, mb, nb, lane, acc);
+            else gemm_epilogue<EPI, 8, 4>(pe, mb, nb, lane, acc);
+        }
+#ifdef REVO_EXPERIMENTS
+        if (p.stamps && wave == 0 && lane == 0 && it_done < p.stamp_items) {
+            // diagnostic build only: when this workgroup's main loop began / ended and when its epilogue had issued its last store
+            unsigned long long* dst = p.stamps + ((size_t)blockIdx.x * p.stamp_items + it_done) * 4;
+            dst[0] = t_a; dst[1] = t_b; dst[2] = __builtin_amdgcn_s_memrealtime(); dst[3] = (unsigned long long)rows_done;
+        }
+#endif
+        if (!more) break;
+        __builtin_amdgcn_s_barrier();      // every wave is out of its slab before A stage 1 is refilled
+    }
+}
+#endif   // REVO_EXPERIMENTS (phased persistent kernel)
 
 // Skinny GEMM for M <= 64 (the attention-pool head at batch <= 64: four layers whose time is the
 // streaming of 2-8 MB of weights).  The tiled kernels give such a problem N/128 workgroups and a
@@ -564,7 +935,7 @@ static int g_force_gy = 0;     // timing experiments only: force the XCD arrange
 void gemm_force_gy(int gy) { g_force_gy = gy; }
 template <int EPI, int DBG>
 static int launch_256d(const GemmArgs& a, hipStream_t st) {
-    REVO_FUNC_LDS((gemm256_kernel<EPI, DBG>), G256_LDS);
+    REVO_FUNC_LDS((gemm256_kernel<EPI, DBG>), G256_LDS_LN);
     // XCD arrangement (measured on MI355X, scripts/gemm_gy.py): with few N tiles every XCD sweeps
     // all of N for its M stripe (gy = 1); from 12 N tiles on, four N stripes keep a weight stripe
     // L2 resident and cut the fabric traffic (qkv 933 -> 1122, fc1 859 -> 920, 8192^3 1322 -> 1453 TF)
@@ -575,7 +946,7 @@ static int launch_256d(const GemmArgs& a, hipStream_t st) {
     b.gy = gy;
     const int gx = 8 / gy;
     const int region = ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
-    hipLaunchKernelGGL((gemm256_kernel<EPI, DBG>), dim3(8 * region), dim3(G256_THREADS), G256_LDS, st, b);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, DBG>), dim3(8 * region), dim3(G256_THREADS), G256_LDS_LN, st, b);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -586,12 +957,19 @@ void gemm_set_stagger(int cycles, int groups) { g_stagger_cycles = cycles; g_sta
 #endif
 static int g_persistent = 1;   // timing experiments only: 0 = one workgroup per tile
 void gemm_set_persistent(int on) { g_persistent = on; }
+#ifdef REVO_EXPERIMENTS
+// phase groups of the persistent kernel (gemm256pp_kernel): 0 / 1 = off (gemm256p_kernel), 2..4 forced
+static int g_phase_groups = 0;
+void gemm_set_phase_groups(int g) { g_phase_groups = g < 0 ? 0 : (g > 4 ? 4 : g); }
+static unsigned long long* g_stamps = nullptr; static int g_stamp_items = 0;
+void gemm_set_stamps(unsigned long long* buf, int items) { g_stamps = buf; g_stamp_items = items; }
+#endif
 template <int EPI, int BMR = 256>
 static int launch_256p(const GemmArgs& a, hipStream_t st) {
-    REVO_FUNC_LDS((gemm256p_kernel<EPI, BMR>), G256P_LDS);
     GemmArgs b = a;
 #ifdef REVO_EXPERIMENTS
     b.stagger_cycles = g_stagger_cycles; b.stagger_groups = g_stagger_groups;
+    b.stamps = g_stamps; b.stamp_items = g_stamp_items;
 #endif
     const int tiles_m = BMR == 256 ? (a.M + 255) / 256 : a.t192_tiles, tiles_n = (a.N + 255) / 256;
     int gy = tiles_n >= 12 ? 4 : (tiles_n >= 8 ? 2 : 1);
@@ -600,6 +978,21 @@ static int launch_256p(const GemmArgs& a, hipStream_t st) {
     const int gx = 8 / gy;
     const int region = ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
     const int nslot = region < 32 ? region : 32;          // 32 CUs per XCD
+#ifdef REVO_EXPERIMENTS
+    {
+        // phase groups (gemm256pp_kernel), forced by scripts/gemm_phase_ab.py only; the stamps live in that kernel too
+        // (one group = every workgroup in step)
+        int groups = g_phase_groups > 1 ? g_phase_groups : 1;
+        if (BMR != 256 && groups > 3) groups = 3;
+        if (groups > 1 || b.stamps != nullptr) {
+            REVO_FUNC_LDS((gemm256pp_kernel<EPI, BMR>), G256P_LDS);
+            hipLaunchKernelGGL((gemm256pp_kernel<EPI, BMR>), dim3(8 * nslot), dim3(G256_THREADS), G256P_LDS, st, b, nslot, groups);
+            REVO_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
+#endif
+    REVO_FUNC_LDS((gemm256p_kernel<EPI, BMR>), G256P_LDS);
     hipLaunchKernelGGL((gemm256p_kernel<EPI, BMR>), dim3(8 * nslot), dim3(G256_THREADS), G256P_LDS, st, b, nslot);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
@@ -730,8 +1123,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float
             float y[8];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                const f32x4 gm = *(const f32x4*)(lw + g * 8 + hh * 4);
-                const f32x4 be = *(const f32x4*)(lb + g * 8 + hh * 4);
+                const f32x4 gm = lw ? *(const f32x4*)(lw + g * 8 + hh * 4) : (f32x4){1.f, 1.f, 1.f, 1.f};
+                const f32x4 be = lb ? *(const f32x4*)(lb + g * 8 + hh * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[hh * 4 + j] = fmaf((v[i][hh][j] - mean) * rstd, gm[j], be[j]);
             }
@@ -754,7 +1147,7 @@ static int try_splitk_tail(const GemmArgs& a, hipStream_t st) {
         // one image: so few tiles that even 128 x 64 ones leave most CUs idle -- the ring kernel on K thirds (80 tiles x 3);
         // with the LayerNorm that follows folded into the reduce this also pays at K = 1024 (out-proj: 5 K-steps per part)
         const int tiles64 = ((a.M + 127) / 128) * ((a.N + 63) / 64);
-        const bool with_ln = a.ln_w && a.ln_b && a.ln_out && a.ln_fused && a.N % 8 == 0 && a.N <= 2048 && a.ln_ldo % 8 == 0;
+        const bool with_ln = a.ln_out && a.ln_fused && a.N % 8 == 0 && a.N <= 2048 && a.ln_ldo % 8 == 0;     // (ln_w / ln_b null: no affine)
         int S = g_ring && a.N % 64 == 0 ? 256 / tiles64 : 0;
         S = S > 8 ? 8 : S;
         while (S > 1 && nt / S < (with_ln ? 4 : 8)) --S;
@@ -856,13 +1249,24 @@ static int launch_skinny(const GemmArgs& a, hipStream_t st) {
     return 0;
 }
 
+static int g_lnf = 1;          // timing experiments only: 0 = never fold a LayerNorm into the residual GEMMs (the caller runs the kernel)
+void gemm_set_ln_fold(int on) { g_lnf = on; }
 template <int EPI>
-static int launch_t(const GemmArgs& a, hipStream_t st) {
+static int launch_t(const GemmArgs& a_in, hipStream_t st) {
+    GemmArgs a = a_in;
+    // Producer side of a folded LayerNorm (kernels.h): only the two launch forms below that cover ALL rows with the
+    // persistent 256-row kernel's row-coalesced epilogue write bf16(x) and the row statistics; every other form leaves
+    // *lnf_done alone and the caller runs the LayerNorm kernel.
+    const bool lnf_ok = EPI == EPI_RESID_F32 && g_lnf && a.lnf_stats && a.lnf_xb && a.lnf_done && a.N % LNF_SLICE == 0 &&
+                        a.N / LNF_SLICE <= 6 && (a.ldc & 7) == 0 && a.lnf_ldxb % 4 == 0 && g_force_tile == 0;
+    bf16_t* const lnf_xb = a.lnf_xb;
+    float2* const lnf_stats = a.lnf_stats;
+    a.lnf_xb = nullptr; a.lnf_stats = nullptr;
     if (a.prefer256 && g_force_tile == 0 && 256l * a.lda * 2 < (1l << 31) && 256l * a.ldb * 2 < (1l << 31))
         return launch_256<EPI>(a, st);
     if constexpr (EPI == EPI_RESID_F32) {
         // a few tiles with a long K (fc2 of one to a few images): the K loop is a latency chain, cut it across CUs
-        if (g_force_tile == 0 && a.M > 64 && (a.K >= 2048 || (a.K >= 1024 && a.ln_w)) && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) <= 96 &&
+        if (g_force_tile == 0 && a.M > 64 && (a.K >= 2048 || (a.K >= 1024 && a.ln_out)) && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) <= 96 &&
             256l * a.lda * 2 < (1l << 31) && 256l * a.ldb * 2 < (1l << 31)) {
             const int rc2 = try_splitk_tail(a, st);
             if (rc2 < 0) return rc2;
@@ -882,9 +1286,12 @@ static int launch_t(const GemmArgs& a, hipStream_t st) {
             int tall = 0;
             if (const int t192 = plan_rows192(a, true, &tall)) {
                 GemmArgs a1 = a;
-                a1.ln_w = nullptr;
+                a1.ln_out = nullptr;
                 a1.t192_tiles = t192; a1.t192_tall = tall;
-                return launch_256p<EPI, 192>(a1, st);
+                if (lnf_ok) { a1.lnf_xb = lnf_xb; a1.lnf_stats = lnf_stats; }
+                const int rc = launch_256p<EPI, 192>(a1, st);
+                if (rc == 0 && lnf_ok) *a.lnf_done = 1;
+                return rc;
             }
         }
         const long tm = (a.M + 255) / 256, tn = (a.N + 255) / 256;
@@ -895,10 +1302,11 @@ static int launch_t(const GemmArgs& a, hipStream_t st) {
             if (m_tiles_main >= 1 && m_tiles_main < tm) {
                 const int m_main = (int)(m_tiles_main * 256);
                 GemmArgs a1 = a, a2 = a;
-                a1.ln_w = a2.ln_w = nullptr;          // a LayerNorm can only be folded into a launch form that covers ALL rows
+                a1.ln_out = a2.ln_out = nullptr;      // a LayerNorm can only be folded into a launch form that covers ALL rows
                 a1.M = m_main;
                 a2.M = a.M - m_main;
                 a2.A = a.A + (long)m_main * a.lda;
+                if (a2.lnc_stats) a2.lnc_stats += (long)m_main * a.lnc_parts;     // the leftover rows' statistics
                 const long esz = (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) ? 2 : 4;
                 a2.C = (char*)a.C + (long)m_main * a.ldc * esz;
                 const int rc = launch_256<EPI>(a1, st);
@@ -910,6 +1318,16 @@ static int launch_t(const GemmArgs& a, hipStream_t st) {
                     if (rc2 == 1) return 0;
                 }
                 return launch_128<EPI>(a2, st);
+            }
+        }
+        if constexpr (EPI == EPI_RESID_F32) {
+            // whole rounds of 256-row tiles on the persistent kernel: all rows in one launch
+            if (lnf_ok && g_persistent && a.K >= 128 && tiles > 256) {
+                GemmArgs a1 = a;
+                a1.lnf_xb = lnf_xb; a1.lnf_stats = lnf_stats;
+                const int rc = launch_256p<EPI>(a1, st);
+                if (rc == 0) *a.lnf_done = 1;
+                return rc;
             }
         }
         return launch_256<EPI>(a, st);
@@ -944,6 +1362,10 @@ static int launch_128(const GemmArgs& a, hipStream_t st) {
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
     if (const char* e = check_args(a)) {
         revo_set_error(e);
+        return -2;
+    }
+    if (a.lnc_stats && (!a.lnc_c || a.lnc_parts < 1 || a.lnc_parts > 6 || (epi != EPI_BF16 && epi != EPI_BF16_GELU && epi != EPI_BF16_ROPE))) {
+        revo_set_error("gemm: a folded LayerNorm (lnc_*) needs a bf16 epilogue, the column sums and 1..6 statistics slots per row");
         return -2;
     }
     switch (epi) {

@@ -166,14 +166,20 @@ __device__ __forceinline__ void g256_issue_prologue(const G256Operand& A, const 
 // carries one full and one half wave tile: 3/4 of the MFMA work of a 256-row tile, evenly spread.  With `tall` (wave
 // uniform) the tile has 208 rows: the second wave-row also takes the first fragment of its A-hi half (rows 192..207),
 // 1/16 of a tile's work more -- how the launcher places a few leftover rows without a launch of their own.
-template <int ROWS = 0>
+// RT = true: the row mode is a run-time, wave-uniform choice instead (rt_lo / rt_hi: this wave computes its first / second
+// 64 rows; `tall`: only the first fragment of its second 64) -- the phased persistent kernel, whose workgroups cut their
+// first tile into two pieces of different heights (gemm.hip gemm256pp_kernel).  Same instruction stream per active part,
+// so every row's result has the bits the fixed modes give it.
+template <int ROWS = 0, bool RT = false>
 __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G256Operand& B, char* smem, int K,
-                                                 int wave, int lane, f32x4 (&acc)[8][4], bool tall = false) {
+                                                 int wave, int lane, f32x4 (&acc)[8][4], bool tall = false,
+                                                 bool rt_lo = true, bool rt_hi = true) {
     static_assert(ROWS == 0 || ROWS == 64 || ROWS == 128 || ROWS == 192, "");
+    static_assert(!RT || ROWS == 0, "the run-time row mode has no compile-time one");
     const bool wact = wave < 4;
-#define G256_LO(...) do { if (ROWS == 0 || ROWS == 192 || wact) { __VA_ARGS__; } } while (0)
-#define G256_HI(...) do { if (ROWS == 0 || ((ROWS == 128 || ROWS == 192) && wact)) { __VA_ARGS__; } } while (0)
-#define G256_HT(...) do { if (ROWS == 192 && !wact && tall) { __VA_ARGS__; } } while (0)
+#define G256_LO(...) do { if (RT ? rt_lo : (ROWS == 0 || ROWS == 192 || wact)) { __VA_ARGS__; } } while (0)
+#define G256_HI(...) do { if (RT ? rt_hi : (ROWS == 0 || ((ROWS == 128 || ROWS == 192) && wact))) { __VA_ARGS__; } } while (0)
+#define G256_HT(...) do { if (RT ? tall : (ROWS == 192 && !wact && tall)) { __VA_ARGS__; } } while (0)
     const int nt = K >> 6;
     G256Frags f;
     G256Addr ad;

@@ -34,9 +34,23 @@ struct GemmArgs {
     // launcher takes the one-image form -- ring kernel on K parts + one reduce -- the reduce also normalises its rows
     // into ln_out (bf16) and *ln_fused is set to 1: the caller then skips that LayerNorm launch (a 577-row LayerNorm is
     // nothing but its launch: 5 us of a 90-us block).  Any other form leaves *ln_fused alone.
+    // (ln_w == null with ln_out set: normalise only, no affine -- the towers' gains and shifts live in the weights of
+    //  the GEMM that follows, api.hip "LayerNorm folded")
     const float* ln_w; const float* ln_b; float ln_eps; bf16_t* ln_out; long ln_ldo; int* ln_fused;
+    // LayerNorm folded into the two GEMMs around it.  The LayerNorm's gain lives in the next GEMM's
+    // weights (W' = bf16(gamma . W), bias b' = b + W beta), so what that GEMM needs from the row is bf16(x) as its A
+    // operand and the row's mean and 1/std in its epilogue:   out = rstd * (bf16(x) . W'^T - mean * c) + b',  c_j = sum_k W'_jk.
+    //  * producer (EPI_RESID_F32, the GEMM that writes the residual row): lnf_xb (bf16 [M][lnf_ldxb]) receives bf16(x_new),
+    //    lnf_stats ([M][N / 256] (mean, M2) of each 256-column slice of the new row: one slot per column tile, fixed
+    //    order, merged by the consumer).  Only launch forms that cover ALL rows with the 256 x 256 kernels' row-coalesced
+    //    epilogue do this; they set *lnf_done = 1, any other form leaves it alone (the caller then runs the LayerNorm kernel).
+    //  * consumer (EPI_BF16 / _GELU / _ROPE): lnc_stats ([M][lnc_parts] as written above; the normalised width is
+    //    256 * lnc_parts), lnc_c ([N] column sums of the rounded weights), lnc_eps; `bias` is b'.
+    bf16_t* lnf_xb; long lnf_ldxb; float2* lnf_stats; int* lnf_done;
+    const float2* lnc_stats; int lnc_parts; const float* lnc_c; float lnc_eps;
 #ifdef REVO_EXPERIMENTS
     int stagger_cycles, stagger_groups;   // timing experiment (persistent kernel): phase groups, see gemm256p_kernel
+    unsigned long long* stamps; int stamp_items;   // diagnostic (gemm256pp_kernel): [workgroup][item][4] 100 MHz time stamps
 #endif
 };
 // true when launch_gemm would run the 256 x 256 kernel with the row-coalesced epilogue for these sizes
@@ -45,6 +59,8 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
 #ifdef REVO_EXPERIMENTS
 void gemm_set_debug(int d);           // timing experiments (results are wrong): librevo_exp.so only
 void gemm_set_stagger(int cycles, int groups);
+void gemm_set_stamps(unsigned long long* buf, int items);
+void gemm_set_phase_groups(int g);    // 0 / 1 = off, 2..4 = forced (scripts/gemm_phase_ab.py)
 #endif
 void gemm_force_gy(int gy);
 void gemm_set_tail_split(int on);
@@ -58,6 +74,10 @@ constexpr int LN_MAXH = 16;
 struct LnLogits { const float* qk; const float* ck; float* logits; int H, S; };
 int launch_layernorm(const float* x, long ldx, const float* w, const float* b, float eps, int rows, int W,
                      void* out, long ldo, int out_is_bf16, hipStream_t st, const LnLogits* logits = nullptr);
+// (w / b null: normalise only.)  Weights of a linear layer with the LayerNorm in front of it folded in (elementwise.hip):
+// out = bf16(gamma . W) [rows][ld], csum[j] = sum_k of the rounded row, bias_out = bias + W beta
+int launch_fold_ln_linear(const float* w, const float* gamma, const float* beta, const float* bias, int rows, int cols,
+                          bf16_t* out, long ld, float* csum, float* bias_out, hipStream_t st);
 // images NCHW (u8 pixel values; f32: already normalised to [-1, 1]) -> im2col matrix for the split-precision patch GEMM:
 // rows [B*G*G][parts * Kp] bf16, k = c*P*P + py*P + px zero padded to Kp, parts = 2 (u8: the exact integers 2v - 255,
 // twice) or 3 (f32: hi | hi | lo of 255 x); the weights carry the 1/255 (elementwise.hip, head.hip split_hi_lo_hi)
@@ -98,6 +118,7 @@ void gemm_set_ring(int on, int max_tiles);   // timing experiments only (default
 void gemm_set_splitk(int on);       // timing experiments only (1 = default)
 void gemm_set_persistent(int on);   // timing experiments only (1 = default)
 void gemm_set_rows192(int on);      // timing experiments only (1 = default)
+void gemm_set_ln_fold(int on);      // timing experiments only (1 = default): 0 = LayerNorm kernels instead of the folded form
 void attention_force_nw(int nw);   // timing experiments only (0 = heuristic)
 
 // ---------------------------------------------------------------- top-k ----

@@ -75,10 +75,39 @@ def test_attention_kernel_keeps_four_waves_per_simd():
 def test_body_gemm_kernels_stay_within_their_allocation():
     d = _usage("gemm.hip")
     # gemm256p_kernel<EPI, BMR>: EPI 1 = GELU (fc1), 2 = residual (out-proj, fc2), 5 = RoPE (qkv); the handful of spilled
-    # registers are epilogue values, outside the main loop (measured kernels: DESIGN.md section 6)
-    for epi, bmr, allowed in ((1, 256, 0), (2, 256, 2), (2, 192, 2), (5, 256, 4), (0, 256, 2)):
+    # registers are epilogue values, outside the main loop (measured kernels: DESIGN.md section 6).  Round 5 (the folded
+    # LayerNorm's statistics in the epilogues, GELU on four fragments side by side): the plain bf16 form parks one f32x4
+    # across the tile loop, the RoPE form two more registers -- all outside the K loop, which the next test checks.
+    for epi, bmr, allowed in ((1, 256, 2), (2, 256, 2), (2, 192, 2), (5, 256, 6), (0, 256, 12)):
         u = _find(d, "gemm256p_kernel", f"ILi{epi}ELi{bmr}E")
         assert u["VGPRs"] <= 256 and u["VGPRs Spill"] <= allowed, (epi, bmr, u)
     for epi in (0, 1, 2, 5):
         u = _find(d, "gemm256_kernel", f"ILi{epi}ELi0E")
         assert u["VGPRs Spill"] == 0, (epi, u)
+
+
+def test_no_scratch_traffic_inside_the_k_loop_of_the_body_gemms():
+    """What the spill counts above cannot say: WHERE the spilled values are reloaded.  A scratch load inside the K loop
+    (the innermost loop of the persistent kernels, `Depth=2` in hipcc's listing) costs every K-tile; behind it -- once per
+    output tile -- it costs a queue drain at most.  Round 5 moved epilogue code twice before the listing was clean."""
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-S",
+                          "--cuda-device-only", "gemm.hip", "-o", "-"], cwd=CSRC, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    asm = out.stdout
+    checked = 0
+    for m in re.finditer(r"^(_ZN4revo15gemm256p_kernelILi\d+ELi\d+EEEvNS_8GemmArgsEi):", asm, flags=re.M):
+        body = asm[m.end(): asm.index(".Lfunc_end", m.end())].splitlines()
+        depth, inner_mfma, inner_scratch = 0, 0, []
+        for ln in body:
+            if ln.startswith(".LBB") or ln.startswith("; %bb."):       # a basic block: hipcc notes the loop it belongs to
+                dm = re.search(r"Depth=(\d+)", ln)
+                depth = int(dm.group(1)) if dm else 0
+            elif depth >= 2:
+                inner_mfma += "v_mfma" in ln
+                if "scratch_" in ln:
+                    inner_scratch.append(ln.strip())
+        if inner_mfma == 0:
+            continue                      # (a listing whose loop nest hipcc printed differently: nothing to judge)
+        checked += 1
+        assert not inner_scratch, (m.group(1), inner_scratch[:4])
+    assert checked >= 4, checked
