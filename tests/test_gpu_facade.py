@@ -389,3 +389,81 @@ def test_resume_refuses_a_build_of_another_folder_model_or_mode(tmp_path, dev):
     assert r2.delete_database("h").startswith("✅")
     assert not os.path.exists(os.path.join(root, "h")) and not os.path.exists(os.path.join(root, "h.building"))
     assert not os.path.exists(os.path.join(root, "checkpoints", "h_checkpoint.json"))
+
+
+def test_two_threads_share_one_instance(tmp_path, dev):
+    """The reference's UI drives ONE global SimpleReverso from Gradio's worker threads with no locks (ui.py:19-20): a build
+    runs in one callback (ui.py:86-94) while another embeds a query and searches the loaded database (ui.py:39, :131-142,
+    swapping `region_embeddings` in place, :128-133) and a third sets the stop flag the build polls (ui.py:109,
+    core_system.py:457-459, :542-545).  Here: thread A builds a 256-image database; thread B, meanwhile, embeds + searches
+    against a previously loaded database and finally asks A to stop.  B's answers equal the single-threaded ones bit for
+    bit (the engine's workspace and the handles are serialised by the instance's lock), A returns the reference's stop
+    message, the loaded database stays the searchable one, and the resumed build ends with the gallery bytes an
+    uninterrupted build gives."""
+    import threading
+    import time
+    folder_small = str(tmp_path / "small")
+    small = _make_jpegs(folder_small, n=24, seed=3)
+    folder_big = str(tmp_path / "big")
+    _make_jpegs(folder_big, n=256, seed=4)
+    r = SimpleReverso(model_name="PE-Core-B16-224", db_root=str(tmp_path / "db"), max_batch=8, checkpoint_interval_s=0.05)
+    assert "ready for searching" in r.create_database(folder_small, "loaded", use_direct_pe=True)
+    # single-threaded answers first
+    want = []
+    for p in small[:6]:
+        emb, _ = r.process_image_direct_pe(p)
+        text, items = r.search_similar(similarity_threshold=0.0, max_results=5)
+        want.append((emb[0].clone(), text, [(it["filename"], it["score"], it["bbox"]) for it in items]))
+    assert all(w[2][0][0] == os.path.basename(p) for w, p in zip(want, small[:6]))           # each image finds itself first
+
+    out, errors, started = {}, [], threading.Event()
+
+    def slow_progress(message, value=None):
+        """A UI's progress callback (ui.py:86-94 hands one in): it also keeps this build going long enough for the other
+        thread's queries -- 256 small JPEGs are a fraction of a second of device time."""
+        started.set()
+        time.sleep(0.02)
+
+    def build():
+        try:
+            out["msg"] = r.create_database(folder_big, "big", use_direct_pe=True, progress_callback=slow_progress)
+        except Exception as e:                       # the reference never raises to the UI (core_system.py:585-591)
+            errors.append(e)
+
+    def query():
+        try:
+            assert started.wait(60)
+            rounds = 0
+            t_end = time.time() + 120
+            while rounds < 3 and time.time() < t_end:
+                for p, (e0, text0, items0) in zip(small[:6], want):
+                    emb, _ = r.process_image_direct_pe(p)
+                    text, items = r.search_similar(similarity_threshold=0.0, max_results=5)
+                    assert torch.equal(emb[0], e0), "a query embedded while a build runs differs"
+                    assert text == text0 and [(it["filename"], it["score"], it["bbox"]) for it in items] == items0
+                    assert r.current_database == "simple_reverso_loaded"              # the build has not replaced it
+                rounds += 1
+            out["rounds"] = rounds
+            out["still_building"] = r._building_name == "big" and ta.is_alive()      # the queries did overlap the build
+            r.request_stop()                         # ui.py:109
+        except Exception as e:
+            errors.append(e)
+            r.request_stop()
+
+    ta, tb = threading.Thread(target=build), threading.Thread(target=query)
+    ta.start(); tb.start()
+    tb.join(180); ta.join(180)
+    assert not ta.is_alive() and not tb.is_alive()
+    assert not errors, errors
+    assert out["rounds"] == 3 and out["still_building"], out
+    assert "⏸️ Processing stopped. You can resume later." in out["msg"], out["msg"][-300:]
+    assert r.list_databases() == ["loaded"] and len(r.vector_db) == 24               # the half-built one is not a database
+    # resume (core_system.py:524-538) and compare with an uninterrupted build of the same folder
+    msg = r.create_database(folder_big, "big", use_direct_pe=True, resume_from_checkpoint=True)
+    assert "ready for searching" in msg and len(r.vector_db) == 256, msg[-300:]
+    resumed = r.vector_db.gallery.read(0, 256).cpu()
+    names = [pl["filename"] for pl in r.vector_db.payloads]
+    r2 = SimpleReverso(model_name="PE-Core-B16-224", db_root=str(tmp_path / "db2"), max_batch=8)
+    assert "ready for searching" in r2.create_database(folder_big, "big", use_direct_pe=True)
+    assert [pl["filename"] for pl in r2.vector_db.payloads] == names
+    assert torch.equal(r2.vector_db.gallery.read(0, 256).cpu(), resumed)
