@@ -413,7 +413,7 @@ def main():
     cert_headline = gal.search_stats() if world == 1 else {"uncertified": ss.last_uncertified}
 
     # BASELINE.json configs[3]: a large batch of replicated queries against the whole gallery THROUGH the sharded
-    # search (per-shard scan, both all-gathers, merge) -- the MFMA-bound regime of the fused scan (north_star:
+    # search (per-shard scan, the packed all-gather, merge + certificate) -- the MFMA-bound regime of the fused scan (north_star:
     # >= 40 % of bf16 MFMA peak on the query x gallery GEMM, >= 6x at 8 GPUs).  Measured after the headline
     # region; it does not enter `value`.
     search_big = None

@@ -901,10 +901,15 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
     // the admission margin only pays where the certificate is expected to fail (see revo_search_topk) and only the
     // 256 x 256 scan has segments; it needs the fp32 rows (no certificate without them)
     margin = margin && g->keep_f32 && N >= SEARCH_SMALL_ROWS;
-    { ProfScope ps("search_prep", st);
-      CHECK_RC(launch_l2norm_rows(queries, D, g->qf, D, g->qb, D, Q, D, st, 1, g->qstat, nullptr));
-      if (margin) CHECK_RC(launch_cert_margin(g->qstat, g->gstat, D, Q, g->marg, g->dropflag, st));
-      if (g->xbuf) REVO_HIP_CHECK(hipMemsetAsync(g->xw.ctr, 0, 32, st)); }
+    // query normalisation (+ rounding norms); the same kernel clears the certificate's counters and -- 256 x 256 scan -- the
+    // score histograms (two memset launches fewer per search: a quarter of a one-query search is launches)
+    auto prep = [&](uint32_t* hist, long hist_words) -> int {
+        ProfScope ps("search_prep", st);
+        CHECK_RC(launch_l2norm_rows(queries, D, g->qf, D, g->qb, D, Q, D, st, 1, g->qstat, nullptr,
+                                    g->xbuf ? (uint32_t*)g->xw.ctr : nullptr, g->xbuf ? 8 : 0, hist, hist_words));
+        if (margin) CHECK_RC(launch_cert_margin(g->qstat, g->gstat, D, Q, g->marg, g->dropflag, st));
+        return 0;
+    };
 
     if (N >= SEARCH_SMALL_ROWS) {
         // ---- 256 x 256 scan.  Pre-pass: a plain GEMM of the queries against the first n_pre rows and a
@@ -937,13 +942,13 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
         uint64_t* final_lists = (uint64_t*)(wsb + fin_off);
         float* pre_scores = (float*)(wsb + sco_off);
         uint32_t* tau_base = g->tau0, *tau_live = g->tau0 + g->q_cap;
+        CHECK_RC(prep(hist, (long)(hist_bytes / 4)));
         {
             ProfScope ps("topk_prepass", st);
             GemmArgs ga{};
             ga.A = g->qb; ga.lda = D; ga.B = g->gb; ga.ldb = D; ga.M = Q; ga.N = (int)n_pre; ga.K = D;
             ga.C = pre_scores; ga.ldc = n_pre; ga.prefer256 = 1;
             CHECK_RC(launch_gemm(EPI_F32, ga, st));
-            REVO_HIP_CHECK(hipMemsetAsync(hist, 0, hist_bytes, st));
             // One shard of a larger gallery, in the two-phase search: what its candidates have to reach is decided by ALL
             // shards' rows (the finish step re-scores only candidates among the best min(64, 2 ksel) of the whole gallery),
             // but its scan can only learn its own rows' scores -- at an eighth of the rows its admission bound sits at an
@@ -987,6 +992,7 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
         // ---- small galleries: 128 x 128 scan with per-wave LDS lists
         const int splits = topk_scan_workspace_splits(Q, N);
         CHECK_RC(need_part((size_t)Q * splits * ksel * 8));
+        CHECK_RC(prep(nullptr, 0));
         ScanArgs a{};
         a.Qb = g->qb; a.ldq = D; a.Gb = g->gb; a.ldg = D; a.Q = Q; a.N = N; a.D = D; a.ksel = ksel;
         a.splits = splits; a.part = g->part;

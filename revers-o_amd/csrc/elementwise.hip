@@ -399,7 +399,11 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
                                                           float* __restrict__ dst_f32, long ld_f32,
                                                           bf16_t* __restrict__ dst_bf16, long ld_bf16, long rows,
                                                           int D, int normalize, float* __restrict__ row_stats,
-                                                          uint32_t* __restrict__ max_stats) {
+                                                          uint32_t* __restrict__ max_stats, uint32_t* __restrict__ zero_a,
+                                                          long zero_a_words, uint32_t* __restrict__ zero_b, long zero_b_words) {
+    // (a search's first kernel also clears the counters and histograms its later kernels add to: two launches fewer)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_a_words; i += (long)gridDim.x * 256) zero_a[i] = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_b_words; i += (long)gridDim.x * 256) zero_b[i] = 0;
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -432,10 +436,12 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     }
 }
 int launch_l2norm_rows(const float* src, long ld_src, float* dst_f32, long ld_f32, bf16_t* dst_bf16, long ld_bf16,
-                       long rows, int D, hipStream_t st, int normalize, float* row_stats, uint32_t* max_stats) {
+                       long rows, int D, hipStream_t st, int normalize, float* row_stats, uint32_t* max_stats,
+                       uint32_t* zero_a, long zero_a_words, uint32_t* zero_b, long zero_b_words) {
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, src, ld_src, dst_f32,
-                       ld_f32, dst_bf16, ld_bf16, rows, D, normalize, row_stats, max_stats);
+                       ld_f32, dst_bf16, ld_bf16, rows, D, normalize, row_stats, max_stats, zero_a, zero_a_words, zero_b,
+                       zero_b_words);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

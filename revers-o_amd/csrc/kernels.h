@@ -103,9 +103,12 @@ int launch_f32_to_bf16(const float* src, long ld_src, bf16_t* dst, long ld_dst, 
 // normalize = 0: rows copied unscaled.  row_stats [rows][2] (optional): (||bf16(y) - y||, ||bf16(y)||) per output row;
 // max_stats [2] (optional): running maxima (fp32 bit patterns) of ||y|| and ||bf16(y) - y||  -- inputs of the search's
 // exactness certificate
+// zero_a / zero_b (optional): two word arrays the kernel also clears (a search's counters and histograms: its first kernel
+// does what two memset launches did)
 int launch_l2norm_rows(const float* src, long ld_src, float* dst_f32, long ld_f32, bf16_t* dst_bf16, long ld_bf16,
                        long rows, int D, hipStream_t st, int normalize = 1, float* row_stats = nullptr,
-                       uint32_t* max_stats = nullptr);
+                       uint32_t* max_stats = nullptr, uint32_t* zero_a = nullptr, long zero_a_words = 0,
+                       uint32_t* zero_b = nullptr, long zero_b_words = 0);
 
 // ----------------------------------------------------------- attention -----
 // qkv [B*S][ld] bf16 (q | k | v thirds, heads contiguous inside a third) -> out [B*S][ldo] bf16
