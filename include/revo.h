@@ -189,9 +189,13 @@ int32_t revo_op_gemm_rope(const void* a_bf16, int64_t lda, const void* b_bf16, i
  *    256-column slice of the new row;
  *  - revo_op_gemm_ln_in: C bf16 = epilogue(rstd * (A . B^T - mean * csum) + bias), epilogue 0 = plain, 1 = exact-erf GELU, the
  *    row's mean and rstd = 1 / sqrt(var + eps) merged from `parts` slices of `stats` as written above. */
+/*    With xlo (bf16 [m][ldxb]) the residual stream itself may be in two bf16 planes (xb_bf16, xlo) = (bf16(x), bf16(x - bf16(x))),
+ *    as the forward keeps it between folded GEMMs: x_in_planes != 0 takes the old values from there instead of c, planes_out
+ *    != 0 writes the new ones there instead of to c (needs a folding form, else status -2); stats may be NULL for planes in,
+ *    fp32 out (the last residual GEMM of a forward). */
 int32_t revo_op_gemm_resid_ln(const void* a_bf16, int64_t lda, const void* b_bf16, int64_t ldb, int32_t m, int32_t n, int32_t k,
                               float* c, int64_t ldc, const float* bias, const float* gamma, void* xb_bf16, int64_t ldxb,
-                              void* stats, int32_t* done, void* stream);
+                              void* stats, int32_t* done, void* xlo_bf16, int32_t x_in_planes, int32_t planes_out, void* stream);
 int32_t revo_op_gemm_ln_in(int32_t epilogue, const void* a_bf16, int64_t lda, const void* b_bf16, int64_t ldb, int32_t m, int32_t n,
                            int32_t k, void* c_bf16, int64_t ldc, const float* bias, const float* csum, const void* stats,
                            int32_t parts, float eps, void* stream);
@@ -230,12 +234,15 @@ int32_t revo_op_set_gemm_tile(int32_t tile);
  * 0 = normal */
 int32_t revo_op_set_variant(int32_t flags);
 /* 0 = ln_1 / ln_2 as LayerNorm kernels in front of their GEMMs instead of the folded form (A/B timing, parity of one
- * against the other); 1 = default */
+ * against the other); 1 = default (folded, the residual stream in two bf16 planes between the folded GEMMs); 2 = folded
+ * with the stream as fp32 rows plus a bf16 copy */
 int32_t revo_op_set_ln_fold(int32_t on);
 /* Timing experiments.  The variant bits above plus: bit 0 = skip the GEMM epilogue stores, bit 1 = skip the GEMM main loop,
  * bit 13 = skip the scan's selection, bit 15 = skip the scan's slow path (all four: WRONG RESULTS),
  * bit 14 = count scan events for revo_debug_scan_stats. */
 int32_t revo_op_set_gemm_debug(int32_t flags);
+/* 1 if a forward of `batch` images keeps the residual stream in two bf16 planes between its folded GEMMs (reporting) */
+int32_t revo_debug_stream_in_planes(const revo_vit* vit, int32_t batch);
 /* copies bytes of the handle's search workspace to host_dst (host_dst NULL: returns the workspace size) */
 int64_t revo_debug_read_workspace(revo_gallery* g, int64_t offset, int64_t bytes, void* host_dst);
 /* experiment: bounds = device array [Q] of order-preserving u32 scan scores (the format revo_search_candidates publishes)

@@ -60,7 +60,8 @@ SIGNATURES = {
     "revo_topk_packed_bytes": (_i64, [_i32, _i32]),
     "revo_topk_merge_packed": (_i32, [_p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p, _p, _p, _p]),
     "revo_op_gemm": (_i32, [_i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p]),
-    "revo_op_gemm_resid_ln": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p, C.POINTER(C.c_int32), _p]),
+    "revo_op_gemm_resid_ln": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p, C.POINTER(C.c_int32), _p, _i32,
+                                     _i32, _p]),
     "revo_op_gemm_ln_in": (_i32, [_i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _f32, _p]),
     "revo_op_gemm_rope": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
     "revo_op_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i64, _i32, _p]),
@@ -88,6 +89,7 @@ EXPERIMENT_SIGNATURES = {
     "revo_debug_scan_stats": (_i32, [C.POINTER(C.c_int64)]),
     "revo_debug_seed_bounds": (_i32, [_p, _p]),
     "revo_debug_read_workspace": (_i64, [_p, _i64, _i64, _p]),
+    "revo_debug_stream_in_planes": (_i32, [_p, _i32]),
 }
 BASE_SIGNATURES = dict(SIGNATURES)
 if os.environ.get("REVO_LIBRARY_PATH"):            # bisecting / A-B runs of another build of the same ABI

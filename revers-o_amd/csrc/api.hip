@@ -188,6 +188,7 @@ struct revo_vit {
     float2* rope_cs = nullptr;
     // workspace
     bf16_t *patches = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
+    bf16_t* xlo = nullptr;             // low plane of the residual stream while it is kept as (h, xlo) = (bf16(x), bf16(x - hi))
     float *x = nullptr, *pool_logits = nullptr, *pool_u = nullptr, *pool_att = nullptr, *pool_o = nullptr, *pool_h = nullptr,
           *pool_m = nullptr, *feat = nullptr;
     float* splitk_ws = nullptr;        // fp32 partial planes of the split-K residual GEMMs
@@ -274,7 +275,7 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
     std::unique_ptr<revo_vit> v(new revo_vit());
     v->cfg = c; v->device = device; v->max_batch = max_batch;
 #ifdef REVO_EXPERIMENTS
-    if (const char* e = getenv("REVO_LN_FOLD")) revo::gemm_set_ln_fold(atoi(e) ? 1 : 0);     // A/B runs of bench.py (scripts/)
+    if (const char* e = getenv("REVO_LN_FOLD")) revo::gemm_set_ln_fold(atoi(e));     // A/B runs of bench.py (scripts/): 0, 1 or 2
 #endif
     const int W = c.width, M = c.mlp_dim, D = c.out_dim, P = c.patch_size, G = c.image_size / P;
     v->G2 = G * G; v->S = v->G2 + (c.use_cls ? 1 : 0);
@@ -449,6 +450,7 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
     CHECK_RC(v->dalloc(&v->splitk_ws, SPLITK_WS_ELEMS));
     v->ln_parts = (W % 256 == 0 && W / 256 <= 6) ? W / 256 : 0;
     if (v->ln_parts) CHECK_RC(v->dalloc(&v->ln_stats, rows * (size_t)v->ln_parts));
+    if (v->ln_parts) CHECK_RC(v->dalloc(&v->xlo, rows * W));
     REVO_HIP_CHECK(hipDeviceSynchronize());
     *out = v.release();
     return 0;
@@ -499,7 +501,8 @@ namespace {
 // launch form can do: *fused = 1: `out` holds the normalised rows (one-image forms: the split-K reduce does it);
 // *folded = 1: `out` holds bf16(x) and `stats` the rows' partial statistics (folded form, kernels.h GemmArgs::lnf_*);
 // neither: the caller runs the LayerNorm kernel.
-struct LnAfter { float eps; bf16_t* out; long ldo; int* fused; float2* stats; int* folded; };
+// planes: keep the residual stream as (out, lo) = (bf16(x), bf16(x - bf16(x))) from here on (kernels.h GemmArgs::xp_*)
+struct LnAfter { float eps; bf16_t* out; long ldo; int* fused; float2* stats; int* folded; bf16_t* lo; int x_in_planes, planes_out; };
 // consumer side of the folded form: A = bf16(x), the epilogue applies rstd (acc - mean c) + bias
 struct LnBefore { const float2* stats; int parts; const float* c; float eps; };
 int gemm(const char* cls, int epi, const bf16_t* A, long lda, const bf16_t* B, long ldb, int M, int N, int K, void* C,
@@ -509,8 +512,10 @@ int gemm(const char* cls, int epi, const bf16_t* A, long lda, const bf16_t* B, l
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
     a.bias = bias; a.gamma = gamma; a.ws = ws; a.ws_elems = ws_elems;
     if (ln) {
-        a.ln_eps = ln->eps; a.ln_out = ln->out; a.ln_ldo = ln->ldo; a.ln_fused = ln->fused;
+        a.ln_eps = ln->eps; a.ln_ldo = ln->ldo; a.ln_fused = ln->fused;
+        if (ln->fused) a.ln_out = ln->out;
         if (ln->stats) { a.lnf_xb = ln->out; a.lnf_ldxb = ln->ldo; a.lnf_stats = ln->stats; a.lnf_done = ln->folded; }
+        if (ln->lo) { a.xp_hi = ln->out; a.xp_lo = ln->lo; a.xp_ld = ln->ldo; a.xp_in = ln->x_in_planes; a.xp_out = ln->planes_out; }
     }
     ProfScope ps(cls, st);
     return revo::launch_gemm(epi, a, st);
@@ -583,11 +588,19 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
     enum { H_NONE = 0, H_NORM = 1, H_XB = 2 };
     int h_state = H_NONE;
     float2* stats = vv->ln_parts ? vv->ln_stats + r0 * vv->ln_parts : nullptr;
+    // Between folded residual GEMMs the stream itself lives in two bf16 planes, (h, xlo) = (bf16(x), bf16(x - bf16(x))):
+    // the high plane IS the next GEMM's A operand, so the residual epilogues move 4 + 4 bytes per element instead of fp32
+    // rows plus a bf16 copy (4 + 4 + 2).  Entered by the first folding out-proj (fp32 in, planes out), left by the last
+    // fc2 (planes in, fp32 out: ln_post and the head read fp32); only when both residual GEMMs of a block fold.
+    bf16_t* xlo = (vv->xlo && gemm_ln_planes_enabled() && gemm_resid_folds(rows, W, W, W, W, W) && gemm_resid_folds(rows, W, Md, Md, Md, W))
+                      ? vv->xlo + r0 * W : nullptr;
+    bool x_planes = false;
     auto ln_before = [&](const float* csum, GemmArgs& a) {
         if (h_state == H_XB) { a.lnc_stats = stats; a.lnc_parts = vv->ln_parts; a.lnc_c = csum; a.lnc_eps = c.ln_eps; }
     };
     auto normalise_if_needed = [&]() -> int {
         if (h_state != H_NONE) return 0;
+        if (x_planes) { revo_set_error("vit_forward: internal: a LayerNorm kernel was asked for while the stream is in planes"); return -3; }
         ProfScope ps("layernorm", st);
         CHECK_RC(launch_layernorm(v->x, W, nullptr, nullptr, c.ln_eps, rows, W, v->h, W, 1, st));
         h_state = H_NORM;
@@ -609,10 +622,11 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
         { ProfScope ps("attention", st);
           CHECK_RC(launch_attention_ex(v->qkv, 3 * W, v->att, W, B, S, c.heads, v->hd, c.use_cls, st)); }
         int fused = 0, folded = 0;
-        const LnAfter ln2{c.ln_eps, v->h, W, &fused, stats, &folded};
+        const LnAfter ln2{c.ln_eps, v->h, W, &fused, stats, &folded, xlo, x_planes ? 1 : 0, xlo ? 1 : 0};
         CHECK_RC(gemm("gemm_out", EPI_RESID_F32, v->att, W, L.w_o, W, rows, W, W, v->x, W, L.b_o, L.ls1, st, vv->splitk_ws,
                       (long)SPLITK_WS_ELEMS, &ln2));
         h_state = folded ? H_XB : (fused ? H_NORM : H_NONE);
+        x_planes = xlo && folded;
 #ifdef REVO_EXPERIMENTS
         // cache-state experiment: re-touch bf16(x) (a device copy into the dead qkv buffer) before the GEMM that streams it
         if (folded && getenv("REVO_LNFOLD_TOUCH")) {
@@ -631,12 +645,16 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
         }
         // (splitk_ws: scratch for the split-K forms of fc2 -- leftover rows at large batch, the whole GEMM at small batch)
         fused = 0; folded = 0;
-        const LnAfter ln1n{c.ln_eps, v->h, W, &fused, stats, &folded};
+        const bool last = i + 1 >= nl;
+        // the last fc2 has no LayerNorm of the body behind it: it brings the stream back to fp32 rows (ln_post, the taps)
+        const LnAfter ln1n{c.ln_eps, v->h, W, last ? nullptr : &fused, last ? nullptr : stats, last ? nullptr : &folded, xlo,
+                           x_planes ? 1 : 0, (xlo && !last) ? 1 : 0};
         CHECK_RC(gemm("gemm_fc2", EPI_RESID_F32, v->mlp, Md, L.w_fc2, Md, rows, W, Md, v->x, W, L.b_fc2, L.ls2, st,
-                      vv->splitk_ws, (long)SPLITK_WS_ELEMS, i + 1 < nl ? &ln1n : nullptr));
-        h_state = (i + 1 < nl) ? (folded ? H_XB : (fused ? H_NORM : H_NONE)) : H_NONE;
+                      vv->splitk_ws, (long)SPLITK_WS_ELEMS, (!last || x_planes) ? &ln1n : nullptr));
+        h_state = last ? H_NONE : (folded ? H_XB : (fused ? H_NORM : H_NONE));
+        x_planes = !last && xlo && folded;
 #ifdef REVO_EXPERIMENTS
-        if (folded && i + 1 < nl && getenv("REVO_LNFOLD_TOUCH")) {
+        if (folded && !last && getenv("REVO_LNFOLD_TOUCH")) {
             ProfScope ps("touch", st);
             REVO_HIP_CHECK(hipMemcpyAsync(v->qkv, v->h, (size_t)rows * W * 2, hipMemcpyDeviceToDevice, st));
         }
@@ -1232,9 +1250,12 @@ extern "C" int32_t revo_op_gemm(int32_t epi, const void* a, int64_t lda, const v
 // The two halves of a LayerNorm folded into the GEMMs around it (kernels.h GemmArgs::lnf_* / lnc_*), one kernel each
 extern "C" int32_t revo_op_gemm_resid_ln(const void* a, int64_t lda, const void* b, int64_t ldb, int32_t m, int32_t n, int32_t k,
                                          float* c, int64_t ldc, const float* bias, const float* gamma, void* xb, int64_t ldxb,
-                                         void* stats, int32_t* done, void* stream) {
+                                         void* stats, int32_t* done, void* xlo, int32_t x_in_planes, int32_t planes_out,
+                                         void* stream) {
     API_BEGIN
-    REVO_REQUIRE(a && b && c && xb && stats && done, "op_gemm_resid_ln: null argument");
+    REVO_REQUIRE(a && b && c && xb && done, "op_gemm_resid_ln: null argument");
+    REVO_REQUIRE(stats || (xlo && x_in_planes && !planes_out), "op_gemm_resid_ln: stats may be NULL only for planes in, fp32 out");
+    REVO_REQUIRE(xlo || (!x_in_planes && !planes_out), "op_gemm_resid_ln: planes need the low plane");
     constexpr long OP_WS_ELEMS = 16l << 20;
     hipStream_t st = (hipStream_t)stream;
     float* ws = nullptr;
@@ -1243,7 +1264,8 @@ extern "C" int32_t revo_op_gemm_resid_ln(const void* a, int64_t lda, const void*
     g.A = (const bf16_t*)a; g.lda = lda; g.B = (const bf16_t*)b; g.ldb = ldb; g.M = m; g.N = n; g.K = k; g.C = c; g.ldc = ldc;
     g.bias = bias; g.gamma = gamma; g.ws = ws; g.ws_elems = OP_WS_ELEMS;
     int flag = 0;
-    g.lnf_xb = (bf16_t*)xb; g.lnf_ldxb = ldxb; g.lnf_stats = (float2*)stats; g.lnf_done = &flag;
+    if (stats) { g.lnf_xb = (bf16_t*)xb; g.lnf_ldxb = ldxb; g.lnf_stats = (float2*)stats; g.lnf_done = &flag; }
+    if (xlo) { g.xp_hi = (bf16_t*)xb; g.xp_lo = (bf16_t*)xlo; g.xp_ld = ldxb; g.xp_in = x_in_planes != 0; g.xp_out = planes_out != 0; }
     const int rc = revo::launch_gemm(revo::EPI_RESID_F32, g, st);
     REVO_HIP_CHECK(hipFreeAsync(ws, st));
     *done = flag;
@@ -1287,7 +1309,8 @@ extern "C" int32_t revo_op_set_variant(int32_t flags) {
 }
 // 0: every ln_1 / ln_2 runs as its own LayerNorm kernel (A/B timing and parity of the folded form against it); 1: default
 extern "C" int32_t revo_op_set_ln_fold(int32_t on) {
-    revo::gemm_set_ln_fold(on ? 1 : 0);
+    REVO_REQUIRE(on >= 0 && on <= 2, "set_ln_fold: 0 (LayerNorm kernels), 1 (folded, stream in planes: default) or 2 (folded, fp32 stream + bf16 copy)");
+    revo::gemm_set_ln_fold(on);
     return 0;
 }
 // phase groups of the persistent 256 x 256 GEMM (gemm.hip gemm256pp_kernel): 0 = the launcher's choice, 1 = off, 2..4 forced
@@ -1313,6 +1336,12 @@ extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
     revo::gemm_set_stagger(((flags >> 28) & 15) * 200, 2 + ((flags >> 2) & 3));   // bits 28-31: stagger in 2 us steps (100 MHz clock), bits 2-3: groups - 2
     revo::topk_scan256_set_debug(((flags >> 13) & 7) | (((flags >> 20) & 255) << 3));
     return revo_op_set_variant(flags);
+}
+// whether the forward keeps the residual stream in planes for this many rows of this tower (reporting / tests)
+extern "C" int32_t revo_debug_stream_in_planes(const revo_vit* v, int32_t batch) {
+    if (!v || !v->xlo) return 0;
+    const int W = v->cfg.width, Md = v->cfg.mlp_dim, rows = batch * v->S;
+    return revo::gemm_ln_planes_enabled() && revo::gemm_resid_folds(rows, W, W, W, W, W) && revo::gemm_resid_folds(rows, W, Md, Md, Md, W);
 }
 // copy bytes [offset, offset + bytes) of the handle's search workspace to the host (debugging the scan's buffers)
 extern "C" int64_t revo_debug_read_workspace(revo_gallery* g, int64_t offset, int64_t bytes, void* host_dst) {

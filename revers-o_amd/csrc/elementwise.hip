@@ -224,6 +224,34 @@ int launch_fold_ln_linear(const float* w, const float* gamma, const float* beta,
     return 0;
 }
 
+// residual stream in two bf16 planes (kernels.h GemmArgs::xp_*) -> fp32 rows: x = hi + lo
+__global__ __launch_bounds__(256) void planes_to_f32_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo, long ldp,
+                                                            float* __restrict__ x, long ldx, long rows, int W) {
+    const int chunks = W >> 3;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= rows * chunks) return;
+    const long r = gid / chunks;
+    const int c = (int)(gid - r * chunks) * 8;
+    const uint4 a = *(const uint4*)(hi + r * ldp + c), b = *(const uint4*)(lo + r * ldp + c);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[2 * j] = __uint_as_float(aw[j] << 16) + __uint_as_float(bw[j] << 16);
+        v[2 * j + 1] = __uint_as_float(aw[j] & 0xffff0000u) + __uint_as_float(bw[j] & 0xffff0000u);
+    }
+    *(f32x4*)(x + r * ldx + c) = (f32x4){v[0], v[1], v[2], v[3]};
+    *(f32x4*)(x + r * ldx + c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+}
+int launch_planes_to_f32(const bf16_t* hi, const bf16_t* lo, long ldp, float* x, long ldx, long rows, int W, hipStream_t st) {
+    REVO_REQUIRE(W % 8 == 0 && ldp % 8 == 0 && ldx % 4 == 0, "planes_to_f32: widths must be multiples of 8");
+    const long total = rows * (W / 8);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(planes_to_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, hi, lo, ldp, x, ldx, rows, W);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------- patchify ----
 // im2col for the SPLIT-PRECISION patch GEMM (api.hip): the row of a patch holds PARTS copies / parts of its Kp values.
 //   u8 images   (PARTS = 2): ( a | a ),            a = 2 v - 255: an odd integer of at most 8 bits, EXACT in bf16

@@ -272,6 +272,101 @@ __device__ __forceinline__ void gemm256_epilogue_f32_quarter(const GemmArgs& p, 
 // residual add after it (on the coalesced rows).
 // SKIP_DEAD (192-row tiles): a wave whose second 64 rows lie past p.M (the caller passes the tile's row limit as p.M)
 // skips them altogether instead of masking their stores.
+// ---- the same residual epilogue with 8 columns per lane and the stream optionally in two bf16 planes (kernels.h xp_*)
+// res[it][2]: the old values of step `it` (8 rows per step, 8 lanes per row): 8 fp32, or 8 bf16 hi + 8 bf16 lo
+template <int QT>
+__device__ __forceinline__ void gemm256_resid8_load(const GemmArgs& p, int m_base, int n_base, int lane, uint4 (&res)[4][2]) {
+    typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+    int gcol = n_base + (lane & 7) * 8;
+    gcol = gcol < p.N ? gcol : p.N - 8;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        int grow = m_base + QT * 32 + it * 8 + (lane >> 3);
+        grow = grow < p.M ? grow : p.M - 1;
+        const nt_u32x4 *s0, *s1;
+        if (p.xp_in) {
+            s0 = (const nt_u32x4*)(p.xp_hi + (long)grow * p.xp_ld + gcol);
+            s1 = (const nt_u32x4*)(p.xp_lo + (long)grow * p.xp_ld + gcol);
+        } else {
+            s0 = (const nt_u32x4*)((const float*)p.C + (long)grow * p.ldc + gcol);
+            s1 = s0 + 1;
+        }
+        res[it][0] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(s0));
+        res[it][1] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(s1));
+    }
+}
+__device__ __forceinline__ float row8_sum(float v) {      // over the 8 lanes that share a row here (half a DPP row)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    return v;
+}
+template <int QT>
+__device__ __forceinline__ void gemm256_resid8_quarter(const GemmArgs& p, char* slab, int m_base, int n_base, int lane,
+                                                       f32x4 (&acc)[8][4], const f32x4 (&bias4)[4], const f32x4 (&gamma4)[4],
+                                                       const uint4 (&res)[4][2], float2* lnst) {
+    constexpr int RS = 272;
+    typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+    asm volatile("" : "+v"(lane) :: "memory");
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const f32x4 v = (acc[QT * 2 + m][n] + bias4[n]) * gamma4[n];
+            *(f32x4*)(slab + (m * 16 + lr) * RS + (n * 16 + lq * 4) * 4) = v;
+        }
+    const int gcol = n_base + (lane & 7) * 8;
+    float keep_m = 0.f, keep_q = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int rl = it * 8 + (lane >> 3);
+        const f32x4 v0 = *(const f32x4*)(slab + rl * RS + (lane & 7) * 32), v1 = *(const f32x4*)(slab + rl * RS + (lane & 7) * 32 + 16);
+        float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const uint32_t a[4] = {res[it][0].x, res[it][0].y, res[it][0].z, res[it][0].w};
+        const uint32_t b[4] = {res[it][1].x, res[it][1].y, res[it][1].z, res[it][1].w};
+        if (p.xp_in) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {      // old value = hi + lo (exact in fp32)
+                x[2 * j] += __uint_as_float(a[j] << 16) + __uint_as_float(b[j] << 16);
+                x[2 * j + 1] += __uint_as_float(a[j] & 0xffff0000u) + __uint_as_float(b[j] & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x[j] += __uint_as_float(a[j]); x[4 + j] += __uint_as_float(b[j]); }
+        }
+        const int grow = m_base + QT * 32 + rl;
+        if (grow < p.M && gcol < p.N) {
+            uint32_t hi[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hi[j] = pack_bf16x2(x[2 * j], x[2 * j + 1]);
+            if (p.xp_out) {
+                uint32_t lo[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    lo[j] = pack_bf16x2(x[2 * j] - __uint_as_float(hi[j] << 16), x[2 * j + 1] - __uint_as_float(hi[j] & 0xffff0000u));
+                *(uint4*)(p.xp_hi + (long)grow * p.xp_ld + gcol) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                __builtin_nontemporal_store((nt_u32x4){lo[0], lo[1], lo[2], lo[3]}, (nt_u32x4*)(p.xp_lo + (long)grow * p.xp_ld + gcol));
+            } else {
+                float* dst = (float*)p.C + (long)grow * p.ldc + gcol;
+                __builtin_nontemporal_store((f32x4){x[0], x[1], x[2], x[3]}, (f32x4*)dst);
+                __builtin_nontemporal_store((f32x4){x[4], x[5], x[6], x[7]}, (f32x4*)(dst + 4));
+                if (lnst) *(uint4*)(p.lnf_xb + (long)grow * p.lnf_ldxb + gcol) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            }
+        }
+        if (lnst) {           // wave-uniform: two-pass statistics of the row's 64 columns held by its 8 lanes
+            const float mean = row8_sum(((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) * (1.0f / 64.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = x[j] - mean; q = fmaf(d, d, q); }
+            q = row8_sum(q);
+            if ((lane & 7) == it) { keep_m = mean; keep_q = q; }       // lane (it, row) keeps row it * 8 + (lane >> 3)
+        }
+    }
+    if (lnst && (lane & 7) < 4) lnst[(QT * 32 + (lane & 7) * 8 + (lane >> 3)) * 4] = make_float2(keep_m, keep_q);
+    asm volatile("" ::: "memory");
+}
+
 // lnst: gemm256_epilogue_f32_quarter (producer side of a folded LayerNorm).  lnmr (consumer side, bf16 epilogues; LDS):
 // (rstd, -mean rstd) of the tile's 256 rows, indexed from the wave's first row.
 template <int EPI, bool SKIP_DEAD = false>
@@ -402,8 +497,22 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
         // load result that is needed while stores are in flight costs a full drain of both: prefetching a quarter
         // "one ahead" between the stores of the previous ones made every use such a drain.  Two batches of loads,
         // each issued when no load result is outstanding, leave two drains per tile.
-        f32x4 ra[8], rb[8];
         if (SKIP_DEAD && m_base >= p.M) return;                         // wave-uniform: a short piece's second wave-row
+        if (EPI == EPI_RESID_F32 && (p.xp_in || p.xp_out)) {
+            // the stream in (or going into / coming out of) two bf16 planes: 8 columns per lane
+            uint4 pa[4][2], pb[4][2];
+            gemm256_resid8_load<0>(p, m_base, n_base, lane, pa);
+            gemm256_resid8_load<1>(p, m_base, n_base, lane, pb);
+            gemm256_resid8_quarter<0>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, pa, lnst);
+            gemm256_resid8_quarter<1>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, pb, lnst);
+            if (SKIP_DEAD && m_base + 64 >= p.M) return;                // wave-uniform
+            gemm256_resid8_load<2>(p, m_base, n_base, lane, pa);
+            gemm256_resid8_load<3>(p, m_base, n_base, lane, pb);
+            gemm256_resid8_quarter<2>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, pa, lnst);
+            gemm256_resid8_quarter<3>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, pb, lnst);
+            return;
+        }
+        f32x4 ra[8], rb[8];
         const bool nt = lnst != nullptr;
         if (EPI == EPI_RESID_F32) gemm256_load_resid<0>(p, m_base, n_base, lane, ra, nt);
         if (EPI == EPI_RESID_F32) gemm256_load_resid<1>(p, m_base, n_base, lane, rb, nt);
@@ -1250,7 +1359,36 @@ static int launch_skinny(const GemmArgs& a, hipStream_t st) {
 }
 
 static int g_lnf = 1;          // timing experiments only: 0 = never fold a LayerNorm into the residual GEMMs (the caller runs the kernel)
-void gemm_set_ln_fold(int on) { g_lnf = on; }
+static int g_ln_planes = 1;    // ... 0 = folded, but the residual stream stays fp32 rows (+ a bf16 copy)
+void gemm_set_ln_fold(int on) { g_lnf = on != 0; g_ln_planes = on != 2; }
+bool gemm_ln_planes_enabled() { return g_lnf && g_ln_planes; }
+// Which launch form launch_t<EPI_RESID_F32> takes for this problem, as far as the folded LayerNorm is concerned: 1 = whole
+// rounds of 192-row tiles, 2 = whole rounds of 256-row tiles on the persistent kernel (both cover ALL rows with the
+// row-coalesced epilogue: they can write bf16(x) + row statistics and keep the stream in planes), 0 = any other form.
+static int resid_fold_form(const GemmArgs& a, int* t192 = nullptr, int* tall = nullptr) {
+    if (!g_lnf || g_force_tile || a.N % LNF_SLICE || a.N / LNF_SLICE > 6 || (a.ldc & 7)) return 0;
+    if (a.prefer256 || 256l * a.lda * 2 >= (1l << 31) || 256l * a.ldb * 2 >= (1l << 31)) return 0;
+    const long tm = (a.M + 255) / 256, tn = (a.N + 255) / 256, tiles = tm * tn;
+    if (a.M > 64 && a.K >= 1024 && tiles <= 96) return 0;              // the split-K forms of small batches
+    if (use_skinny(a) || !use_256(a)) return 0;
+    int tl = 0;
+    if (const int t = plan_rows192(a, true, &tl)) {
+        if (t192) *t192 = t;
+        if (tall) *tall = tl;
+        return 1;
+    }
+    const long full = tiles / 256 * 256, rem = tiles - full;
+    if (g_tail_split && full > 0 && rem > 0 && rem <= 160) {
+        const long m_tiles_main = full / tn;
+        if (m_tiles_main >= 1 && m_tiles_main < tm) return 0;           // main rows + leftover rows: two launches
+    }
+    return (g_persistent && a.K >= 128 && tiles > 256) ? 2 : 0;
+}
+bool gemm_resid_folds(int M, int N, int K, long lda, long ldb, long ldc) {
+    GemmArgs a{};
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    return resid_fold_form(a) != 0;
+}
 template <int EPI>
 static int launch_t(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
@@ -1258,10 +1396,38 @@ static int launch_t(const GemmArgs& a_in, hipStream_t st) {
     // persistent 256-row kernel's row-coalesced epilogue write bf16(x) and the row statistics; every other form leaves
     // *lnf_done alone and the caller runs the LayerNorm kernel.
     const bool lnf_ok = EPI == EPI_RESID_F32 && g_lnf && a.lnf_stats && a.lnf_xb && a.lnf_done && a.N % LNF_SLICE == 0 &&
-                        a.N / LNF_SLICE <= 6 && (a.ldc & 7) == 0 && a.lnf_ldxb % 4 == 0 && g_force_tile == 0;
+                        a.N / LNF_SLICE <= 6 && (a.ldc & 7) == 0 && a.lnf_ldxb % 8 == 0 && g_force_tile == 0;
     bf16_t* const lnf_xb = a.lnf_xb;
     float2* const lnf_stats = a.lnf_stats;
     a.lnf_xb = nullptr; a.lnf_stats = nullptr;
+    if constexpr (EPI == EPI_RESID_F32) {
+        // the residual stream in planes (kernels.h xp_*): only the two whole-rows forms read / write them
+        const bool planes = a.xp_in || a.xp_out;
+        if (planes || lnf_ok) {
+            int t192 = 0, tall = 0;
+            const int form = resid_fold_form(a, &t192, &tall);
+            if (planes && (!form || !a.xp_hi || !a.xp_lo || a.xp_ld % 8 || (a.xp_out && (!lnf_ok || a.xp_hi != lnf_xb)))) {
+                revo_set_error("gemm: the residual stream in planes needs a launch form that folds (gemm_resid_folds) and, for xp_out, "
+                               "the folded LayerNorm's outputs with xp_hi == lnf_xb");
+                return -2;
+            }
+            if (form) {
+                GemmArgs a1 = a;
+                a1.ln_out = nullptr;
+                if (lnf_ok) { a1.lnf_xb = lnf_xb; a1.lnf_stats = lnf_stats; }
+                int rc;
+                if (form == 1) {
+                    a1.t192_tiles = t192; a1.t192_tall = tall;
+                    rc = launch_256p<EPI, 192>(a1, st);
+                } else {
+                    rc = launch_256p<EPI>(a1, st);
+                }
+                if (rc == 0 && lnf_ok) *a.lnf_done = 1;
+                return rc;
+            }
+        }
+    }
+    a.xp_in = a.xp_out = 0;
     if (a.prefer256 && g_force_tile == 0 && 256l * a.lda * 2 < (1l << 31) && 256l * a.ldb * 2 < (1l << 31))
         return launch_256<EPI>(a, st);
     if constexpr (EPI == EPI_RESID_F32) {
@@ -1288,10 +1454,7 @@ static int launch_t(const GemmArgs& a_in, hipStream_t st) {
                 GemmArgs a1 = a;
                 a1.ln_out = nullptr;
                 a1.t192_tiles = t192; a1.t192_tall = tall;
-                if (lnf_ok) { a1.lnf_xb = lnf_xb; a1.lnf_stats = lnf_stats; }
-                const int rc = launch_256p<EPI, 192>(a1, st);
-                if (rc == 0 && lnf_ok) *a.lnf_done = 1;
-                return rc;
+                return launch_256p<EPI, 192>(a1, st);
             }
         }
         const long tm = (a.M + 255) / 256, tn = (a.N + 255) / 256;
@@ -1318,16 +1481,6 @@ static int launch_t(const GemmArgs& a_in, hipStream_t st) {
                     if (rc2 == 1) return 0;
                 }
                 return launch_128<EPI>(a2, st);
-            }
-        }
-        if constexpr (EPI == EPI_RESID_F32) {
-            // whole rounds of 256-row tiles on the persistent kernel: all rows in one launch
-            if (lnf_ok && g_persistent && a.K >= 128 && tiles > 256) {
-                GemmArgs a1 = a;
-                a1.lnf_xb = lnf_xb; a1.lnf_stats = lnf_stats;
-                const int rc = launch_256p<EPI>(a1, st);
-                if (rc == 0) *a.lnf_done = 1;
-                return rc;
             }
         }
         return launch_256<EPI>(a, st);

@@ -47,6 +47,13 @@ struct GemmArgs {
     //  * consumer (EPI_BF16 / _GELU / _ROPE): lnc_stats ([M][lnc_parts] as written above; the normalised width is
     //    256 * lnc_parts), lnc_c ([N] column sums of the rounded weights), lnc_eps; `bias` is b'.
     bf16_t* lnf_xb; long lnf_ldxb; float2* lnf_stats; int* lnf_done;
+    // Residual stream as two bf16 planes (EPI_RESID_F32, the two whole-rows persistent forms only):
+    // between the folded residual GEMMs of one forward the stream is kept as hi = bf16(x), lo = bf16(x - hi) -- x to 2^-17
+    // instead of 2^-24, still 256 times finer than the bf16 GEMM operands -- because hi IS the next GEMM's A operand: the
+    // epilogue moves 4 + 4 bytes per element where fp32 rows plus their bf16 copy were 4 + 4 + 2.  xp_in: the old
+    // values come from (xp_hi, xp_lo) instead of C; xp_out: the new values go there instead of to C (C is then stale;
+    // xp_hi must be lnf_xb).  *lnf_done = 1 also says that xp_out was honoured.
+    bf16_t* xp_hi; bf16_t* xp_lo; long xp_ld; int xp_in, xp_out;
     const float2* lnc_stats; int lnc_parts; const float* lnc_c; float lnc_eps;
 #ifdef REVO_EXPERIMENTS
     int stagger_cycles, stagger_groups;   // timing experiment (persistent kernel): phase groups, see gemm256p_kernel
@@ -56,6 +63,11 @@ struct GemmArgs {
 // true when launch_gemm would run the 256 x 256 kernel with the row-coalesced epilogue for these sizes
 bool gemm_uses_wide_epilogue(int M, int N, long lda, long ldb, long ldc);
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
+// true when launch_gemm(EPI_RESID_F32) would take one of the two launch forms that can fold the LayerNorm behind it (and
+// keep the residual stream in planes): the persistent 256-row kernel over ALL rows
+bool gemm_resid_folds(int M, int N, int K, long lda, long ldb, long ldc);
+// residual stream planes <-> fp32 (format changes at the ends of a forward's folded stretch; parity hooks)
+int launch_planes_to_f32(const bf16_t* hi, const bf16_t* lo, long ldp, float* x, long ldx, long rows, int W, hipStream_t st);
 #ifdef REVO_EXPERIMENTS
 void gemm_set_debug(int d);           // timing experiments (results are wrong): librevo_exp.so only
 void gemm_set_stagger(int cycles, int groups);
@@ -121,7 +133,8 @@ void gemm_set_ring(int on, int max_tiles);   // timing experiments only (default
 void gemm_set_splitk(int on);       // timing experiments only (1 = default)
 void gemm_set_persistent(int on);   // timing experiments only (1 = default)
 void gemm_set_rows192(int on);      // timing experiments only (1 = default)
-void gemm_set_ln_fold(int on);      // timing experiments only (1 = default): 0 = LayerNorm kernels instead of the folded form
+void gemm_set_ln_fold(int on);      // timing experiments only (1 = default): 0 = LayerNorm kernels instead of the folded form, 2 = folded with an fp32 stream
+bool gemm_ln_planes_enabled();
 void attention_force_nw(int nw);   // timing experiments only (0 = heuristic)
 
 // ---------------------------------------------------------------- top-k ----
