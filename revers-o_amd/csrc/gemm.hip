@@ -274,7 +274,7 @@ __device__ __forceinline__ void gemm256_epilogue_f32_quarter(const GemmArgs& p, 
 // skips them altogether instead of masking their stores.
 // ---- the same residual epilogue with 8 columns per lane and the stream optionally in two bf16 planes (kernels.h xp_*)
 // res[it][2]: the old values of step `it` (8 rows per step, 8 lanes per row): 8 fp32, or 8 bf16 hi + 8 bf16 lo
-template <int QT>
+template <int QT, bool PIN>
 __device__ __forceinline__ void gemm256_resid8_load(const GemmArgs& p, int m_base, int n_base, int lane, uint4 (&res)[4][2]) {
     typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
     int gcol = n_base + (lane & 7) * 8;
@@ -284,7 +284,7 @@ __device__ __forceinline__ void gemm256_resid8_load(const GemmArgs& p, int m_bas
         int grow = m_base + QT * 32 + it * 8 + (lane >> 3);
         grow = grow < p.M ? grow : p.M - 1;
         const nt_u32x4 *s0, *s1;
-        if (p.xp_in) {
+        if (PIN) {
             s0 = (const nt_u32x4*)(p.xp_hi + (long)grow * p.xp_ld + gcol);
             s1 = (const nt_u32x4*)(p.xp_lo + (long)grow * p.xp_ld + gcol);
         } else {
@@ -301,21 +301,20 @@ __device__ __forceinline__ float row8_sum(float v) {      // over the 8 lanes th
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
     return v;
 }
-template <int QT>
+// PIN / POUT: the old values come from / the new ones go to the planes; ST: row statistics (and, with fp32 rows out, their bf16 copy)
+template <int QT, bool PIN, bool POUT, bool ST>
 __device__ __forceinline__ void gemm256_resid8_quarter(const GemmArgs& p, char* slab, int m_base, int n_base, int lane,
-                                                       f32x4 (&acc)[8][4], const f32x4 (&bias4)[4], const f32x4 (&gamma4)[4],
-                                                       const uint4 (&res)[4][2], float2* lnst) {
+                                                       f32x4 (&acc)[8][4], const uint4 (&res)[4][2], float2* lnst) {
     constexpr int RS = 272;
     typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
     asm volatile("" : "+v"(lane) :: "memory");
     const int lr = lane & 15, lq = lane >> 4;
+    // (acc already holds gamma * (acc + bias): the caller scales it in place once, so that the bias and gain vectors are
+    //  not live across the four quarters -- with them the quarters spilled accumulator registers to scratch)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const f32x4 v = (acc[QT * 2 + m][n] + bias4[n]) * gamma4[n];
-            *(f32x4*)(slab + (m * 16 + lr) * RS + (n * 16 + lq * 4) * 4) = v;
-        }
+        for (int n = 0; n < 4; ++n) *(f32x4*)(slab + (m * 16 + lr) * RS + (n * 16 + lq * 4) * 4) = acc[QT * 2 + m][n];
     const int gcol = n_base + (lane & 7) * 8;
     float keep_m = 0.f, keep_q = 0.f;
 #pragma unroll
@@ -325,7 +324,7 @@ __device__ __forceinline__ void gemm256_resid8_quarter(const GemmArgs& p, char* 
         float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         const uint32_t a[4] = {res[it][0].x, res[it][0].y, res[it][0].z, res[it][0].w};
         const uint32_t b[4] = {res[it][1].x, res[it][1].y, res[it][1].z, res[it][1].w};
-        if (p.xp_in) {
+        if (PIN) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {      // old value = hi + lo (exact in fp32)
                 x[2 * j] += __uint_as_float(a[j] << 16) + __uint_as_float(b[j] << 16);
@@ -340,7 +339,7 @@ __device__ __forceinline__ void gemm256_resid8_quarter(const GemmArgs& p, char* 
             uint32_t hi[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) hi[j] = pack_bf16x2(x[2 * j], x[2 * j + 1]);
-            if (p.xp_out) {
+            if (POUT) {
                 uint32_t lo[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -351,10 +350,10 @@ __device__ __forceinline__ void gemm256_resid8_quarter(const GemmArgs& p, char* 
                 float* dst = (float*)p.C + (long)grow * p.ldc + gcol;
                 __builtin_nontemporal_store((f32x4){x[0], x[1], x[2], x[3]}, (f32x4*)dst);
                 __builtin_nontemporal_store((f32x4){x[4], x[5], x[6], x[7]}, (f32x4*)(dst + 4));
-                if (lnst) *(uint4*)(p.lnf_xb + (long)grow * p.lnf_ldxb + gcol) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                if (ST) *(uint4*)(p.lnf_xb + (long)grow * p.lnf_ldxb + gcol) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
             }
         }
-        if (lnst) {           // wave-uniform: two-pass statistics of the row's 64 columns held by its 8 lanes
+        if (ST) {             // two-pass statistics of the row's 64 columns held by its 8 lanes
             const float mean = row8_sum(((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) * (1.0f / 64.0f);
             float q = 0.f;
 #pragma unroll
@@ -363,13 +362,16 @@ __device__ __forceinline__ void gemm256_resid8_quarter(const GemmArgs& p, char* 
             if ((lane & 7) == it) { keep_m = mean; keep_q = q; }       // lane (it, row) keeps row it * 8 + (lane >> 3)
         }
     }
-    if (lnst && (lane & 7) < 4) lnst[(QT * 32 + (lane & 7) * 8 + (lane >> 3)) * 4] = make_float2(keep_m, keep_q);
+    if (ST && (lane & 7) < 4) lnst[(QT * 32 + (lane & 7) * 8 + (lane >> 3)) * 4] = make_float2(keep_m, keep_q);
     asm volatile("" ::: "memory");
 }
 
 // lnst: gemm256_epilogue_f32_quarter (producer side of a folded LayerNorm).  lnmr (consumer side, bf16 epilogues; LDS):
 // (rstd, -mean rstd) of the tile's 256 rows, indexed from the wave's first row.
-template <int EPI, bool SKIP_DEAD = false>
+// XP (EPI_RESID_F32): the residual stream in planes (kernels.h xp_*): 0 = fp32 rows, 1 = fp32 in / planes out, 2 = planes
+// in / planes out, 3 = planes in / fp32 out, no statistics (the last fc2 of a forward).  A compile-time choice, one kernel
+// instantiation each: with run-time tests (or four copies) of the formats inside one kernel hipcc spilled 35-160 registers.
+template <int EPI, bool SKIP_DEAD = false, int XP = 0>
 __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, int m_base, int n_base, int lane,
                                                  f32x4 (&acc)[8][4], float2* lnst = nullptr, const float2* lnmr = nullptr) {
     static_assert(EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_F32 || EPI == EPI_RESID_F32 ||
@@ -498,18 +500,26 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
         // "one ahead" between the stores of the previous ones made every use such a drain.  Two batches of loads,
         // each issued when no load result is outstanding, leave two drains per tile.
         if (SKIP_DEAD && m_base >= p.M) return;                         // wave-uniform: a short piece's second wave-row
-        if (EPI == EPI_RESID_F32 && (p.xp_in || p.xp_out)) {
-            // the stream in (or going into / coming out of) two bf16 planes: 8 columns per lane
+        if constexpr (EPI == EPI_RESID_F32 && XP != 0) {
+            // the stream in (or going into / coming out of) two bf16 planes: 8 columns per lane.  Old values in three
+            // batches (quarter 0 | quarters 1, 2 | quarter 3), each requested when no load result is outstanding (two
+            // batches like the 4-column path below: the same step time, scripts/experiments/r5_resid8_batches.sh).
+            constexpr bool PIN = XP >= 2, POUT = XP <= 2, ST = XP <= 2;
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = (acc[m][n] + bias4[n]) * gamma4[n];
+            asm volatile("" ::: "memory");
             uint4 pa[4][2], pb[4][2];
-            gemm256_resid8_load<0>(p, m_base, n_base, lane, pa);
-            gemm256_resid8_load<1>(p, m_base, n_base, lane, pb);
-            gemm256_resid8_quarter<0>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, pa, lnst);
-            gemm256_resid8_quarter<1>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, pb, lnst);
+            gemm256_resid8_load<0, PIN>(p, m_base, n_base, lane, pa);
+            gemm256_resid8_quarter<0, PIN, POUT, ST>(p, slab, m_base, n_base, lane, acc, pa, lnst);
+            gemm256_resid8_load<1, PIN>(p, m_base, n_base, lane, pa);
+            gemm256_resid8_load<2, PIN>(p, m_base, n_base, lane, pb);       // (unconditional: rows past the piece are clamped, never stored)
+            gemm256_resid8_quarter<1, PIN, POUT, ST>(p, slab, m_base, n_base, lane, acc, pa, lnst);
             if (SKIP_DEAD && m_base + 64 >= p.M) return;                // wave-uniform
-            gemm256_resid8_load<2>(p, m_base, n_base, lane, pa);
-            gemm256_resid8_load<3>(p, m_base, n_base, lane, pb);
-            gemm256_resid8_quarter<2>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, pa, lnst);
-            gemm256_resid8_quarter<3>(p, slab, m_base, n_base, lane, acc, bias4, gamma4, pb, lnst);
+            gemm256_resid8_quarter<2, PIN, POUT, ST>(p, slab, m_base, n_base, lane, acc, pb, lnst);
+            gemm256_resid8_load<3, PIN>(p, m_base, n_base, lane, pa);
+            gemm256_resid8_quarter<3, PIN, POUT, ST>(p, slab, m_base, n_base, lane, acc, pa, lnst);
             return;
         }
         f32x4 ra[8], rb[8];
@@ -734,7 +744,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256_kernel(GemmArgs p) {
 // 1 plus the 32 KiB above the main-loop image (waves 3-7).
 // BMR = 192: 192-row tiles (gemm256_mainloop<192>), chosen by the launcher where they make whole rounds.
 constexpr int G256P_LDS = 163840;
-template <int EPI, int BMR = 256>
+template <int EPI, int BMR = 256, int XP = 0>
 __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, int nslot) {
     static_assert(BMR == 256 || BMR == 192, "");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -826,9 +836,9 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
             gemm_epilogue<EPI, 8, 4>(pe, mb, nb, lane, acc);
         } else {
             const bool wide = (p.N & 7) == 0 && (p.ldc & 7) == 0;
-            if (wide) gemm256_epilogue<EPI, BMR != 256>(pe, slab, mb, nb, lane, acc,
-                                                        lnf ? lds_st + (wave >> 2) * 128 * 4 + (wave & 3) : nullptr,
-                                                        lnc ? lds_mr + (wave >> 2) * 128 : nullptr);
+            if (wide) gemm256_epilogue<EPI, BMR != 256, XP>(pe, slab, mb, nb, lane, acc,
+                                                            lnf ? lds_st + (wave >> 2) * 128 * 4 + (wave & 3) : nullptr,
+                                                            lnc ? lds_mr + (wave >> 2) * 128 : nullptr);
             else gemm_epilogue<EPI, 8, 4>(pe, mb, nb, lane, acc);
         }
         if (lnf) {
@@ -1101,6 +1111,19 @@ static int launch_256p(const GemmArgs& a, hipStream_t st) {
         }
     }
 #endif
+    if constexpr (EPI == EPI_RESID_F32) {
+        // the residual stream in planes: one kernel instantiation per format pair (gemm256_epilogue, XP)
+        const int xp = (b.xp_in || b.xp_out) ? (b.xp_in ? (b.xp_out ? 2 : 3) : 1) : 0;
+        if (xp && ((b.N & 7) || (b.ldc & 7))) { revo_set_error("gemm: planes need the row-coalesced epilogue"); return -2; }
+#define REVO_LAUNCH_XP(X)                                                                                              \
+    case X:                                                                                                             \
+        REVO_FUNC_LDS((gemm256p_kernel<EPI, BMR, X>), G256P_LDS);                                                       \
+        hipLaunchKernelGGL((gemm256p_kernel<EPI, BMR, X>), dim3(8 * nslot), dim3(G256_THREADS), G256P_LDS, st, b, nslot); \
+        break;
+        switch (xp) { REVO_LAUNCH_XP(1) REVO_LAUNCH_XP(2) REVO_LAUNCH_XP(3) default: break; }
+#undef REVO_LAUNCH_XP
+        if (xp) { REVO_HIP_CHECK(hipGetLastError()); return 0; }
+    }
     REVO_FUNC_LDS((gemm256p_kernel<EPI, BMR>), G256P_LDS);
     hipLaunchKernelGGL((gemm256p_kernel<EPI, BMR>), dim3(8 * nslot), dim3(G256_THREADS), G256P_LDS, st, b, nslot);
     REVO_HIP_CHECK(hipGetLastError());
