@@ -379,7 +379,11 @@ def main():
     roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source, "kernel": "gemm256p_kernel (+ the leftover-row kernels of the same linear layer; one layer call = one launch)",
                 "avg_launch_ms": avg_ms, "launches": gemm_launches,
-                "algorithmic_flops_per_launch": flops_per_launch}
+                "algorithmic_flops_per_launch": flops_per_launch,
+                "note": ("since round 5 these launches also carry the body's LayerNorms (row statistics and bf16 rows out of the "
+                         "residual epilogues, the correction in the qkv / fc1 epilogues: DESIGN.md section 4d) -- work that used to "
+                         "be 48 LayerNorm kernels per step outside this kernel class; `achieved` divides the GEMMs' algorithmic "
+                         "FLOPs alone by the whole launch time")}
     # per layer type: the four linear layers of a block have different shapes and epilogues
     W_, M_, rows_ = cfg.width, cfg.mlp_dim, B * cfg.seq
     layer_flops = {"gemm_qkv": 2.0 * rows_ * W_ * 3 * W_, "gemm_out": 2.0 * rows_ * W_ * W_,

@@ -31,7 +31,7 @@ if len(sys.argv) > 2:
         # GELU (1), residual (2) or RoPE (5) epilogue, plus the kernels that take its leftover rows
         main = "revo::gemm256" in k and any(t in k for t in ("<1>", "<2>", "<5>", "<1,", "<2,", "<5,")) and "<3, 4>" not in k
         tail = ("gemm256_kernel<3, 4>" in k or "gemm128_kernel<2" in k or "splitk_reduce_resid" in k or
-                "gemm_skinny_kernel<1>" in k)
+                "gemm_skinny_kernel<1," in k)
         if main or tail:
             tot += (2 * sum(fe[k].get("FETCH_SIZE", [])) + sum(wr[k].get("WRITE_SIZE", []))) * 1024
         if main:
