@@ -539,7 +539,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
 // ---- folded LayerNorm in the 256 x 256 kernels: LDS beyond the operand image / the slabs
 //   consumer: raw partial statistics of the tile's 256 rows (DMA, [256][parts] float2, <= 12 KiB), then (rstd, -mean rstd) per row
 //   producer: the waves' 64-column partials [256 rows][4] float2 (8 KiB), merged per 256-column tile behind the epilogue
-constexpr int LNC_RAW_BYTES = 256 * 6 * 8, LNC_MR_BYTES = 256 * 8;           // parts <= 6 in these kernels (width <= 1536)
+constexpr int LNC_RAW_BYTES = 256 * 6 * 8 + 1024, LNC_MR_BYTES = 256 * 8;    // parts <= 6 in these kernels (width <= 1536); + the last piece's spill-over
 constexpr int G256P_LN_OFF = 98304 + 5 * 9216;                                // persistent kernel: above the last slab (144384)
 static_assert(G256P_LN_OFF + LNC_RAW_BYTES + LNC_MR_BYTES <= 163840, "");
 constexpr int G256_LDS_LN = G256_LDS + LNC_RAW_BYTES + LNC_MR_BYTES;          // one-tile kernel: above the operand image
@@ -549,18 +549,31 @@ constexpr int G256_LDS_LN = G256_LDS + LNC_RAW_BYTES + LNC_MR_BYTES;          //
 //  ahead of it is spilled and reloaded behind it -- a scratch load whose wait also drains the DMA queue and every older store)
 __device__ __forceinline__ void lnc_issue_stats(const GemmArgs& p, int m0, char* lds_raw, int wave, int lane) {
     asm volatile("" : "+v"(lane) :: "memory");
+    if (wave >= 4) return;
+    // wave w requests the slots of rows 64 w .. 64 w + 63 -- the rows its own threads merge (lnc_merge_rows): its own
+    // vmcnt wait is then all the ordering the merge needs (a piece that runs past the wave's share re-writes the next
+    // wave's first bytes with the same values)
     const int P = p.lnc_parts;
     long left = ((long)p.M - m0) * P * 8;
     const long full = 256l * P * 8;
     left = left < 0 ? 0 : (left > full ? full : left);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lnc_stats + (long)m0 * P), 0, (int)left, 0x00020000);
-    for (int i = wave; i < 2 * P; i += 8)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds_raw + i * 1024), 16,
-                                                 (uint32_t)(i * 1024 + lane * 16), 0, 0, 0);
+    const int share = 512 * P, pieces = (share + 1023) >> 10;
+    for (int j = 0; j < pieces; ++j) {
+        const int off = wave * share + j * 1024;
+        if (off + 1024 <= LNC_RAW_BYTES)             // (always, for parts <= 6: the raw area includes the last piece's spill-over KiB)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds_raw + off), 16,
+                                                     (uint32_t)(off + lane * 16), 0, 0, 0);
+    }
 }
-// after the main loop (its last barrier): one thread per tile row merges the row's partials; ends with a workgroup barrier
-__device__ __forceinline__ void lnc_merge_rows(const GemmArgs& p, const char* lds_raw, float2* lds_mr, int wave, int lane) {
+// BEFORE the main loop: one thread per tile row merges the row's partials into (rstd, -mean rstd).  No barrier of its own:
+// a wave reads only slots it requested itself (behind its own counted wait: the statistics are older than the K-tile
+// DMA the main loop's first wait leaves in flight), and the epilogue reads lds_mr behind the main loop's barriers.
+__device__ __forceinline__ void lnc_merge_rows(const GemmArgs& p, const char* lds_raw, float2* lds_mr, int wave, int lane, bool one_ktile) {
     asm volatile("" : "+v"(lane) :: "memory");
+    if (wave >= 4) return;
+    if (one_ktile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     const int t = wave * 64 + lane;
     if (t < 256) {
         float r, m;
@@ -583,7 +596,6 @@ __device__ __forceinline__ void lnc_merge_rows(const GemmArgs& p, const char* ld
         lds_mr[t] = make_float2(r, m);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 }
 // producer: the four waves' 64-column partials of every row -> one (mean, M2) per row and 256-column tile, slot `tn` of the row
 __device__ __forceinline__ void lnf_store_tile_stats(const GemmArgs& p, const float2* lds_st, int m0, int mend, int tn, int wave,
@@ -716,8 +728,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256_kernel(GemmArgs p) {
     if (!(DBG & 2)) {
         if (lnc) lnc_issue_stats(p, m0, smem + G256_LDS, wave, lane);
         g256_issue_prologue(A, B, smem, p.K, wave);
+        if (lnc) lnc_merge_rows(p, smem + G256_LDS, lds_mr, wave, lane, p.K <= 64);
         gemm256_mainloop(A, B, smem, p.K, wave, lane, acc);
-        if (lnc) lnc_merge_rows(p, smem + G256_LDS, lds_mr, wave, lane);
     }
     if (DBG & 1) {
         if (acc[0][0][0] != 12345.678f) return;     // timing-only build: keep acc live, store nothing
@@ -799,6 +811,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
             g256_issue_half(A, 0, 128, G256_A(smem, 1), wave);
             g256_issue_half(A, 1, 128, G256_A(smem, 1), wave);
         }
+        // this tile's rows: (rstd, -mean rstd) into LDS while its second K-tile is on its way (no barrier of its own)
+        if (lnc && !(REVO_LNC_ABLATE & 1)) lnc_merge_rows(p, lds_raw, lds_mr, wave, lane, p.K <= 64);
         f32x4 acc[8][4];
 #pragma unroll
         for (int m = 0; m < 8; ++m)
@@ -806,7 +820,6 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
             for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (BMR == 256) gemm256_mainloop(A, B, smem, p.K, wave, lane, acc);
         else gemm256_mainloop<192>(A, B, smem, p.K, wave, lane, acc, tall);
-        if (lnc && !(REVO_LNC_ABLATE & 1)) lnc_merge_rows(p, lds_raw, lds_mr, wave, lane);       // this tile's rows: (rstd, -mean rstd) in LDS; ends with a barrier
 
         const int mb = m0 + (wave >> 2) * 128, nb = n0 + (wave & 3) * 64;
         GemmArgs pe = p;                                   // the epilogue's row limit: the end of this tile
@@ -822,8 +835,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
             m0 = tile_row0(mi);
             n0 = (n_lo + slot % n_cnt) * 256;
             tall = BMR != 256 && mi >= tall0;
-            // the next tile's row statistics travel with its first K-tile: the raw slots are free again (merged above,
-            // behind a barrier) and the DMA has the whole epilogue to land
+            // the next tile's row statistics travel with its first K-tile: the raw slots are free again (merged before this
+            // tile's main loop, whose barriers lie in between) and the DMA has the whole epilogue to land
             if (lnc && !(REVO_LNC_ABLATE & 4)) lnc_issue_stats(p, m0, lds_raw, wave, lane);
             g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane, BMR == 256 ? 256 : (tall ? 208 : 192));
             g256_operand_init(B, p.B, p.ldb, p.N, n0, wave, lane);
@@ -1373,6 +1386,7 @@ static int launch_skinny(const GemmArgs& a, hipStream_t st) {
     // few output columns (N / 16 workgroups would leave most CUs idle, each pulling all of A through one L2 port): one
     // workgroup per 16 x 16 fragment, all loads of 256 k per wave in flight -- 64 x 1024 x 4096: 21 -> 9 us, x 1024: 8 -> 6
     // (same bits: per element the same K order and the same fixed-order sum of the waves' parts)
+    // (not for fc1's 64 x 4096 x 1024 leftover rows: measured in the step, round 5: fc1 7.70 -> 7.79 ms with the fragment form)
     if (a.K % 1024 == 0 && a.N <= 2048)
         hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 4, 4, 4>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, st, a);
     else
