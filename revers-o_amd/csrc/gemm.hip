@@ -547,9 +547,10 @@ constexpr int G256_LDS_LN = G256_LDS + LNC_RAW_BYTES + LNC_MR_BYTES;          //
 // BEFORE operand DMA the main loop's counted waits cover (vmcnt retires in issue order), read after the main loop's barriers.
 // (lane ids are made opaque in these helpers: the main loop runs at the 256-VGPR limit, and an address the compiler computes
 //  ahead of it is spilled and reloaded behind it -- a scratch load whose wait also drains the DMA queue and every older store)
-__device__ __forceinline__ void lnc_issue_stats(const GemmArgs& p, int m0, char* lds_raw, int wave, int lane) {
-    asm volatile("" : "+v"(lane) :: "memory");
+__device__ __forceinline__ void lnc_issue_stats(const GemmArgs& p, int m0, char* lds_raw, int wave, int /*lane*/) {
     if (wave >= 4) return;
+    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // (see lnc_merge_rows)
+    asm volatile("" : "+v"(lane) :: "memory");
     // wave w requests the slots of rows 64 w .. 64 w + 63 -- the rows its own threads merge (lnc_merge_rows): its own
     // vmcnt wait is then all the ordering the merge needs (a piece that runs past the wave's share re-writes the next
     // wave's first bytes with the same values)
@@ -569,9 +570,12 @@ __device__ __forceinline__ void lnc_issue_stats(const GemmArgs& p, int m0, char*
 // BEFORE the main loop: one thread per tile row merges the row's partials into (rstd, -mean rstd).  No barrier of its own:
 // a wave reads only slots it requested itself (behind its own counted wait: the statistics are older than the K-tile
 // DMA the main loop's first wait leaves in flight), and the epilogue reads lds_mr behind the main loop's barriers.
-__device__ __forceinline__ void lnc_merge_rows(const GemmArgs& p, const char* lds_raw, float2* lds_mr, int wave, int lane, bool one_ktile) {
-    asm volatile("" : "+v"(lane) :: "memory");
+__device__ __forceinline__ void lnc_merge_rows(const GemmArgs& p, const char* lds_raw, float2* lds_mr, int wave, int /*lane*/, bool one_ktile) {
     if (wave >= 4) return;
+    // (the lane id is read from the hardware here: derived from the kernel's `lane` it became one more value alive across
+    //  the main loop, and hipcc spilled accumulator registers INSIDE the K loop of the RoPE kernel)
+    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane) :: "memory");
     if (one_ktile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     const int t = wave * 64 + lane;
