@@ -252,6 +252,8 @@ int32_t revo_debug_seed_bounds(revo_gallery* g, const uint32_t* bounds);
 /* counters of the fused scan when debug bit 14 is set */
 int32_t revo_debug_scan_stats(int64_t* out8);
 #endif
+/* (w / b NULL: normalise only -- how the forward runs the LayerNorms it cannot fold: their gain and shift live in the weights
+ * of the linear layer behind them) */
 int32_t revo_op_layernorm(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows,
                           int32_t width, void* out, int64_t ldo, int32_t out_is_bf16, void* stream);
 int32_t revo_op_rope(void* qkv_bf16, int64_t ld, const float* cos_sin, int32_t rows, int32_t seq, int32_t width,
