@@ -340,6 +340,11 @@ class PendingSearch:
         if ev is not None:
             ev.synchronize()
             n = int(host_n[0])
+            # give the landing place back BEFORE anything below starts another search: with eight searches pending the
+            # repair search of this one would find "itself" in its slot and ask it for its result again
+            slot = self._gen % len(o._inflight)
+            if o._inflight[slot] is self:
+                o._inflight[slot] = None
         else:
             n = int(self._unc[0][0])                                             # CPU backends (tests)
         o.last_uncertified = n
@@ -367,10 +372,6 @@ class PendingSearch:
                 o.last_uncertified = n
                 self._res = (scores, idx, counts)
         self._done = True
-        if ev is not None:
-            slot = self._gen % len(o._inflight)
-            if o._inflight[slot] is self:
-                o._inflight[slot] = None
         return self._res
 
 

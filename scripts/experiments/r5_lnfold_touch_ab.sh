@@ -1,3 +1,5 @@
+#!/bin/bash
+# Round 5, no effect: re-touch bf16(x) right before the GEMM that streams it (is the consumer's extra time Infinity-Cache residency? no).
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline --ingest-images 0 --search-queries 0"
 for r in 1 2; do
   REVO_EXPERIMENTS=1 python bench.py $ARGS 2>/dev/null > gpurun_out/touch_off_$r.json

@@ -1,3 +1,6 @@
+#!/bin/bash
+# Round 5, same step time: two instead of three batches of old values in the plane epilogue of the residual GEMMs (the macro
+# REVO_RESID8_TWO_BATCHES existed in gemm.hip for this run only: commit 07985f2's successor; re-create it to repeat).
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline --ingest-images 0 --search-queries 0"
 for r in 1 2 3; do
   REVO_EXPERIMENTS=1 python bench.py $ARGS 2>/dev/null > gpurun_out/b3_$r.json
