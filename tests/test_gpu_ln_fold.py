@@ -253,6 +253,18 @@ def test_forward_with_the_fold_equals_the_layernorm_kernel_form(dev):
     # (two realisations of the bf16 rounding noise: a 2^-17 change of the stream flips one bf16 rounding of the GEMM operands
     #  in ~256, so they sit as far from each other as each sits from the oracle -- block 11: 3.9e-3, tests/test_gpu_l14_golden.py)
     assert float((x12 - x12_f32).norm() / x12_f32.norm()) <= 6e-3 and torch.isfinite(x12).all()
+    # the oracle's per-block activations of two of the 64 images (tests/golden/l14_batch64.npz), taken INSIDE the batch:
+    # the folded LayerNorms and the stream in planes land where the LayerNorm-kernel path of the two-image forwards lands
+    # (tests/test_gpu_l14_golden.py: block 6 / 12 / 24 at 3.1 / 3.9 / 4.6e-3, asserted at 5 / 6 / 7e-3)
+    gold = np.load(os.path.join(HERE, "golden", "l14_batch64.npz"))
+    timg, ttok = gold["tap_images"].tolist(), gold["tap_tokens"].tolist()
+    rel = {}
+    for b, bound in zip(gold["tap_blocks"].tolist(), (5e-3, 6e-3, 7e-3)):
+        x = eng.residual_after(img, b + 1)[timg][:, ttok].cpu()
+        r = torch.from_numpy(gold[f"tap_block{b}"])
+        rel[b] = float((x - r).norm() / r.norm())
+        assert rel[b] <= bound, rel
+    print("L14 batch 64, folded LayerNorm + planes: relative distance from the oracle after blocks", {k: round(v, 5) for k, v in rel.items()})
     assert torch.isfinite(x_fold).all()
     assert torch.equal(eng.embed(img), e_fold)            # repeatable bit for bit
     eng.close()
