@@ -581,22 +581,27 @@ __device__ __forceinline__ void lnc_merge_rows(const GemmArgs& p, const char* ld
     const int t = wave * 64 + lane;
     if (t < 256) {
         float r, m;
-        if (p.lnc_parts == 4) {
-            // width 1024: two 16-byte reads, no loops (the same operations in the same order as lnf_merge)
-            const f32x4 a = *(const f32x4*)(lds_raw + t * 32), b = *(const f32x4*)(lds_raw + t * 32 + 16);
-            const float sm = ((0.f + a[0]) + a[2]) + b[0] + b[2], sq = ((0.f + a[1]) + a[3]) + b[1] + b[3];
-            const float mean = sm / 4.0f;
-            float dd = 0.f, d;
-            d = a[0] - mean; dd = fmaf(d, d, dd);
-            d = a[2] - mean; dd = fmaf(d, d, dd);
-            d = b[0] - mean; dd = fmaf(d, d, dd);
-            d = b[2] - mean; dd = fmaf(d, d, dd);
-            const float var = fmaf((float)LNF_SLICE, dd, sq) / (float)(LNF_SLICE * 4);
+        // widths 1024 and 1536 unrolled (16-byte reads, no loops, no division by a run-time count); the same operations in the
+        // same order as lnf_merge
+        auto merge_n = [&](auto np) {
+            constexpr int NP = decltype(np)::value;
+            f32x4 v[NP / 2];
+#pragma unroll
+            for (int i = 0; i < NP / 2; ++i) v[i] = *(const f32x4*)(lds_raw + t * (NP * 8) + i * 16);
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) { sm += v[i >> 1][(i & 1) * 2]; sq += v[i >> 1][(i & 1) * 2 + 1]; }
+            const float mean = sm / (float)NP;
+            float dd = 0.f;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) { const float d = v[i >> 1][(i & 1) * 2] - mean; dd = fmaf(d, d, dd); }
+            const float var = fmaf((float)LNF_SLICE, dd, sq) / (float)(LNF_SLICE * NP);
             r = rsqrtf(var + p.lnc_eps);
             m = -mean * r;
-        } else {
-            lnf_merge((const float2*)lds_raw + t * p.lnc_parts, p.lnc_parts, p.lnc_eps, r, m);
-        }
+        };
+        if (p.lnc_parts == 4) merge_n(std::integral_constant<int, 4>{});
+        else if (p.lnc_parts == 6) merge_n(std::integral_constant<int, 6>{});
+        else lnf_merge((const float2*)lds_raw + t * p.lnc_parts, p.lnc_parts, p.lnc_eps, r, m);
         lds_mr[t] = make_float2(r, m);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
