@@ -97,7 +97,11 @@ __device__ __forceinline__ void att_dma_issue(const AttDmaSrc& src, char* dst, u
 // scripts/attn_knockout.sh): 1 = no K/V DMA in the loop and no wait for it, 2 = no per-tile barrier, 4 = no exponentials
 // (scores packed as they are), 8 = no PV MFMAs, 16 = no score MFMAs, 32 = no row sums (the 16 v_pk_add_f32 per tile),
 // 64 = no scale-and-shift before the exponentials (the 16 v_pk_fma_f32 per tile)
-template <int HD, int NW, int DBG = 0>
+// STAG (head_dim 64, 8 waves; experiment, round 5): waves 4-7 run half a key tile behind waves 0-3 -- their P.V of tile t - 1
+// moves behind the barrier of tile t, so that on every SIMD one wave's matrix segment lies beside its partner's softmax
+// (the MI355X guide's stagger for same-program partners).  Needs a fourth ring slot (tile t - 1's V must outlive the
+// barrier of tile t: 64 KiB per workgroup); same arithmetic in the same order per row: same bits.
+template <int HD, int NW, int DBG = 0, bool STAG = false>
 __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                           bf16_t* __restrict__ out, long ldo, int S, int H, float c,
                                                           int q_rot, int k_lo) {
@@ -114,7 +118,9 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
     constexpr int ROWB = HD == 64 ? 128 : 256;
     constexpr int TILE = 64 * ROWB;      // one operand of one key tile: 8 or 16 KB
     constexpr int BUF = 2 * TILE;        // K then V
-    constexpr int NBUF = HD == 64 ? 3 : 2;   // ring depth: 48 KiB (hd 64) / 64 KiB (hd 96) per workgroup
+    static_assert(!STAG || (HD == 64 && NW == 8), "");
+    constexpr int LOOK = HD == 64 ? 2 : 1;  // key tiles requested ahead of the one being worked on
+    constexpr int NBUF = LOOK + 1 + (STAG ? 1 : 0);   // ring depth: 48 KiB (hd 64; 64 KiB staggered) / 64 KiB (hd 96) per workgroup
     constexpr int NI = BUF / 1024;       // DMA wave-instructions per tile (1 KiB each)
     constexpr int NPW = (NI + NW - 1) / NW;   // per wave per tile; when NW does not divide NI the surplus
     constexpr int NDUMMY = NPW * NW - NI;     // instructions read out of bounds (zeros) into a spare KiB each
@@ -193,10 +199,10 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
             att_dma_issue(dma_src, d_, dma_voff[i], (uint32_t)(t) * tile_bytes);                \
         }                                                                                       \
     } while (0)
-    // wait until tile u has landed, given that tiles up to min(u + NBUF - 2, nt - 1) have been requested
+    // wait until tile u has landed, given that tiles up to min(u + LOOK - 1, nt - 1) have been requested
 #define ATT_WAIT_TILE(u)                                                                                  \
     do {                                                                                                  \
-        const int inflight_ = ((u) + NBUF - 2 < nt ? NBUF - 2 : nt - 1 - (u));                             \
+        const int inflight_ = ((u) + LOOK - 1 < nt ? LOOK - 1 : nt - 1 - (u));                             \
         if (inflight_ >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");                    \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
     } while (0)
@@ -224,10 +230,11 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
 
-    // ring discipline: tiles 0 .. NBUF-2 are requested here; the iteration that starts tile t requests
-    // tile t + NBUF - 1 behind its barrier, i.e. once every wave is done with tile t-1 (same buffer)
+    // ring discipline: tiles 0 .. LOOK-1 are requested here; the iteration that starts tile t requests tile t + LOOK
+    // behind its barrier, i.e. once every wave is done with the tile whose buffer it takes (t - 1; staggered: t - 2,
+    // whose P.V the late waves finished in the step of tile t - 1)
 #pragma unroll
-    for (int u = 0; u < NBUF - 1; ++u)
+    for (int u = 0; u < LOOK; ++u)
         if (u < nt) ATT_ISSUE_TILE(u, u);
 
     if (k_lo == 1 && wave_active) {
@@ -261,6 +268,37 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
     // vmcnt(3..0) in front of the score MFMAs of EVERY iteration, which drains the K/V tiles just requested.
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    const bool late = STAG && wave >= NW / 2;                 // wave-uniform
+    uint32_t pw[2][8];                                        // the tile's probabilities, packed bf16 (late waves: kept across the barrier)
+    uint64_t vt0[2][DB][2], vt1[2][DB][2];
+    // O^T += V^T . P^T for the 64 keys of the tile whose ring slot starts at byte SBX; issued0: block 0's V^T fragments are
+    // already requested (ahead of the exponentials)
+    auto pv_tile = [&](auto sbx_c, const bool issued0) __attribute__((always_inline)) {
+        constexpr int SBX = decltype(sbx_c)::value;
+        if (!issued0) att_v_issue<ROWB, DB, SBX>(vt0, vaddr);
+        att_v_wait<DB>(vt0);
+        att_v_issue<ROWB, DB, SBX + 32 * ROWB>(vt1, vaddr);
+#define ATT_PV(KB, VT)                                                                                  \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                  \
+        uint4 pk;                                                                                       \
+        pk.x = pw[KB][4 * s2 + 0];                                                                      \
+        pk.y = pw[KB][4 * s2 + 1];                                                                      \
+        pk.z = pw[KB][4 * s2 + 2];                                                                      \
+        pk.w = pw[KB][4 * s2 + 3];                                                                      \
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, pk);                                               \
+        /* k index (h, j) of this step is key 16*s2 + 8*(j>>2) + 4*h + (j&3) of the block */            \
+        _Pragma("unroll") for (int d = 0; d < DB; ++d)                                                  \
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_v_frag(VT[s2][d][0], VT[s2][d][1]), pb, oacc[d], 0, 0, 0); \
+    }
+        if constexpr (!(dbg & 8)) { ATT_PV(0, vt0); }
+        att_v_wait<DB>(vt1);
+        if constexpr (!(dbg & 8)) { ATT_PV(1, vt1); }
+        else {      // knock-out build: keep the operands alive
+            const uint32_t keep_ = pw[0][0] ^ pw[1][7] ^ (uint32_t)vt0[0][0][0] ^ (uint32_t)vt1[1][DB - 1][1];
+            asm volatile("" :: "v"(keep_));
+        }
+#undef ATT_PV
+    };
     // One key tile.  The ring slot is a compile-time constant (the loop below is unrolled NBUF times), so every LDS
     // address is a per-lane register fixed at kernel entry plus an immediate.
     auto tile_step = [&](auto slot_c, const int t) __attribute__((always_inline)) {
@@ -268,8 +306,12 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
         constexpr int SB = SLOT * BUF;
         if constexpr (!(dbg & 1)) ATT_WAIT_TILE(t);
         if constexpr (!(dbg & 2)) __builtin_amdgcn_s_barrier();           // tile t is in LDS for every wave; every wave is done with tile t-1
-        if constexpr (!(dbg & 1)) if (t + NBUF - 1 < nt) ATT_ISSUE_TILE((SLOT + NBUF - 1) % NBUF, t + NBUF - 1);
+        if constexpr (!(dbg & 1)) if (t + LOOK < nt) ATT_ISSUE_TILE((SLOT + LOOK) % NBUF, t + LOOK);
         if (!wave_active) return;
+        if constexpr (STAG) {
+            // late waves: the previous tile's P.V first (its probabilities were kept in pw, its V tile is still in the ring)
+            if (late && t > 0) pv_tile(std::integral_constant<int, ((SLOT + NBUF - 1) % NBUF) * BUF>{}, false);
+        }
         f32x16 sacc[2];
         att_u32x4 kf[4];
         // S^T = K . Q^T for the 64 keys of the tile, masked past the last key
@@ -310,15 +352,13 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
         if constexpr (!(dbg & 16)) scores();
         else { _Pragma("unroll") for (int kb_ = 0; kb_ < 2; ++kb_) _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) sacc[kb_][i_] = (float)(lane + i_) * 1e-3f; }
         // V^T fragments of key block 0 are requested ahead of the exponentials, block 1's before block 0's MFMAs
-        uint64_t vt0[2][DB][2], vt1[2][DB][2];
-        att_v_issue<ROWB, DB, SB>(vt0, vaddr);
+        if (!(STAG && late)) att_v_issue<ROWB, DB, SB>(vt0, vaddr);
         // Optimistic softmax.  p = 2^(s c - m) is computed against the running reference m on
         // register pairs (v_pk_fma_f32 / v_pk_add_f32 / v_cvt_pk_bf16_f32) WITHOUT first taking the
         // tile maximum: the softmax VALU work, not the MFMAs, bounds this kernel at head_dim 64.
         // fp32 and bf16 share the exponent range, so a reference that lags the true maximum by up
         // to 2^80 loses no precision; only when a row sum leaves that range (or m is still -inf)
         // does the wave take the maximum, move the reference, rescale and redo the exponentials.
-        uint32_t pw[2][8];
         f32x2 ps2;
         auto exps = [&]() __attribute__((always_inline)) {
             const f32x2 c2_ = {c, c}, m2_ = {m_run, m_run};
@@ -362,25 +402,7 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
             ps = ps2.x + ps2.y;
         }
         l_run += ps;
-        att_v_wait<DB>(vt0);
-        att_v_issue<ROWB, DB, SB + 32 * ROWB>(vt1, vaddr);
-#define ATT_PV(KB, VT)                                                                                  \
-    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                  \
-        uint4 pk;                                                                                       \
-        pk.x = pw[KB][4 * s2 + 0];                                                                      \
-        pk.y = pw[KB][4 * s2 + 1];                                                                      \
-        pk.z = pw[KB][4 * s2 + 2];                                                                      \
-        pk.w = pw[KB][4 * s2 + 3];                                                                      \
-        const bf16x8 pb = __builtin_bit_cast(bf16x8, pk);                                               \
-        /* k index (h, j) of this step is key 16*s2 + 8*(j>>2) + 4*h + (j&3) of the block */            \
-        _Pragma("unroll") for (int d = 0; d < DB; ++d)                                                  \
-            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(att_v_frag(VT[s2][d][0], VT[s2][d][1]), pb, oacc[d], 0, 0, 0); \
-    }
-        if constexpr (!(dbg & 8)) { ATT_PV(0, vt0); }
-        att_v_wait<DB>(vt1);
-        if constexpr (!(dbg & 8)) { ATT_PV(1, vt1); }
-        else { asm volatile("" :: "v"(pw[0][0]), "v"(pw[1][7]), "v"(vt0[0][0][0]), "v"(vt1[1][DB - 1][1])); }
-#undef ATT_PV
+        if (!(STAG && late)) pv_tile(std::integral_constant<int, SB>{}, true);
     };
 #ifdef REVO_ATTN_PRIO
     // experiment (MI355X guide, "static priority for the younger half"): waves 4-7 are the arbitration losers of every segment
@@ -390,6 +412,18 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
         tile_step(std::integral_constant<int, 0>{}, t);
         if (NBUF > 1 && t + 1 < nt) tile_step(std::integral_constant<int, 1 % NBUF>{}, t + 1);
         if (NBUF > 2 && t + 2 < nt) tile_step(std::integral_constant<int, 2 % NBUF>{}, t + 2);
+        if (NBUF > 3 && t + 3 < nt) tile_step(std::integral_constant<int, 3 % NBUF>{}, t + 3);
+    }
+    if constexpr (STAG) {
+        // the late waves' last P.V (its V tile stays in the ring: nothing is requested behind the last tile)
+        if (late && wave_active && nt > 0) {
+            switch ((nt - 1) % NBUF) {
+                case 0: pv_tile(std::integral_constant<int, 0>{}, false); break;
+                case 1: pv_tile(std::integral_constant<int, BUF>{}, false); break;
+                case 2: pv_tile(std::integral_constant<int, 2 * BUF>{}, false); break;
+                default: pv_tile(std::integral_constant<int, 3 * BUF>{}, false); break;
+            }
+        }
     }
 
     if constexpr (HD == 64) {
@@ -450,6 +484,10 @@ static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, in
     dim3 grid((rows + NW * 32 - 1) / (NW * 32), B * H), block(NW * 64);
 #ifdef REVO_EXPERIMENTS
     if constexpr (HD == 64 && NW == 8) {
+        if (getenv("REVO_ATTN_STAG")) {            // A/B of the half-tile stagger (scripts/experiments/r5_attn_stagger.sh)
+            hipLaunchKernelGGL((attn_fwd_kernel<HD, NW, 0, true>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo);
+            return;
+        }
         if (const char* e = getenv("REVO_ATTN_DBG")) {
             switch (atoi(e)) {
 #define ATT_DBG_CASE(D) case D: hipLaunchKernelGGL((attn_fwd_kernel<HD, NW, D>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo); return;
