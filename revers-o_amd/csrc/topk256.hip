@@ -348,13 +348,17 @@ __device__ __noinline__ void s256_drain(const S256Lds& L, uint64_t* seg0, long s
     __syncthreads();
 }
 
+constexpr int S256_PHASES = 8;
 struct Scan256Args {
     const bf16_t* Qb; long ldq;
     const bf16_t* Gb; long ldg;
     int Q; long N; int D;
     long n_begin;                 // rows [0, n_begin) are covered by the pre-pass
-    int splits;
-    int qt_pad;                   // query tiles per slice in the block order (the real count, rounded up to 8 when >= 8)
+    int splits;                   // segment slots per query: the most slices any phase has
+    // The launch is a sequence of up to S256_PHASES phases; phase i holds the blocks [first[i], first[i + 1]) and deals
+    // them as (query tile q0[i] + j % qn[i], slice j / qn[i]) of ns[i] slices (launch_topk_scan256 says which phases)
+    int nph;
+    int ph_first[S256_PHASES + 1], ph_q0[S256_PHASES], ph_qn[S256_PHASES], ph_ns[S256_PHASES];
     uint64_t* seg;                // [Q][splits][2 KSEL] appended keys (score desc / index asc order, unsorted)
     int* seg_cnt;                 // [Q][splits] valid entries of each segment (written when the slice is done)
     uint32_t* tau_g;              // [Q] shared admission scores (order-preserving u32), seeded by the pre-pass, raised by drains
@@ -398,21 +402,34 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = tid & 63;
-    // 1-D grid, block b -> (query tile b % qt_pad, slice b / qt_pad).  Blocks are dealt to the 8 XCDs round-robin,
-    // so with qt_pad a multiple of 8 all slices of a query tile run on one XCD (shared L2: histograms, query rows)
-    const int qtile = blockIdx.x % p.qt_pad;
-    const int sp = blockIdx.x / p.qt_pad;
+    // 1-D grid in phases: block b of phase i (scalar compares against the phases' first blocks) -> local j = b - first[i],
+    // query tile q0[i] + j % qn[i], slice j / qn[i] of ns[i].  Blocks are dealt to the 8 XCDs round-robin and every phase
+    // starts at a multiple of 8, so in a phase of 8 a query tiles all slices of a query tile run on one XCD (shared L2:
+    // histograms, query rows) and the a workgroups that hold the same slice of the XCD's a query tiles stream the same
+    // gallery rows side by side.
+    // (constant indices only: a run-time index into the by-value argument block makes hipcc copy it to scratch)
+    int ph_first = p.ph_first[0], ph_q0 = p.ph_q0[0], ph_qn = p.ph_qn[0], nsl = p.ph_ns[0];
+#pragma unroll
+    for (int i = 1; i < S256_PHASES; ++i)
+        if (i < p.nph && (int)blockIdx.x >= p.ph_first[i]) { ph_first = p.ph_first[i]; ph_q0 = p.ph_q0[i]; ph_qn = p.ph_qn[i]; nsl = p.ph_ns[i]; }
+    const int jloc = (int)blockIdx.x - ph_first;
+    // (an integer division is a vector-unit sequence: its wave-uniform results are moved to scalar registers here, or the
+    //  slice bounds derived from them sit in vector registers across the main loop -- at the 256-register limit, in scratch)
+    const int sp = __builtin_amdgcn_readfirstlane(jloc / ph_qn);
+    const int qtile = ph_q0 + (jloc - sp * ph_qn);
     const int q0 = qtile * 256;
-    if (q0 >= p.Q) return;                                  // padding block
+    if (q0 >= p.Q) return;
     const int qvalid = (p.Q - q0) < 256 ? (p.Q - q0) : 256;
 
     // slices: the tiles are dealt out as evenly as possible (the first `rem` slices take one more)
     const long span = p.N - p.n_begin;
     const long tiles = (span + 255) / 256;
-    const long per = tiles / p.splits, rem = tiles - per * p.splits;
-    const long t0 = sp * per + (sp < rem ? sp : rem);
-    const long t1 = t0 + per + (sp < rem ? 1 : 0);
-    const long row_begin = p.n_begin + t0 * 256;            // first gallery row of this slice
+    // (32-bit and scalar: tiles < 2^24; the hardware has no scalar 64-bit order compare, so as `long` these bounds lived in
+    //  vector registers across the main loop)
+    const int per = __builtin_amdgcn_readfirstlane((int)tiles / nsl), rem = (int)tiles - per * nsl;
+    const int t0 = sp * per + (sp < rem ? sp : rem);
+    const int t1 = t0 + per + (sp < rem ? 1 : 0);
+    const long row_begin = p.n_begin + (long)t0 * 256;            // first gallery row of this slice
     const uint32_t idx_base = (uint32_t)row_begin;
     const long seg_row_stride = (long)p.splits * SEG;
     uint64_t* myseg = p.seg + ((long)q0 * p.splits + sp) * SEG;      // row r of the tile: + r * seg_row_stride
@@ -429,6 +446,9 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     }
     if (tid == 0) { L.ctrl[0] = 0; L.ctrl[1] = 0; }
     __syncthreads();
+    // (phases differ in their slice counts: a query's slots beyond its phase's slices are closed by slice 0)
+    if (sp == 0 && tid < qvalid)
+        for (int s2 = nsl; s2 < p.splits; ++s2) p.seg_cnt[(long)(q0 + tid) * p.splits + s2] = 0;
     if (t0 >= t1) {
         if (tid < qvalid) p.seg_cnt[(long)(q0 + tid) * p.splits + sp] = 0;
         return;
@@ -450,11 +470,11 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     // it holds, or stages more survivors than the staging buffer holds (an adversarially ordered gallery), the tile
     // is recomputed in 2, 4, ... 64 column groups, one pass and one drain per group; at 64 groups a pass can
     // admit at most 256 x 4 = 1024 entries, so the retry always terminates.  Entries found twice are dropped when lists are merged (drain, final reduce).
-    long t = t0;
+    int t = t0;
     int groups = 1, grp = 0;
     uint32_t staged_before = 0;            // survivors staged by earlier passes (the LDS total is never reset)
     while (t < t1) {
-        const long n0 = p.n_begin + t * 256;
+        const long n0 = p.n_begin + (long)t * 256;
         {
             f32x4 acc[8][4];
 #pragma unroll
@@ -586,7 +606,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
             // what all slices of these queries have learnt meanwhile: after the first two tiles (the bound moves
             // fastest early on: it follows KSEL / rows seen), then every fourth tile, every 16th from tile 32 on
             // (each refresh is an L2 round trip plus ~3 us of wave scans)
-            const long tl = t - t0;
+            const int tl = t - t0;
             if (t + 1 < t1 && !(p.dbg & 17) && (tl < 2 || ((tl & 3) == 3 && tl < 32) || (tl & 15) == 15)) {
                 if (p.stats && tid == 0) atomicAdd(p.stats + 5, 1ull);
                 s256_refresh_hist<KSEL, MARGIN>(L, p.hist, p.tau_g, q0, qvalid, tid, MARGIN ? p.marg : nullptr);
@@ -609,7 +629,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // a DMA issued for another tile must not land on top
         __syncthreads();
         if (t < t1) {
-            const long nn = p.n_begin + t * 256;
+            const long nn = p.n_begin + (long)t * 256;
             g256_operand_init(B, p.Gb + nn * p.ldg, p.ldg, p.N - nn, 0, wave, lane);
             g256_issue_prologue(A, B, smem, p.D, wave);
         }
@@ -734,6 +754,57 @@ static unsigned long long* topk_scan256_stats() { return nullptr; }
 int topk_scan256_hist_buckets() { return S256_NB; }
 int topk_scan256_hist_shift() { return S256_SH; }
 
+// Slices per query tile for up to 7 query tiles (and for the last, unpinned phase of a larger launch).  Workgroups run
+// one per CU in rounds; a slice costs its tiles plus about one tile time of fixed work (pipeline fill, refreshes, the
+// tail), and the slices are dealt out evenly, so the phase takes about  rounds x (ceil(tiles / s) + 1)  tile times.
+// Fewer, longer slices on a tie.
+static int scan256_best_splits(int qtiles, long tiles, double* cost_out) {
+    int best = 1;
+    double best_cost = 1e300;
+    for (int s = 1; s <= 512; ++s) {
+        if (s > tiles) break;
+        const long per = (tiles + s - 1) / s;
+        if (s > 1 && per < 3) break;
+        const long rounds = ((long)qtiles * s + 255) / 256;
+        const double cost = (double)rounds * ((double)per + 1.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    if (cost_out) *cost_out = best_cost;
+    return best;
+}
+// The phases of a scan launch.  With 8 query tiles and more, query tiles are pinned to XCDs (kernel comment) and the
+// slices of an XCD's query tiles have to line up, so an XCD's 32 CUs are all busy only when it holds a = 1, 2, 4, 8, 16 or
+// 32 query tiles (32 / a slices each).  The query tiles are therefore taken in phases of 8 a, largest first -- 39 query
+// tiles: 32 as 4 per XCD x 8 slices, then the other 7 with the slices of a small launch -- each phase one even round of
+// workgroups; the hardware starts a phase's blocks as the previous phase's end.  (Rounds 2-4 ran all query tiles in one
+// phase, 5 per XCD x 6 slices = 30 of 32 CUs and 24 on the eighth XCD: 615 tile times where 39 x 3 875 / 256 = 590 is even,
+// 78 against 69.5 on a shard of an eighth.)
+struct Scan256Plan { int nph, splits; int q0[S256_PHASES], qn[S256_PHASES], ns[S256_PHASES]; double cost; };
+static void scan256_plan(int qtiles, long tiles, Scan256Plan& pl) {
+    pl = Scan256Plan{};
+    int q = 0;
+    auto add = [&](int qn, int ns, double cost) {
+        pl.q0[pl.nph] = q; pl.qn[pl.nph] = qn; pl.ns[pl.nph] = ns; ++pl.nph;
+        pl.splits = ns > pl.splits ? ns : pl.splits;
+        pl.cost += cost;
+        q += qn;
+    };
+    while (qtiles - q >= 8 && pl.nph < S256_PHASES - 1) {
+        int a = 1;
+        while (a < 32 && 16 * a <= qtiles - q) a *= 2;                 // the largest power of two with 8 a <= what is left
+        int rounds = 1;
+        if (a == 32) rounds = (qtiles - q) / 256;                       // whole rounds of one query tile per CU
+        long ns = 32 / a;
+        if (ns > tiles) ns = tiles;
+        while (ns > 1 && (tiles + ns - 1) / ns < 3) --ns;               // (a gallery of a few tiles: fewer, longer slices)
+        add(8 * a * rounds, (int)ns, (double)rounds * ((double)((tiles + ns - 1) / ns) + 1.0));
+    }
+    if (q < qtiles) {
+        double c = 0.0;
+        const int ns = scan256_best_splits(qtiles - q, tiles, &c);
+        add(qtiles - q, ns, c);
+    }
+}
 int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, int Q, long N, int D, long n_begin,
                         int splits, uint64_t* seg, int* seg_cnt, uint32_t* tau_g, const uint32_t* tau_base, uint32_t* hist,
                         int ksel, hipStream_t st, const float* marg, int* dropflag) {
@@ -743,14 +814,27 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
     REVO_REQUIRE(256l * ldg * 2 < (1l << 31) && 256l * ldq * 2 < (1l << 31), "search: row too long for the DMA window");
     REVO_REQUIRE(splits >= 1 && splits <= 65535, "search: bad slice count");
     const long tiles = (N - n_begin + 255) / 256;
-    const long per = (tiles + splits - 1) / splits;
-    REVO_REQUIRE(per * 256 <= (1l << 24), "search: a gallery slice holds at most 2^24 rows; use more splits");
     if (Q <= 0 || N <= n_begin) return 0;
     const int qtiles = (Q + 255) / 256;
-    const int qt_pad = qtiles >= 8 ? (qtiles + 7) / 8 * 8 : qtiles;
-    Scan256Args a{Qb, ldq, Gb, ldg, Q, N, D, n_begin, splits, qt_pad, seg, seg_cnt, tau_g, tau_base, hist, marg, dropflag, g_scan_dbg,
-                  (g_scan_dbg & 2) ? topk_scan256_stats() : nullptr};
-    const dim3 grid((unsigned)((long)qt_pad * splits)), block(G256_THREADS);
+    Scan256Plan pl;
+    scan256_plan(qtiles, tiles, pl);
+    REVO_REQUIRE(splits == pl.splits, "search: the slice count is not the one topk_scan256_splits() gave");
+    Scan256Args a{};
+    a.Qb = Qb; a.ldq = ldq; a.Gb = Gb; a.ldg = ldg; a.Q = Q; a.N = N; a.D = D; a.n_begin = n_begin; a.splits = splits;
+    a.nph = pl.nph;
+    long blocks = 0;
+    for (int i = 0; i < pl.nph; ++i) {
+        const long per = (tiles + pl.ns[i] - 1) / pl.ns[i];
+        REVO_REQUIRE(per * 256 <= (1l << 24), "search: a gallery slice holds at most 2^24 rows; use more splits");
+        a.ph_first[i] = (int)blocks; a.ph_q0[i] = pl.q0[i]; a.ph_qn[i] = pl.qn[i]; a.ph_ns[i] = pl.ns[i];
+        blocks += (long)pl.qn[i] * pl.ns[i];
+        if (i + 1 < pl.nph) blocks = (blocks + 7) / 8 * 8;       // (pinned phases are multiples of 8 blocks anyway)
+    }
+    REVO_REQUIRE(blocks < (1l << 31), "search: too many scan workgroups");
+    a.ph_first[pl.nph] = (int)blocks;
+    a.seg = seg; a.seg_cnt = seg_cnt; a.tau_g = tau_g; a.tau_base = tau_base; a.hist = hist; a.marg = marg; a.dropflag = dropflag;
+    a.dbg = g_scan_dbg; a.stats = (g_scan_dbg & 2) ? topk_scan256_stats() : nullptr;
+    const dim3 grid((unsigned)blocks), block(G256_THREADS);
 #define S256_LAUNCH_M(KS, RW, MG)                                                                              \
     do {                                                                                                       \
         REVO_FUNC_LDS((topk_scan256_kernel<KS, RW, MG>), S256_LDS);                                              \
@@ -783,29 +867,12 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
     return 0;
 }
 
-// Slices per query tile.  Workgroups run one per CU in rounds; a slice costs its tiles plus about one tile time of
-// fixed work (pipeline fill, refreshes, the tail), and the slices of a launch are dealt out evenly, so the scan
-// takes about  rounds x (ceil(tiles / s) + 1)  tile times.  Fewer, longer slices on a tie.
-static int scan256_best_splits(int qtiles, long tiles, double* cost_out) {
-    int best = 1;
-    double best_cost = 1e300;
-    for (int s = 1; s <= 512; ++s) {
-        if (s > tiles) break;
-        const long per = (tiles + s - 1) / s;
-        if (s > 1 && per < 3) break;
-        // with >= 8 query tiles the launcher pins every query tile to one XCD (shared histograms): the busiest XCD has
-        // ceil(qtiles / 8) of them and runs their slices on its 32 CUs; with fewer, the slices spread over all 256 CUs
-        const long rounds = qtiles >= 8 ? ((long)((qtiles + 7) / 8) * s + 31) / 32 : ((long)qtiles * s + 255) / 256;
-        const double cost = (double)rounds * ((double)per + 1.0);
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
-    }
-    if (cost_out) *cost_out = best_cost;
-    return best;
-}
 int topk_scan256_splits(int Q, long rows) {
     const long tiles = (rows + 255) / 256;
     if (tiles <= 0) return 1;
-    return scan256_best_splits((Q + 255) / 256, tiles, nullptr);
+    Scan256Plan pl;
+    scan256_plan((Q + 255) / 256, tiles, pl);
+    return pl.splits;
 }
 // A query count that leaves a mostly empty last query tile (10 000 = 39 x 256 + 16) pays a whole tile row of MFMA work
 // for those few queries, and one more query tile can halve the slices the busiest XCD has room for (2064 queries =
@@ -816,11 +883,11 @@ int topk_scan256_main_queries(int Q, long rows) {
     const long tiles = (rows + 255) / 256;
     const int rem = Q % 256;
     if (tiles <= 0 || Q <= 256 || rem == 0 || rem > 128) return Q;
-    double whole = 0.0, main = 0.0;
-    scan256_best_splits((Q + 255) / 256, tiles, &whole);
-    scan256_best_splits(Q / 256, tiles, &main);
+    Scan256Plan whole, main;
+    scan256_plan((Q + 255) / 256, tiles, whole);
+    scan256_plan(Q / 256, tiles, main);
     const double tail = 0.006 * (double)tiles + 0.5;
-    return main + tail < whole ? Q - rem : Q;
+    return main.cost + tail < whole.cost ? Q - rem : Q;
 }
 
 // ---------------------------------------------------------------- the collect pass ----

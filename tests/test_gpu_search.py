@@ -594,6 +594,35 @@ def test_scan_slice_balance_and_tails(dev):
         G.close()
 
 
+@pytest.mark.parametrize("N,Q,k", [(40001, 2048, 10), (70003, 2300, 10), (120000, 2064, 10), (33000, 3000, 50),
+                                   (300000, 2560, 5)])
+def test_phases_of_query_tiles_vs_oracle(dev, N, Q, k):
+    """Eight query tiles and more: the scan launch is a sequence of phases (8 a query tiles pinned a per XCD with 32 / a
+    slices each, largest a first, then the remaining < 8 query tiles with the slices of a small launch: topk256.hip), phases
+    have different slice counts and the segment slots a phase does not use are closed by its slice 0.  Ragged last query
+    tiles (2300 = 8 x 256 + 252; 2064 = 8 x 256 + 16: a tail launch or a ninth tile, as the cost model decides), the margin
+    form (k = 50), best rows planted in the gallery's first scanned and very last rows and at every query tile's edges."""
+    D = 64
+    rng = np.random.default_rng(N + Q + k)
+    gal = rng.standard_normal((N, D), dtype=np.float32)
+    qr = rng.standard_normal((Q, D), dtype=np.float32)
+    plant = sorted(set([0, 255, 256, 257, Q - 1] + [t * 256 for t in range(1, Q // 256)] + [t * 256 - 1 for t in range(1, Q // 256 + 1)]))
+    rows = np.linspace(N - 1, N // 2, num=len(plant)).astype(np.int64)     # one distinct gallery row per planted query
+    rows[0] = N - 1
+    for qi, r in zip(plant, rows):
+        gal[r] = qr[qi]
+    G = engine.Gallery(D, N, device=0)
+    G.add(torch.from_numpy(gal).to(dev))
+    plan = G.search_plan(Q, k)
+    assert plan["scan256"] and 2 <= plan["slices"] <= 512, plan             # segment slots per query: the most slices of any phase
+    out = G.search(torch.from_numpy(qr).to(dev), k)
+    _check(out, osearch.search(gal, qr, k), atol=1e-5, near_tie=3e-7)      # (150 000 places: fp32 and fp64 orders differ at ~1e-7)
+    for qi, r in zip(plant, rows):
+        assert int(out[1][qi, 0]) == int(r), (qi, r)
+    _check(G.search(torch.from_numpy(qr).to(dev), k, 0.35), osearch.search(gal, qr, k, 0.35), atol=1e-5, near_tie=3e-7)
+    G.close()
+
+
 def test_config4_gallery_10m_x_1536(dev):
     """BASELINE.json configs[4]'s gallery as written: 10 M x 1536 (bf16 scan copy 30.7 GB + fp32 master 61 GB of
     the 288 GB), 256 queries, through the 256 x 256 scan.  The CPU oracle cannot hold this; what is checked:

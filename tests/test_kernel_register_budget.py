@@ -51,17 +51,48 @@ def scan_usage():
 
 
 def test_plain_scan_forms_do_not_spill_vectors(scan_usage):
-    """topk_scan256_kernel<KSEL, ROWS, MARGIN = false>: the forms every search with k <= 25 runs."""
+    """topk_scan256_kernel<KSEL, ROWS, MARGIN = false>: the forms every search with k <= 25 runs.  (Round 5: the slice
+    bounds as 32-bit scalars -- as `long` they lived in vector registers, the hardware has no scalar 64-bit order compare --
+    took the 192-row forms from 9 spilled registers to 2 and the margin form from 16 to 4; the 256-row forms park one
+    register outside the tile loop.)"""
     for ksel in (32, 64):
-        for rows, allowed in ((0, 0), (64, 0), (128, 0), (192, 9)):          # (the 192-row form has always spilled 9)
+        for rows, allowed in ((0, 1), (64, 0), (128, 0), (192, 2)):
             u = _find(scan_usage, "topk_scan256_kernel", f"ILi{ksel}ELi{rows}ELb0E")
             assert u["VGPRs"] <= 256 and u["VGPRs Spill"] <= allowed, (ksel, rows, u)
     # the margin forms (k > 25) are allowed their handful; the 192-row margin form must not exist (464 spills when built)
-    for rows, allowed in ((0, 16), (64, 0), (128, 2)):
+    for rows, allowed in ((0, 4), (64, 0), (128, 2)):
         u = _find(scan_usage, "topk_scan256_kernel", f"ILi64ELi{rows}ELb1E")
         assert u["VGPRs Spill"] <= allowed, (rows, u)
     assert not [k for k in scan_usage if "topk_scan256_kernel" in k and "ELi192ELb1E" in k]
     assert not [k for k in scan_usage if "topk_scan256_kernel" in k and "ILi32E" in k and "ELb1E" in k]
+
+
+def test_no_scratch_traffic_inside_the_tile_loop_of_the_scans():
+    """WHERE the parked registers are touched: never inside a scan's loop over gallery tiles, let alone its K loop, on the path
+    every tile takes.  A reload there waits for ALL vector memory (scratch shares the counter), i.e. for the next tile's
+    first operands, which are requested before the selection so that they fly during it: one build of round 5 reloaded an
+    LDS address in the per-tile flush and lost 9 % with a clean K loop.  Allowed: the 192-row forms' one reload in the
+    flush (measured with it), and the margin forms' reload of the drop-flag pointer on the retry path (rare)."""
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-S",
+                          "--cuda-device-only", "topk256.hip", "-o", "-"], cwd=CSRC, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    asm = out.stdout
+    seen = 0
+    for m in re.finditer(r"^(_ZN4revo19topk_scan256_kernelILi(\d+)ELi(\d+)ELb(\d)EEEvNS_11Scan256ArgsE):", asm, flags=re.M):
+        rows, margin = int(m.group(3)), int(m.group(4))
+        body = asm[m.end(): asm.index(".Lfunc_end", m.end())].splitlines()
+        depth, hot = 0, []
+        for ln in body:
+            if ln.startswith(".LBB") or ln.startswith("; %bb."):
+                dm = re.search(r"Depth=(\d+)", ln)
+                depth = int(dm.group(1)) if dm else 0
+            elif depth >= 1 and "scratch_" in ln:
+                hot.append((depth, ln.strip()))
+        seen += 1
+        assert not [h for h in hot if h[0] >= 2], (m.group(1), hot)            # K loop and the selection's inner loops
+        allowed = 1 if (rows == 192 or margin) else 0
+        assert len(hot) <= allowed, (m.group(1), hot)
+    assert seen == 11, seen
 
 
 def test_attention_kernel_keeps_four_waves_per_simd():
