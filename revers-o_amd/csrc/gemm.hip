@@ -277,6 +277,7 @@ __device__ __forceinline__ void gemm256_epilogue_f32_quarter(const GemmArgs& p, 
 template <int QT, bool PIN>
 __device__ __forceinline__ void gemm256_resid8_load(const GemmArgs& p, int m_base, int n_base, int lane, uint4 (&res)[4][2]) {
     typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+    asm volatile("" : "+v"(lane));       // (derived here, not ahead of the main loop: hoisted, the row / column offsets were parked in scratch)
     int gcol = n_base + (lane & 7) * 8;
     gcol = gcol < p.N ? gcol : p.N - 8;
 #pragma unroll
@@ -775,8 +776,8 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
     const int tall0 = tiles_m - p.t192_tall;
     const int gy = p.gy, gx = 8 / gy;
     const int xcd = blockIdx.x & 7;
-    const int xi = xcd / gy, xj = xcd - xi * gy;
-    const int pm = (tiles_m + gx - 1) / gx, pn = (tiles_n + gy - 1) / gy;
+    const int xi = __builtin_amdgcn_readfirstlane(xcd / gy), xj = xcd - xi * gy;
+    const int pm = __builtin_amdgcn_readfirstlane((tiles_m + gx - 1) / gx), pn = __builtin_amdgcn_readfirstlane((tiles_n + gy - 1) / gy);
     const int m_lo = xi * pm, n_lo = xj * pn;
     const int m_cnt = (tiles_m - m_lo) < pm ? (tiles_m - m_lo) : pm;
     const int n_cnt = (tiles_n - n_lo) < pn ? (tiles_n - n_lo) : pn;
@@ -798,8 +799,10 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
 
     // row origin / height of tile row mi
     auto tile_row0 = [&](int mi) { return BMR == 256 ? mi * 256 : mi * 192 + (mi > tall0 ? (mi - tall0) * 16 : 0); };
-    int mi = m_lo + slot / n_cnt;
-    int m0 = tile_row0(mi), n0 = (n_lo + slot % n_cnt) * 256;
+    // (integer divisions are vector-unit sequences: their wave-uniform results are moved to scalar registers at once)
+    int sq = __builtin_amdgcn_readfirstlane(slot / n_cnt);
+    int mi = m_lo + sq;
+    int m0 = tile_row0(mi), n0 = (n_lo + (slot - sq * n_cnt)) * 256;
     bool tall = BMR != 256 && mi >= tall0;
     // folded LayerNorm (kernels.h): consumer side of the bf16 epilogues, producer side of the residual epilogue
     const bool lnc = (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE) && p.lnc_stats != nullptr;
@@ -830,6 +833,13 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
         if constexpr (BMR == 256) gemm256_mainloop(A, B, smem, p.K, wave, lane, acc);
         else gemm256_mainloop<192>(A, B, smem, p.K, wave, lane, acc, tall);
 
+        // the epilogue's lane id comes from the hardware, here: `lane` kept alive across the main loop is parked in scratch by
+        // hipcc and reloaded at the head of every epilogue, behind a wait for all vector memory
+        // (not in the plain bf16 and RoPE forms: there the same change made hipcc park four accumulator registers across the
+        //  main loop's last K-tile instead)
+        int lane_e = lane;
+        if constexpr (EPI != EPI_BF16 && EPI != EPI_BF16_ROPE)
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
         const int mb = m0 + (wave >> 2) * 128, nb = n0 + (wave & 3) * 64;
         GemmArgs pe = p;                                   // the epilogue's row limit: the end of this tile
         if (BMR != 256) {
@@ -840,9 +850,10 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
         slot += nslot;
         const bool more = slot < total;
         if (more) {
-            mi = m_lo + slot / n_cnt;
+            sq = __builtin_amdgcn_readfirstlane(slot / n_cnt);
+            mi = m_lo + sq;
             m0 = tile_row0(mi);
-            n0 = (n_lo + slot % n_cnt) * 256;
+            n0 = (n_lo + (slot - sq * n_cnt)) * 256;
             tall = BMR != 256 && mi >= tall0;
             // the next tile's row statistics travel with its first K-tile: the raw slots are free again (merged before this
             // tile's main loop, whose barriers lie in between) and the DMA has the whole epilogue to land
@@ -855,19 +866,19 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
             g256_issue_half(B, 1, 0, G256_B(smem, 0), wave);
         }
         if constexpr (EPI == EPI_PATCH) {
-            gemm_epilogue<EPI, 8, 4>(pe, mb, nb, lane, acc);
+            gemm_epilogue<EPI, 8, 4>(pe, mb, nb, lane_e, acc);
         } else {
             const bool wide = (p.N & 7) == 0 && (p.ldc & 7) == 0;
-            if (wide) gemm256_epilogue<EPI, BMR != 256, XP>(pe, slab, mb, nb, lane, acc,
+            if (wide) gemm256_epilogue<EPI, BMR != 256, XP>(pe, slab, mb, nb, lane_e, acc,
                                                             lnf ? lds_st + (wave >> 2) * 128 * 4 + (wave & 3) : nullptr,
                                                             lnc ? lds_mr + (wave >> 2) * 128 : nullptr);
-            else gemm_epilogue<EPI, 8, 4>(pe, mb, nb, lane, acc);
+            else gemm_epilogue<EPI, 8, 4>(pe, mb, nb, lane_e, acc);
         }
         if (lnf) {
             // the four waves' 64-column partials of every row of this tile are in LDS: one slot per row and column tile
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                  // (also: every wave is out of its slab)
-            lnf_store_tile_stats(pe, lds_st, m0_done, pe.M, tn_done, wave, lane);
+            lnf_store_tile_stats(pe, lds_st, m0_done, pe.M, tn_done, wave, lane_e);
             if (!more) break;
             continue;                                      // the main loop's barriers separate these reads from the next tile's writes
         }

@@ -111,7 +111,9 @@ def test_body_gemm_kernels_stay_within_their_allocation():
     # side): the bf16 forms park 5-9 registers around the tile loop -- all OUTSIDE the K loop, which the next test checks
     # (one version of the merge kept a lane id alive across the main loop and put an accumulator spill INSIDE the RoPE
     # kernel's K loop: that is what the next test is for).
-    for epi, bmr, allowed in ((1, 256, 6), (2, 256, 2), (2, 192, 2), (5, 256, 10), (0, 256, 8)):
+    # (later in round 5: tile coordinates moved to scalar registers right after their integer divisions, the epilogue's lane
+    #  id read from the hardware behind the main loop in the GELU / residual forms: 6 -> 2, 2 -> 0, 10 -> 7, 8 -> 7)
+    for epi, bmr, allowed in ((1, 256, 2), (2, 256, 0), (2, 192, 0), (5, 256, 7), (0, 256, 7)):
         u = _find(d, "gemm256p_kernel", f"ILi{epi}ELi{bmr}ELi0E")
         assert u["VGPRs"] <= 256 and u["VGPRs Spill"] <= allowed, (epi, bmr, u)
     # the residual stream in two bf16 planes: one instantiation per format pair (XP 1..3).  With the formats as run-time
@@ -120,7 +122,7 @@ def test_body_gemm_kernels_stay_within_their_allocation():
     for bmr in (192, 256):
         for xp in (1, 2, 3):
             u = _find(d, "gemm256p_kernel", f"ILi2ELi{bmr}ELi{xp}E")
-            assert u["VGPRs"] <= 256 and u["VGPRs Spill"] <= 2, (bmr, xp, u)
+            assert u["VGPRs"] <= 256 and u["VGPRs Spill"] == 0, (bmr, xp, u)
     for epi in (0, 1, 2, 5):
         u = _find(d, "gemm256_kernel", f"ILi{epi}ELi0E")
         assert u["VGPRs Spill"] == 0, (epi, u)
