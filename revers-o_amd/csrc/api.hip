@@ -1077,7 +1077,10 @@ extern "C" int32_t revo_search_topk(revo_gallery* g, const float* queries, int32
     // candidates per query: 32 for k <= 16, 64 beyond -- and 64 on very large galleries whatever k is: there a query
     // that fails its certificate costs a whole extra pass over the gallery (10 M x 1536: 5.9 ms next to a 7.7 ms scan),
     // and the wider list all but rules that out (the k-th to 64th score gap is 1.6 x the k-th to 32nd) for 0.1 ms of re-scores
-    const int ksel = g->size >= SEARCH_WIDE_ROWS ? 64 : search_ksel(k);
+    int ksel = g->size >= SEARCH_WIDE_ROWS ? 64 : search_ksel(k);
+#ifdef REVO_EXPERIMENTS
+    if (const char* e = getenv("REVO_KSEL")) ksel = atoi(e) == 64 ? 64 : ksel;         // candidate-list width study (scripts/)
+#endif
     // k > 25: 64 candidates leave the certificate less room than its error bound on ordinary data (the 50th-to-64th score
     // gap of a random 1 M gallery is half of eps), so nearly every query fails it.  The scan then runs with an admission
     // margin of 2 eps: what an uncertified query needs is in its segments, and no second pass over the gallery is made
