@@ -209,6 +209,10 @@ int launch_topk_reduce(uint64_t* part, int Q, int splits, int ksel, hipStream_t 
 }
 
 // ----------------------------------------------------------- the finish ----
+// WIDE (few queries): one workgroup per query, its four waves share the fp32 re-scores -- a wave re-scores four candidates
+// per HBM round trip, 32 candidates are eight round trips in a row for one wave (28 us of a one-query search) and two for four.
+// Every candidate keeps its own fma chain: the scores are the same bits.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __restrict__ part, long part_stride, int ksel,
                                                           const float* __restrict__ Qf, long ldqf,
                                                           const float* __restrict__ Gf, long ldgf, int D, int Q, int k,
@@ -217,8 +221,9 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __rest
                                                           float* __restrict__ out_scores,
                                                           long long* __restrict__ out_idx, int* __restrict__ out_counts,
                                                           int has_cert, CertArgs cert) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ float wide_sc[WIDE ? 64 : 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = WIDE ? (int)blockIdx.x : (int)blockIdx.x * 4 + wv;
     if (q >= Q) return;
     const uint64_t key = lane < ksel ? part[(long)q * part_stride + lane] : 0ull;
     // Row-sharded gallery: every shard has published the (bf16-scan) scores of its best top_m candidates for this
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __rest
         const float* qr = Qf + (long)q * ldqf;
         // four candidates at a time: their row reads are independent, so the HBM round trips overlap
         // (each candidate keeps its own fma chain in the same order: the scores do not change)
-        for (int cnd0 = 0; cnd0 < nv; cnd0 += 4) {
+        for (int cnd0 = WIDE ? wv * 4 : 0; cnd0 < nv; cnd0 += WIDE ? 16 : 4) {
             const float* gr[4];
             float t[4];
 #pragma unroll
@@ -279,9 +284,17 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __rest
             exact_dot4(qr, gr, D, lane, t);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (lane == cnd0 + u && cnd0 + u < nv) score = t[u];
+                if (lane == cnd0 + u && cnd0 + u < nv) {
+                    if (WIDE) wide_sc[lane] = t[u];
+                    else score = t[u];
+                }
         }
-    }
+        if (WIDE) {
+            __syncthreads();
+            if (wv != 0) return;                   // wave 0 carries on with all the scores
+            if (lane < nv) score = wide_sc[lane];
+        }
+    } else if (WIDE && wv != 0) return;
     uint64_t k2 = valid ? make_key(score, idx) : 0ull;
     k2 = wave_sort_desc(k2, lane);
     const bool ok = k2 != 0ull && lane < k && (!has_thr || key_score(k2) >= thr);
@@ -372,9 +385,14 @@ int launch_topk_finish(const uint64_t* part, long part_stride, int ksel, const f
     CertArgs c{};
     const int has_cert = cert ? 1 : 0;
     if (has_cert) c = *cert;
-    hipLaunchKernelGGL(topk_finish_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, part, part_stride, ksel, Qf, ldqf, Gf,
-                       ldgf, D, Q, k, has_thr, thr, idx_offset, all_bounds, parts, top_m, out_scores, out_idx, out_counts,
-                       has_cert, c);
+    if (Q <= 256 && Gf)
+        hipLaunchKernelGGL(topk_finish_kernel<true>, dim3(Q), dim3(256), 0, st, part, part_stride, ksel, Qf, ldqf, Gf,
+                           ldgf, D, Q, k, has_thr, thr, idx_offset, all_bounds, parts, top_m, out_scores, out_idx, out_counts,
+                           has_cert, c);
+    else
+        hipLaunchKernelGGL(topk_finish_kernel<false>, dim3((Q + 3) / 4), dim3(256), 0, st, part, part_stride, ksel, Qf, ldqf, Gf,
+                           ldgf, D, Q, k, has_thr, thr, idx_offset, all_bounds, parts, top_m, out_scores, out_idx, out_counts,
+                           has_cert, c);
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
