@@ -967,7 +967,15 @@ static int search_candidates(revo_gallery* g, const float* queries, int Q, int k
             ga.A = g->qb; ga.lda = D; ga.B = g->gb; ga.ldb = D; ga.M = Q; ga.N = (int)n_pre; ga.K = D;
             ga.C = pre_scores; ga.ldc = n_pre; ga.prefer256 = 1;
             // (few queries: the skinny form instead -- measured: pre-pass 48 -> 37 us at one query, 50 -> 57 at 64; nothing in the search)
-            CHECK_RC(launch_gemm(EPI_F32, ga, st));
+            // Up to 128 queries: 128 x 64 tiles on the six-deep ring (two rounds of workgroups with five K-steps of loads in
+            // flight; one 256 x 256 tile per CU is a chain of sixteen DMA latencies): pre-pass 48 -> 40 us at one query,
+            // 49 -> 42 at 64, 52 -> 46 at 128
+            bool ring = Q <= 128 && n_pre % 64 == 0;
+#ifdef REVO_EXPERIMENTS
+            if (getenv("REVO_PREPASS_256")) ring = false;
+#endif
+            if (ring) CHECK_RC(launch_gemm_f32_ring(ga, st));
+            else CHECK_RC(launch_gemm(EPI_F32, ga, st));
             // One shard of a larger gallery, in the two-phase search: what its candidates have to reach is decided by ALL
             // shards' rows (the finish step re-scores only candidates among the best min(64, 2 ksel) of the whole gallery),
             // but its scan can only learn its own rows' scores -- at an eighth of the rows its admission bound sits at an

@@ -1569,6 +1569,25 @@ static int launch_128(const GemmArgs& a, hipStream_t st) {
     return 0;
 }
 
+// Few rows against very many columns with a plain fp32 output (the search pre-pass of up to 128 queries): 128 x 64 tiles
+// on the six-deep ring, a round or two of workgroups whose K loops keep five steps of loads in flight (one 256 x 256 tile
+// per CU is a chain of sixteen DMA latencies).
+int launch_gemm_f32_ring(const GemmArgs& a, hipStream_t st) {
+    if (const char* e = check_args(a)) {
+        revo_set_error(e);
+        return -2;
+    }
+    REVO_REQUIRE(a.N % 64 == 0 && a.K % 64 == 0, "gemm ring: N and K must be multiples of 64");
+    const int tiles64 = ((a.M + 127) / 128) * ((a.N + 63) / 64);
+    constexpr int LDS = G128R_NST * (128 + 64) * 128;
+    REVO_FUNC_LDS((gemm128r_kernel<EPI_F32>), LDS);
+    GemmArgs b = a;
+    b.ksplit = 1;
+    hipLaunchKernelGGL((gemm128r_kernel<EPI_F32>), dim3(tiles64), dim3(GEMM_THREADS), LDS, st, b);
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
     if (const char* e = check_args(a)) {
         revo_set_error(e);

@@ -63,6 +63,8 @@ struct GemmArgs {
 // true when launch_gemm would run the 256 x 256 kernel with the row-coalesced epilogue for these sizes
 bool gemm_uses_wide_epilogue(int M, int N, long lda, long ldb, long ldc);
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);
+// EPI_F32 on 128 x 64 ring tiles whatever the tile count (few rows x very many columns: the search pre-pass of few queries)
+int launch_gemm_f32_ring(const GemmArgs& a, hipStream_t st);
 // true when launch_gemm(EPI_RESID_F32) would take one of the two launch forms that can fold the LayerNorm behind it (and
 // keep the residual stream in planes): the persistent 256-row kernel over ALL rows
 bool gemm_resid_folds(int M, int N, int K, long lda, long ldb, long ldc);

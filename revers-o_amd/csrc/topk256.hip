@@ -678,10 +678,18 @@ __global__ __launch_bounds__((RW == 1 ? 4 : RW) * 64) void topk_reduce_segs_kern
     if (RW == 1 && q >= Q) return;
     uint64_t* ws = wsb[wv];
     uint64_t run = (w == 0 && lane < KSEL) ? prelist[q * KSEL + lane] : 0ull;
-    uint64_t chunk = 0ull;
     int fill = 0;                                      // wave-uniform
     const int* cq = seg_cnt + q * splits;
     const uint64_t* sq = seg + q * (long)splits * SEG;
+    // A chunk is first laid out from the counts alone -- lane l takes entry src_off of its slices, whole segments as before --
+    // and then fetched by ONE gather.  (A load per non-empty slice, each waited for before the next could be merged into the
+    // chunk register, was a chain of 20-30 memory round trips per wave: 18 of a one-query search's 440 us.)
+    long src_off = 0;                                  // this lane's entry of the chunk being laid out: offset into sq
+    auto fold = [&]() {
+        const uint64_t chunk = lane < fill ? sq[src_off] : 0ull;
+        run = s256_fold_chunk<KSEL>(run, chunk, ws, lane);
+        fill = 0;
+    };
     // this wave's counts, one slice per lane (slices w + RW * lane), 64 slices at a time
     for (int sb = w; sb < splits; sb += RW * 64) {
         const int my = sb + RW * lane;
@@ -690,21 +698,21 @@ __global__ __launch_bounds__((RW == 1 ? 4 : RW) * 64) void topk_reduce_segs_kern
         for (int i = 0; i < (nlan < 64 ? nlan : 64); ++i) {
             int c = __builtin_amdgcn_readlane(cl, i);
             if (c <= 0) continue;
-            const uint64_t* sp = sq + (long)(sb + RW * i) * SEG;
+            const long sp = (long)(sb + RW * i) * SEG;
             int done = 0;
             while (done < c) {
                 int take = c - done;
                 if (fill + take > 64) {
-                    if (fill > 0) { run = s256_fold_chunk<KSEL>(run, chunk, ws, lane); chunk = 0ull; fill = 0; }
+                    if (fill > 0) fold();
                     take = take < 64 ? take : 64;
                 }
-                if (lane >= fill && lane < fill + take) chunk = sp[done + lane - fill];
+                if (lane >= fill && lane < fill + take) src_off = sp + done + lane - fill;
                 fill += take;
                 done += take;
             }
         }
     }
-    if (fill > 0) run = s256_fold_chunk<KSEL>(run, chunk, ws, lane);
+    if (fill > 0) fold();
     if constexpr (RW == 1) {
         if (lane < KSEL) out[q * KSEL + lane] = run;
         // row-sharded search: the scan scores of the best top_m candidates, published for the bound exchange (was a launch of its own)
