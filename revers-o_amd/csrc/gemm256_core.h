@@ -153,6 +153,15 @@ __device__ __forceinline__ void g256_issue_prologue(const G256Operand& A, const 
         g256_issue_half(A, 1, 128, G256_A(smem, 1), wave);
     }
 }
+// for gemm256_mainloop<ROWS, RT, DEEP = true>: the first TWO K-tiles complete
+__device__ __forceinline__ void g256_issue_prologue_deep(const G256Operand& A, const G256Operand& B, char* smem, int K,
+                                                         int wave) {
+    g256_issue_prologue(A, B, smem, K, wave);
+    if (K > 64) {
+        g256_issue_half(B, 0, 128, G256_B(smem, 1), wave);
+        g256_issue_half(B, 1, 128, G256_B(smem, 1), wave);
+    }
+}
 
 // K % 64 == 0, K >= 64.  acc must be zero-initialised (or hold the running sum) by the caller,
 // and g256_issue_prologue(A, B, ...) must have been issued by this wave (any vector-memory
@@ -170,7 +179,13 @@ __device__ __forceinline__ void g256_issue_prologue(const G256Operand& A, const 
 // 64 rows; `tall`: only the first fragment of its second 64) -- the phased persistent kernel, whose workgroups cut their
 // first tile into two pieces of different heights (gemm.hip gemm256pp_kernel).  Same instruction stream per active part,
 // so every row's result has the bits the fixed modes give it.
-template <int ROWS = 0, bool RT = false>
+// DEEP = true (the HBM-bound row modes of the scan): BOTH operands of K-tile t + 2 are requested behind the barrier of
+// tile t's third phase, when every wave has finished reading the stage they go to -- a K-tile and a half ahead of their
+// use -- and nothing in the first two phases; the wait leaves those eight DMA instructions in flight (vmcnt(8)).  In the
+// ordinary schedule B of tile t + 1 is requested half a tile ahead: with MFMA work for 64 query rows only a K-tile takes
+// about as long as the CU's share of HBM delivers its 32 KiB (1.3 us), less than a DMA's latency, and the loop ran at
+// one gallery K-tile per latency: 5.3 of the 6.3 TB/s a copy reaches.
+template <int ROWS = 0, bool RT = false, bool DEEP = false>
 __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G256Operand& B, char* smem, int K,
                                                  int wave, int lane, f32x4 (&acc)[8][4], bool tall = false,
                                                  bool rt_lo = true, bool rt_hi = true) {
@@ -186,7 +201,8 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
     g256_addr_init(ad, wave, lane);
 
     if (nt > 1) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (DEEP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -204,13 +220,13 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             // P0
             G256_HI(g256_read_a<64, 0>(f.ahi, ad.a););
             G256_HT(g256_read_a1<64, 0>(f.ahi, ad.a););
-            if (n1) g256_issue_half(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
+            if (!DEEP && n1) g256_issue_half(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_LO(g256_cluster<0, 0>(f.alo, f.blo, acc););
             G256_FENCE();
             // P1
             G256_LO(g256_read_b<32, 0>(f.bhi, ad.b););
-            if (n1) g256_issue_half(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
+            if (!DEEP && n1) g256_issue_half(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
             G256_HT(g256_cluster1<4, 0>(f.ahi, f.blo, acc););
@@ -219,14 +235,16 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (n2) g256_issue_half(A, 0, (t + 2) * 128, G256_A(smem, 0), wave);
+            if (DEEP && n2) g256_issue_half(B, 0, (t + 2) * 128, G256_B(smem, 0), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 2>(f.ahi, f.bhi, acc););
             G256_HT(g256_cluster1<4, 2>(f.ahi, f.bhi, acc););
             G256_FENCE();
             // P3: publish tile t+1, start reading it
             if (n2) g256_issue_half(A, 1, (t + 2) * 128, G256_A(smem, 0), wave);
+            if (DEEP && n2) g256_issue_half(B, 1, (t + 2) * 128, G256_B(smem, 0), wave);
             if (n1) {
-                if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (n2) { if (DEEP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 G256_HI(g256_read_a<64, 1>(f.ahi, ad.a););          // odd tiles start with A-hi
@@ -243,14 +261,14 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             const bool n1 = u + 1 < nt, n2 = u + 2 < nt;
             // P0'
             G256_LO(g256_read_a<0, 1>(f.alo, ad.a););
-            if (n1) g256_issue_half(B, 0, (u + 1) * 128, G256_B(smem, 0), wave);
+            if (!DEEP && n1) g256_issue_half(B, 0, (u + 1) * 128, G256_B(smem, 0), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
             G256_HT(g256_cluster1<4, 0>(f.ahi, f.blo, acc););
             G256_FENCE();
             // P1'
             G256_LO(g256_read_b<32, 1>(f.bhi, ad.b););
-            if (n1) g256_issue_half(B, 1, (u + 1) * 128, G256_B(smem, 0), wave);
+            if (!DEEP && n1) g256_issue_half(B, 1, (u + 1) * 128, G256_B(smem, 0), wave);
             G256_FENCE();
             G256_LO(g256_cluster<0, 0>(f.alo, f.blo, acc););
             G256_FENCE();
@@ -258,13 +276,15 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (n2) g256_issue_half(A, 0, (u + 2) * 128, G256_A(smem, 1), wave);
+            if (DEEP && n2) g256_issue_half(B, 0, (u + 2) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_LO(g256_cluster<0, 2>(f.alo, f.bhi, acc););
             G256_FENCE();
             // P3'
             if (n2) g256_issue_half(A, 1, (u + 2) * 128, G256_A(smem, 1), wave);
+            if (DEEP && n2) g256_issue_half(B, 1, (u + 2) * 128, G256_B(smem, 1), wave);
             if (n1) {
-                if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (n2) { if (DEEP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 G256_LO(g256_read_a<0, 0>(f.alo, ad.a););               // even tiles start with A-lo
@@ -283,13 +303,13 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             // P0
             G256_HI(g256_read_a<64, 0>(f.ahi, ad.a););
             G256_HT(g256_read_a1<64, 0>(f.ahi, ad.a););
-            if (n1) g256_issue_half(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
+            if (!DEEP && n1) g256_issue_half(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_LO(g256_cluster<0, 0>(f.alo, f.blo, acc););
             G256_FENCE();
             // P1
             G256_LO(g256_read_b<32, 0>(f.bhi, ad.b););
-            if (n1) g256_issue_half(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
+            if (!DEEP && n1) g256_issue_half(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
             G256_HT(g256_cluster1<4, 0>(f.ahi, f.blo, acc););
@@ -298,14 +318,16 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (n2) g256_issue_half(A, 0, (t + 2) * 128, G256_A(smem, 0), wave);
+            if (DEEP && n2) g256_issue_half(B, 0, (t + 2) * 128, G256_B(smem, 0), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 2>(f.ahi, f.bhi, acc););
             G256_HT(g256_cluster1<4, 2>(f.ahi, f.bhi, acc););
             G256_FENCE();
             // P3: publish tile t+1, start reading it
             if (n2) g256_issue_half(A, 1, (t + 2) * 128, G256_A(smem, 0), wave);
+            if (DEEP && n2) g256_issue_half(B, 1, (t + 2) * 128, G256_B(smem, 0), wave);
             if (n1) {
-                if (n2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (n2) { if (DEEP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 G256_HI(g256_read_a<64, 1>(f.ahi, ad.a););          // odd tiles start with A-hi

@@ -379,6 +379,8 @@ struct Scan256Args {
 template <int KSEL, int ROWS, bool MARGIN = false>
 __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Args p) {
     constexpr int SEG = 2 * KSEL;
+    // up to 128 queries the loop runs at the HBM rate: operands are requested a K-tile and a half ahead (gemm256_core.h)
+    constexpr bool DEEP = ROWS == 64 || ROWS == 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     S256Lds L;
     L.queue = (uint64_t*)(smem + G256_LDS);
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     G256Operand A, B;
     g256_operand_init(A, p.Qb, p.ldq, p.Q, q0, wave, lane);
     g256_operand_init(B, p.Gb + row_begin * p.ldg, p.ldg, p.N - row_begin, 0, wave, lane);
-    g256_issue_prologue(A, B, smem, p.D, wave);
+    if constexpr (DEEP) g256_issue_prologue_deep(A, B, smem, p.D, wave); else g256_issue_prologue(A, B, smem, p.D, wave);
     // Slices that start after others have run (later rounds of workgroups on this CU) begin with what those have
     // learnt, not with the pre-pass bound: one refresh while the first operands are in flight.  (Without it every
     // slice's first tile admitted about one score per row: at 24 tiles per slice a third of all slow fragments.)
@@ -483,12 +485,12 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
                 for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             // few queries: most of the tile's MFMA work would multiply zero rows (separate kernel
             // instantiations: inside one kernel a second main loop costs the main path its register allocation)
-            gemm256_mainloop<ROWS>(A, B, smem, p.D, wave, lane, acc);
+            gemm256_mainloop<ROWS, false, DEEP>(A, B, smem, p.D, wave, lane, acc);
 
             if (groups == 1 && t + 1 < t1) {
                 // next gallery tile: rebased descriptors (any gallery size), DMA in flight during the selection
                 g256_operand_init(B, p.Gb + (n0 + 256) * p.ldg, p.ldg, p.N - (n0 + 256), 0, wave, lane);
-                g256_issue_prologue(A, B, smem, p.D, wave);
+                if constexpr (DEEP) g256_issue_prologue_deep(A, B, smem, p.D, wave); else g256_issue_prologue(A, B, smem, p.D, wave);
             }
             asm volatile("" : "+v"(lane) :: "memory");
             const int lr = lane & 15, lq = lane >> 4;
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
         if (t < t1) {
             const long nn = p.n_begin + (long)t * 256;
             g256_operand_init(B, p.Gb + nn * p.ldg, p.ldg, p.N - nn, 0, wave, lane);
-            g256_issue_prologue(A, B, smem, p.D, wave);
+            if constexpr (DEEP) g256_issue_prologue_deep(A, B, smem, p.D, wave); else g256_issue_prologue(A, B, smem, p.D, wave);
         }
     }
     if (tid < qvalid) {
