@@ -437,20 +437,50 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     if (row >= rows) return;
     const float* s = src + row * ld_src;
     float inv = 1.0f;
-    if (normalize) {
-        float q = 0.f;
-        for (int c = lane; c < D; c += 64) q = fmaf(s[c], s[c], q);
-        q = wave_sum(q);
-        inv = q > 0.f ? 1.0f / sqrtf(q) : 1.0f;
-    }
     float ny = 0.f, nb = 0.f, ne = 0.f;
-    for (int c = lane; c < D; c += 64) {
-        const float y = s[c] * inv;
-        const bf16_t yb = f32_to_bf16(y);
-        if (dst_f32) dst_f32[row * ld_f32 + c] = y;
-        if (dst_bf16) dst_bf16[row * ld_bf16 + c] = yb;
-        const float fb = bf16_to_f32(yb), d = fb - y;         // the difference of two neighbouring floats is exact
-        ny = fmaf(y, y, ny); nb = fmaf(fb, fb, nb); ne = fmaf(d, d, ne);
+    constexpr int NV = 32;                    // rows of up to 64 NV = 2048 elements are held in registers
+    if (D <= 64 * NV) {
+        // every load of the row requested before the first is used, and the row read once: with a load inside each step of
+        // the two fma chains a one-row call (the search's query) was 32 memory round trips in a row, 12 us of a 430 us
+        // search.  Same element order per lane as the loops below: same bits.
+        float v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = lane + 64 * i < D ? s[lane + 64 * i] : 0.f;
+        if (normalize) {
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (lane + 64 * i < D) q = fmaf(v[i], v[i], q);
+            q = wave_sum(q);
+            inv = q > 0.f ? 1.0f / sqrtf(q) : 1.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                const float y = v[i] * inv;
+                const bf16_t yb = f32_to_bf16(y);
+                if (dst_f32) dst_f32[row * ld_f32 + c] = y;
+                if (dst_bf16) dst_bf16[row * ld_bf16 + c] = yb;
+                const float fb = bf16_to_f32(yb), d = fb - y;     // the difference of two neighbouring floats is exact
+                ny = fmaf(y, y, ny); nb = fmaf(fb, fb, nb); ne = fmaf(d, d, ne);
+            }
+        }
+    } else {
+        if (normalize) {
+            float q = 0.f;
+            for (int c = lane; c < D; c += 64) q = fmaf(s[c], s[c], q);
+            q = wave_sum(q);
+            inv = q > 0.f ? 1.0f / sqrtf(q) : 1.0f;
+        }
+        for (int c = lane; c < D; c += 64) {
+            const float y = s[c] * inv;
+            const bf16_t yb = f32_to_bf16(y);
+            if (dst_f32) dst_f32[row * ld_f32 + c] = y;
+            if (dst_bf16) dst_bf16[row * ld_bf16 + c] = yb;
+            const float fb = bf16_to_f32(yb), d = fb - y;
+            ny = fmaf(y, y, ny); nb = fmaf(fb, fb, nb); ne = fmaf(d, d, ne);
+        }
     }
     if (!row_stats && !max_stats) return;
     ny = sqrtf(wave_sum(ny)); nb = sqrtf(wave_sum(nb)); ne = sqrtf(wave_sum(ne));
