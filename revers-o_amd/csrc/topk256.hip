@@ -40,8 +40,8 @@ constexpr int S256_SH = 17;              // bucket width: 2^17 ulps of the fp32 
 // vmcnt wait of its next main loop.  The price: the eight XCDs hold eight partial copies of a histogram.  That is
 // safe -- a copy is "what memory held when the line was fetched" plus this XCD's own increments, so it never
 // exceeds the true count and the derived bound only lags -- and nearly free: the launcher maps all slices of a
-// query tile to one XCD whenever there are at least 8 query tiles (fewer query tiles: each XCD tightens on its
-// own eighth of the gallery, and the scan is HBM-bound there anyway).
+// query tile to one XCD in every phase of 8 a query tiles (fewer than 8 query tiles, or left over: each XCD tightens on
+// its own share of the gallery, and with few queries the scan is HBM-bound anyway).
 #define S256_HIST_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
 // main-loop image + queue + staging + tau / base / start / end / cnt (256 x 4 B each) + ctrl + merge scratch + wkey
 constexpr int S256_LDS = G256_LDS + S256_QCAP * 8 + S256_STG * 8 + 256 * 4 * 5 + 64 + 8 * 128 * 8 + 256 * 8;
