@@ -454,7 +454,7 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
                                                                         uint32_t* __restrict__ tau_copy, float est_z) {
     __shared__ uint64_t partial[SEL_MAXW][64];
     __shared__ float mom[SEL_MAXW][3];          // est_z != 0: per-wave count, sum, sum of squares of the strip's scores
-    __shared__ uint64_t cand[SEL_MAXW][64];     // per wave: survivors of pass 2, compacted
+    __shared__ uint64_t cand[SEL_MAXW][128];    // per wave: survivors of pass 2, compacted (up to two sorts' worth)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nw = blockDim.x >> 6;
     const int q = blockIdx.x;
@@ -517,7 +517,9 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
         if (lane >= o) incl += t;
     }
     const int total = __builtin_amdgcn_readlane(incl, 63);
-    if (total <= 64) {
+    // (up to 128: about 45 of a strip's 4096 scores reach T, 64 is 2.8 sigma away -- with 64 queries some wave of the launch
+    //  passed it in most searches and the whole launch waited for its chunked walk: 28 us against 16 for one query)
+    if (total <= 128) {
         int pos = incl - mine;
 #pragma unroll
         for (int i = 0; i < SEL_NV; ++i)
@@ -527,6 +529,12 @@ __global__ __launch_bounds__(SEL_MAXW * 64) void topk_select_rows_kernel(const f
                 if (sv >= tau && sv > -INFINITY) cand[w][pos++] = make_key(sv, (uint32_t)(c0 + (i * 64 + lane) * 4 + e));
             }
         cnt = total;
+        if (total > 64) {
+            cnt = 64;
+            sel_flush<KSEL>(run, tau, cnt, cand[w], lane);          // the first 64; the rest below, from cand[w] + 64
+            cnt = total - 64;
+            sel_flush<KSEL>(run, tau, cnt, cand[w] + 64, lane);
+        }
     } else {
 #pragma unroll
     for (int i = 0; i < SEL_NV; ++i) {
