@@ -241,6 +241,10 @@ int32_t revo_op_set_ln_fold(int32_t on);
  * bit 13 = skip the scan's selection, bit 15 = skip the scan's slow path (all four: WRONG RESULTS),
  * bit 14 = count scan events for revo_debug_scan_stats. */
 int32_t revo_op_set_gemm_debug(int32_t flags);
+/* The phases of the scan launch of a search of Q queries over `rows` scanned gallery rows (host logic only, no device):
+ * out[0] = phases, out[1] = segment slots per query, then per phase: first block, first query tile, query tiles, slices.
+ * Returns the number of workgroups of the launch (-1: bad arguments). */
+int64_t revo_debug_scan_plan(int32_t Q, int64_t rows, int64_t* out, int32_t cap);
 /* 1 if a forward of `batch` images keeps the residual stream in two bf16 planes between its folded GEMMs (reporting) */
 int32_t revo_debug_stream_in_planes(const revo_vit* vit, int32_t batch);
 /* copies bytes of the handle's search workspace to host_dst (host_dst NULL: returns the workspace size) */

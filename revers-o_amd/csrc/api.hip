@@ -1349,6 +1349,11 @@ extern "C" int32_t revo_op_set_gemm_debug(int32_t flags) {
     revo::topk_scan256_set_debug(((flags >> 13) & 7) | (((flags >> 20) & 255) << 3));
     return revo_op_set_variant(flags);
 }
+// the scan launch's phases for Q queries over `rows` scanned rows: host logic only, no device needed (CPU-tier tests)
+extern "C" int64_t revo_debug_scan_plan(int32_t Q, int64_t rows, int64_t* out, int32_t cap) {
+    if (Q < 1 || rows < 1 || !out || cap < 2) return -1;
+    return (int64_t)revo::topk_scan256_plan_dump(Q, (long)rows, (long*)out, cap);
+}
 // whether the forward keeps the residual stream in planes for this many rows of this tower (reporting / tests)
 extern "C" int32_t revo_debug_stream_in_planes(const revo_vit* v, int32_t batch) {
     if (!v || !v->xlo) return 0;

@@ -259,6 +259,7 @@ int topk_scan256_splits(int Q, long rows);
 // queries the main launch of a search takes; the rest (a ragged tail of <= 128 queries) runs as a second launch in the
 // small-query mode of the kernel when that is cheaper (Q = one launch)
 int topk_scan256_main_queries(int Q, long rows);
+long topk_scan256_plan_dump(int Q, long rows, long* out, int cap);   // the launch's phases (reporting / CPU tests)
 int topk_scan256_hist_buckets();      // u32 counters per query in `hist`
 int topk_scan256_hist_shift();        // bucket width = 2^shift ulps of the fp32 score above the pre-pass bound
 #ifdef REVO_EXPERIMENTS

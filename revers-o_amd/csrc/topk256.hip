@@ -877,6 +877,22 @@ int launch_topk_scan256(const bf16_t* Qb, long ldq, const bf16_t* Gb, long ldg, 
     return 0;
 }
 
+// the phases of the launch for Q queries over `rows` scanned rows (host logic only; tests/test_host_logic.py through the
+// experiment library): out[0] = phases, out[1] = segment slots per query, then per phase: first block, first query tile,
+// query tiles, slices.  Returns the number of blocks.
+long topk_scan256_plan_dump(int Q, long rows, long* out, int cap) {
+    const long tiles = (rows + 255) / 256;
+    Scan256Plan pl;
+    scan256_plan((Q + 255) / 256, tiles < 1 ? 1 : tiles, pl);
+    long blocks = 0;
+    if (cap >= 2) { out[0] = pl.nph; out[1] = pl.splits; }
+    for (int i = 0; i < pl.nph; ++i) {
+        if (cap >= 2 + 4 * (i + 1)) { out[2 + 4 * i] = blocks; out[3 + 4 * i] = pl.q0[i]; out[4 + 4 * i] = pl.qn[i]; out[5 + 4 * i] = pl.ns[i]; }
+        blocks += (long)pl.qn[i] * pl.ns[i];
+        if (i + 1 < pl.nph) blocks = (blocks + 7) / 8 * 8;
+    }
+    return blocks;
+}
 int topk_scan256_splits(int Q, long rows) {
     const long tiles = (rows + 255) / 256;
     if (tiles <= 0) return 1;
