@@ -400,25 +400,35 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
                 c4[n] = col < p.N ? *(const f32x4*)(p.lnc_c + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
+        f32x4 rtab_next[8][2];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (SKIP_DEAD && m_base + half * 64 >= p.M) break;          // wave-uniform
             asm volatile("" : "+v"(lane) :: "memory");
             const int lr = lane & 15, lq = lane >> 4;
-            // RoPE table entries of this half's 8 store steps, requested before the LDS transpose so that
-            // their latency is not paid once per step (a lane holds 4 interleaved pairs of one token)
-            f32x4 rtab[8][2];
-            if (EPI == EPI_BF16_ROPE) {
+            // RoPE table entries of a half's 8 store steps, requested before the LDS transpose so that
+            // their latency is not paid once per step (a lane holds 4 interleaved pairs of one token).  The second half's
+            // are requested behind the first half's fragment phase (its accumulators are dead by then) and BEFORE the first
+            // half's stores: loads and stores retire in order, and behind those stores the wait for them was a drain.
+            auto rope_load = [&](int hf, f32x4 (&rt)[8][2]) {
                 const int gcol_ = n_base + (lane & 7) * 8;
-                int tok_ = (m_base + half * 64 + (lane >> 3)) % p.rope_S;      // one division per 64 rows; then +8 per step
+                int tok_ = (m_base + hf * 64 + (lane >> 3)) % p.rope_S;        // one division per 64 rows; then +8 per step
                 const float2* cs_ = p.rope_cs + ((gcol_ % p.rope_hd) >> 1);
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const float2* t = cs_ + (long)tok_ * (p.rope_hd >> 1);
-                    rtab[it][0] = *(const f32x4*)t;
-                    rtab[it][1] = *(const f32x4*)(t + 2);
+                    rt[it][0] = *(const f32x4*)t;
+                    rt[it][1] = *(const f32x4*)(t + 2);
                     tok_ += 8;
                     if (tok_ >= p.rope_S) tok_ -= p.rope_S;
+                }
+            };
+            f32x4 rtab[8][2];
+            if (EPI == EPI_BF16_ROPE) {
+                if (half == 0) rope_load(0, rtab);
+                else {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) { rtab[it][0] = rtab_next[it][0]; rtab[it][1] = rtab_next[it][1]; }
                 }
             }
             // fragment phase: bias (or the folded LayerNorm's rstd (acc - mean c) + b'), GELU, bf16, transpose through the slab.
@@ -465,6 +475,7 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& p, char* slab, 
             };
             if (lnmr) frag_phase(std::true_type{});
             else frag_phase(std::false_type{});
+            if (EPI == EPI_BF16_ROPE && half == 0 && !(SKIP_DEAD && m_base + 64 >= p.M)) rope_load(1, rtab_next);
             const int gcol = n_base + (lane & 7) * 8;
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
