@@ -1140,8 +1140,10 @@ static int launch_256p(const GemmArgs& a, hipStream_t st) {
     b.gy = gy;
     const int gx = 8 / gy;
     const int region = ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
-    const int nslot = region < 32 ? region : 32;          // 32 CUs per XCD
+    int nslot = region < 32 ? region : 32;                // 32 CUs per XCD
 #ifdef REVO_EXPERIMENTS
+    // (burst-size study, scripts/experiments/r5_gemm_half_chip.py: fewer persistent workgroups per XCD)
+    if (const char* e = getenv("REVO_GEMM_NSLOT")) { const int v = atoi(e); if (v >= 1 && v < nslot) nslot = v; }
     {
         // phase groups (gemm256pp_kernel), forced by scripts/gemm_phase_ab.py only; the stamps live in that kernel too
         // (one group = every workgroup in step)
