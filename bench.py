@@ -111,6 +111,20 @@ def layer_gemm_flops(cfg, batch):
     return cfg.layers * 2.0 * rows * (W * 3 * W + W * W + 2 * W * M)
 
 
+def allgather_budget(one_gpu_ms, sharded_ms, exchange_ms_per_search, target_speedup=6.0):
+    """What north_star's ">= 6x at 8 GPUs on the 1M-gallery top-k" leaves for the exchange: the sharded search may take
+    one_gpu_ms / target in all; this rank's compute is what its measured search time holds besides the measured
+    exchanges; the difference is the budget every all-gather of a search (torch.distributed's host path included) must fit
+    in.  Negative = the compute alone misses the target."""
+    per_rank_compute = sharded_ms - exchange_ms_per_search
+    allowed = one_gpu_ms / target_speedup
+    return {"target_speedup": target_speedup, "one_gpu_ms": one_gpu_ms, "allowed_ms_per_search": allowed,
+            "per_rank_compute_ms": per_rank_compute, "exchange_ms_per_search_measured": exchange_ms_per_search,
+            "allgather_budget_ms": allowed - per_rank_compute,
+            "speedup_measured": one_gpu_ms / sharded_ms if sharded_ms > 0 else None,
+            "meets_target": bool(sharded_ms > 0 and one_gpu_ms / sharded_ms >= target_speedup)}
+
+
 def cpu_baseline(cfg, gallery_rows, dim, k, n_images, search_rows):
     """The CPU oracle run the way the reference runs: fp32, one image per forward
     (core_system.py:439-442), one query per search over a float32 numpy gallery."""
@@ -173,6 +187,63 @@ def cpu_baseline(cfg, gallery_rows, dim, k, n_images, search_rows):
     }
 
 
+def calibration(dev, warm_s=0.7, timed_s=0.35):
+    """How fast is THIS box: two fixed kernels (revers-o_amd/csrc/probe.hip: they do not change from round to round) run right
+    before the timed region, each warm for ~0.7 s and then timed for ~0.35 s with HIP events on the launch stream --
+    (a) a register-resident v_mfma_f32_16x16x32_bf16 loop on every CU, random operands -> `mfma_probe_tflops`;
+    (b) a 16-byte-per-lane copy of 1 GiB (2 GiB of traffic) -> `hbm_copy_tbs`.
+    MI355X devices differ by several per cent on MFMA-dense loops (MI355X_MICROARCH.md, DVFS give-back item 5: one binary,
+    12 % apart in wall time): `value_at_reference_box` = value x (reference probe / this probe) is the headline number a
+    reader can compare across rounds; profiles/calibration_reference.json holds the reference constants."""
+    from reverso_amd import _lib
+    lib = _lib.load()
+    st = _lib.current_stream()
+    g = torch.Generator(device=dev).manual_seed(99)
+    src = torch.randn(1 << 20, generator=g, device=dev).bfloat16()
+    blocks, iters = 1024, 2000
+    sink = torch.empty(blocks * 256, device=dev)
+
+    def timed(fn, per_launch):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < warm_s:       # warm: the clock settles under THIS load
+            for _ in range(8):
+                fn()
+            torch.cuda.synchronize()
+            n += 8
+        reps = max(8, int(n * timed_s / warm_s))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return per_launch / (e0.elapsed_time(e1) / reps * 1e-3), e0.elapsed_time(e1) / reps
+    fl = float(lib.revo_probe_mfma_flops(blocks, iters))
+    mfma, mfma_ms = timed(lambda: _lib.check(lib.revo_probe_mfma(_lib.ptr(src), src.numel(), _lib.ptr(sink), blocks, iters, st)), fl)
+    nbytes = 1 << 30
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    a.random_(0, 256, generator=g)
+    b = torch.empty_like(a)
+    copy, copy_ms = timed(lambda: _lib.check(lib.revo_probe_copy(_lib.ptr(b), _lib.ptr(a), nbytes, st)), 2.0 * nbytes)
+    del a, b
+    out = {"mfma_probe_tflops": mfma / 1e12, "mfma_probe_ms_per_launch": mfma_ms, "hbm_copy_tbs": copy / 1e12,
+           "hbm_copy_ms_per_launch": copy_ms,
+           "what": "probe.hip: 1024 x 4 waves x 2000 trips of 32 register-resident 16x16x32 bf16 MFMAs on random operands; "
+                   "1 GiB copied 16 B per lane (read + write counted); each warm ~0.7 s, then timed ~0.35 s"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "calibration_reference.json")) as f:
+            ref = json.load(f)
+        out["reference"] = {k: ref[k] for k in ("mfma_probe_tflops", "hbm_copy_tbs", "box") if k in ref}
+        out["mfma_probe_vs_reference"] = out["mfma_probe_tflops"] / ref["mfma_probe_tflops"]
+        out["hbm_copy_vs_reference"] = out["hbm_copy_tbs"] / ref["hbm_copy_tbs"]
+    except Exception:
+        out["reference"] = None
+    return out
+
+
 def ingest_leg(variant, n_images, device_index):
     """SURVEY 8(f) row 1 next to the headline: n JPEGs (640 x 480, written to a temporary folder) -> decode pool -> H2D ->
     device resize -> embed -> device gallery append -> delta-shard flush, through SimpleReverso.create_database.  Reported,
@@ -224,6 +295,7 @@ def main():
     ap.add_argument("--variant", default="PE-Core-L14-336")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the two box-speed probes (about 2.5 s) before the timed region")
     ap.add_argument("--cpu-images", type=int, default=6)
     ap.add_argument("--timed-events", type=int, default=3,
                     help="profiler mode inside the timed region: 3 = HIP events around every fourth launch of each body-GEMM "
@@ -324,6 +396,10 @@ def main():
 
     run_steps(args.warmup)
     fence()
+    calib = None if args.no_calibration else calibration(dev)     # every rank (they stay in step); rank 0's is printed
+    if calib is not None:
+        run_steps(1)                                              # back to the step's own kernels and caches
+        fence()
     # Timed region: HIP events (on the launch stream) only around the roofline kernel class, the four body
     # GEMMs, and only around every fourth launch of each (24 identical layers): an event pair costs a few
     # microseconds of stream time (all ~250 kernels of a step: 1 ms; the 96 GEMMs: 0.4 ms; sampled: 0.1 ms).
@@ -473,6 +549,7 @@ def main():
         engine.prof_enable(False)
         p2 = engine.prof_report()
         exch_big = ss.timing_report() if world > 1 else None
+        ss_timing_counts = dict(ss._timing or {})                  # tag -> the recorded exchanges (their count per tag)
         ss.enable_timing(False)
         sc = p2.get("topk_scan", {})
         scan_ms_big = sc["ms"] / sc["launches"] if sc.get("launches") else None
@@ -515,6 +592,14 @@ def main():
             full.close()
             search_big["one_gpu_ms_same_process"] = one * 1e3
             search_big["speedup_vs_1gpu_model"] = one / dts
+            # the budget the >= 6x target leaves for the exchanges, from this run's own measured times (every
+            # all-gather of a search, HIP events: allgather_ms x how often each ran per search)
+            ex_ms = 0.0
+            if exch_big:
+                n_s = max(exch_big.get("searches", reps), 1)
+                ex_ms = sum(v * len(ss_timing_counts.get(t, [])) / n_s for t, v in exch_big["allgather_ms"].items() if t != "queries")
+            search_big["allgather_budget"] = allgather_budget(one * 1e3, dts * 1e3, ex_ms)
+            search_big["allgather_budget_ms"] = search_big["allgather_budget"]["allgather_budget_ms"]
         if world > 1:
             dist.barrier()
 
@@ -545,6 +630,7 @@ def main():
                            "exchanges_per_search": exch_headline["exchanges_per_search"] if exch_headline else None,
                            "redone_searches": ss.redone_searches, "init_timeout_s": PG_TIMEOUT_S if world > 1 else None},
             "kernel_ms_per_step": classes_ms,
+            "calibration": calib,
             "embed_tflops": cfg.flops_per_image() * B * args.steps / dt / 1e12,
             # whole step (embed + search) against the MFMA peak, SURVEY.md 8(d): images/s x FLOPs/image -- not the kernel-class `roofline.frac`
             "embed_frac_of_peak": cfg.flops_per_image() * B * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS / world,
@@ -553,6 +639,16 @@ def main():
                             "note": "every query's top-k is certified equal to an exhaustive fp32 scoring or re-done exactly "
                                     "(include/revo.h EXACTNESS); the fallback's time is inside ms_per_step"},
         }
+        if calib is not None:
+            # the unchanged attention kernel is the third yardstick: a control INSIDE the step
+            att = classes_ms.get("attention")
+            calib["attention_ms_per_launch"] = att / cfg.layers if att else None
+            if calib.get("reference"):
+                res["value_at_reference_box"] = value / calib["mfma_probe_vs_reference"]
+                res["ms_per_step_at_reference_box"] = ms_per_step * calib["mfma_probe_vs_reference"]
+                calib["note"] = ("value_at_reference_box = value x (reference mfma probe / this box's): the step is 95 % MFMA kernels "
+                                 "(body GEMMs + attention); the copy probe and the attention control are printed beside it, not "
+                                 "folded in")
         if world == 1 and args.ingest_images > 0:
             eng.close()
             gal.close()

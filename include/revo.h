@@ -66,6 +66,17 @@ int32_t revo_vit_destroy(revo_vit* vit);
 int32_t revo_vit_forward(revo_vit* vit, const void* images, int32_t image_dtype, int32_t batch, float* out,
                          int32_t normalize, void* stream);
 int32_t revo_vit_seq_len(const revo_vit* vit);
+/* Run-time telemetry of the LayerNorm folded into the GEMMs around it (batch-sized forwards: ln_1 / ln_2 are not kernels;
+ * qkv / fc1 read A = bf16(x) UN-CENTRED and apply rstd * (acc - mean * csum) + b' in their epilogues).  The form is the same
+ * function as LayerNorm-then-GEMM, but its rounding error grows with |mean| / std of a row (bf16(x) spends its 8 bits on
+ * the common offset): 1.0 x the LayerNorm kernel's error at offset 0, 1.0 x at 2 sigma, ~1.4 x at 8 sigma, ~4 x at 32
+ * sigma (tests/test_gpu_ln_fold.py::test_fold_error_against_the_row_offset records the curve and holds it to a bound).  The
+ * reference normalises in the activations' precision before the matmul (oracle/pe_vit.py:146-155 <- core_system.py:341), so on
+ * a trained checkpoint this is the number to look at first if embeddings drift: out4 = { rows the consuming GEMMs merged
+ * statistics for since the last reset (each row of each folded LayerNorm of each forward, counted once; rows that the
+ * leftover-row kernels take are not sampled), of those: rows with |mean| * rstd > out4[3], rows with |mean| * rstd > 4 *
+ * out4[3], the ratio that counts as large (8) }.  Synchronises `stream`; reset != 0 clears the counters. */
+int32_t revo_vit_stats(revo_vit* vit, double* out4, int32_t reset, void* stream);
 
 /* ---- gallery: replaces recreate_collection(size=D, COSINE) + upsert (core_system.py:600-622) */
 int32_t revo_gallery_create(int32_t dim, int64_t capacity, int32_t device, int32_t keep_f32, revo_gallery** out);
@@ -95,7 +106,15 @@ int32_t revo_gallery_read(revo_gallery* g, int64_t start, int64_t n, float* dst,
  * fp32 pass.  Searches with k > 25 (64 candidates leave the certificate too little room on ordinary data) scan with an
  * admission margin of twice that bound: what an uncertified query needs is then among the rows its scan kept, and it is
  * re-done exactly WITHOUT another pass over the gallery.  All of it is enqueued on `stream`; revo_search_stats reports how often it happened.  (A gallery created
- * with keep_f32 = 0 has no fp32 rows: it returns the scan's own scores and certifies nothing.) */
+ * with keep_f32 = 0 has no fp32 rows: it returns the scan's own scores and certifies nothing.)
+ * What "exactly" is relative to: the ranking is the exhaustive one UNDER THIS LIBRARY'S fp32 SUMMATION ORDER (one fused
+ * multiply-add chain over the D products, k = 0 .. D - 1, of the fp32 query and the fp32 gallery row, both normalised in
+ * fp32).  The reference accumulates the same products in float64 and rounds once (numpy G @ q on Python floats): two rows
+ * whose true scores differ by less than the fp32 chain's rounding error (about D * 2^-24 * |score| <= 3e-7 at D = 1024) can
+ * come out in either order there and here.  tests/test_gpu_search.py therefore compares with the float64 oracle up to
+ * swaps of ADJACENT results inside that band (`near_tie`) -- a tolerance of the checker's arithmetic, not of this
+ * search -- and asserts that the k-th place of no query of the headline 1 M x 1024 gallery falls inside it; exact
+ * duplicates (scores equal to the bit) are always returned index-ascending. */
 int32_t revo_search_topk(revo_gallery* g, const float* queries, int32_t n_queries, int32_t k, int32_t has_threshold,
                          float threshold, int64_t index_offset, float* scores, int64_t* indices, int32_t* counts,
                          void* stream);
@@ -198,7 +217,18 @@ int32_t revo_op_gemm_resid_ln(const void* a_bf16, int64_t lda, const void* b_bf1
                               void* stats, int32_t* done, void* xlo_bf16, int32_t x_in_planes, int32_t planes_out, void* stream);
 int32_t revo_op_gemm_ln_in(int32_t epilogue, const void* a_bf16, int64_t lda, const void* b_bf16, int64_t ldb, int32_t m, int32_t n,
                            int32_t k, void* c_bf16, int64_t ldc, const float* bias, const float* csum, const void* stats,
-                           int32_t parts, float eps, void* stream);
+                           int32_t parts, float eps, void* tele, void* stream);
+/*    tele (optional; device, 3 x uint64, zeroed by the caller): the counters behind revo_vit_stats -- rows merged, rows with
+ *    |mean| * rstd > 8, rows with |mean| * rstd > 32. */
+/* ---- calibration probes (bench.py's `calibration` object; not on the reference's path: nothing there to cite).  Two fixed
+ * kernels that say how fast the BOX is, so that bench lines taken on different MI355X devices can be compared:
+ *  - revo_probe_mfma: `blocks` workgroups of four waves, each wave `iters` trips of 32 register-resident
+ *    v_mfma_f32_16x16x32_bf16 on operands read once from src (bf16, n_elems of them, random data); sink receives one
+ *    float per thread (blocks * 256).  revo_probe_mfma_flops(blocks, iters) = the launch's FLOPs.
+ *  - revo_probe_copy: dst[0, bytes) = src[0, bytes), 16 bytes per lane (the HBM copy rate: 2 * bytes of traffic). */
+int32_t revo_probe_mfma(const void* src_bf16, int64_t n_elems, float* sink, int32_t blocks, int32_t iters, void* stream);
+int64_t revo_probe_mfma_flops(int32_t blocks, int32_t iters);
+int32_t revo_probe_copy(void* dst, const void* src, int64_t bytes, void* stream);
 #ifdef REVO_EXPERIMENTS
 /* Kernel-variant selection and timing experiments: compiled only into librevo_exp.so (`make exp`: the same sources
  * with -DREVO_EXPERIMENTS; used by scripts/ and by the forced-tile runs of tests/test_gpu_kernels.py), never into

@@ -41,6 +41,7 @@ SIGNATURES = {
     "revo_vit_destroy": (_i32, [_p]),
     "revo_vit_forward": (_i32, [_p, _p, _i32, _i32, _p, _i32, _p]),
     "revo_vit_seq_len": (_i32, [_p]),
+    "revo_vit_stats": (_i32, [_p, C.POINTER(C.c_double), _i32, _p]),
     "revo_gallery_create": (_i32, [_i32, _i64, _i32, _i32, C.POINTER(_p)]),
     "revo_gallery_destroy": (_i32, [_p]),
     "revo_gallery_append": (_i32, [_p, _p, _i64, _i32, _i32, _p]),
@@ -62,7 +63,7 @@ SIGNATURES = {
     "revo_op_gemm": (_i32, [_i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p]),
     "revo_op_gemm_resid_ln": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p, C.POINTER(C.c_int32), _p, _i32,
                                      _i32, _p]),
-    "revo_op_gemm_ln_in": (_i32, [_i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _f32, _p]),
+    "revo_op_gemm_ln_in": (_i32, [_i32, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _f32, _p, _p]),
     "revo_op_gemm_rope": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
     "revo_op_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i64, _i32, _p]),
     "revo_op_rope": (_i32, [_p, _i64, _p, _i32, _i32, _i32, _i32, _p]),
@@ -72,6 +73,9 @@ SIGNATURES = {
     "revo_prof_reset": (_i32, []),
     "revo_prof_report": (_i32, [C.c_char_p, _i32]),
     "revo_preprocess_crop_resize": (_i32, [C.POINTER(CropJob), _i32, _i32, _p, _p]),
+    "revo_probe_mfma": (_i32, [_p, _i64, _p, _i32, _i32, _p]),
+    "revo_probe_mfma_flops": (_i64, [_i32, _i32]),
+    "revo_probe_copy": (_i32, [_p, _p, _i64, _p]),
 }
 
 # only in librevo_exp.so (built by `make exp` with -DREVO_EXPERIMENTS; timing scripts under scripts/)

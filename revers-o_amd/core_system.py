@@ -67,8 +67,10 @@ class Regions:
 
 class SimpleReverso:
     """Simplified visual investigation system (MI355X-native hot path)."""
-    _building_name = None       # name of the database a create_database call of this instance is building right now:
-                                # list_databases / load_database leave that build directory alone meanwhile
+    # names of the databases create_database calls of this instance are building right now (two UI threads may overlap):
+    # list_databases / load_database leave those build directories alone meanwhile.  Guarded by _building_lock.
+    _building_lock = threading.Lock()
+    _building_names = frozenset()      # (per-instance set from __init__ on)
 
     def __init__(self, model_name=DEFAULT_VARIANT, checkpoint=None, device=0, db_root=DB_ROOT, max_batch=64,
                  detector=None, decode_workers=None, synthetic_seed=0, region_mode="global", device_resize=False,
@@ -103,6 +105,8 @@ class SimpleReverso:
         self.detected_regions = []
         self.region_embeddings = None
         self.query_embedding_for_search = None
+        self._building_names = set()
+        self._building_lock = threading.Lock()
         self._stop_requested = False
         self._last_processed_file = None
         self._partial_embeddings = []
@@ -117,20 +121,26 @@ class SimpleReverso:
         if not os.path.exists(self.db_root):
             return []
         for n in os.listdir(self.db_root):              # a crash inside the final swap of a build: put the database back
-            for suf in (BUILDING, st.OLD):
-                # (not the build this very process is finishing: create_database swaps that one in itself)
-                if n.endswith(suf) and n[: -len(suf)] != self._building_name:
+            for suf in (BUILDING, st.OLD, st.OLD_LEGACY):
+                if suf == st.OLD_LEGACY and not st.is_legacy_set_aside(self.db_root, n):
+                    continue
+                # (not a build this very process is finishing: create_database swaps that one in itself)
+                if n.endswith(suf) and not self._is_building(n[: -len(suf)]):
                     st.recover(os.path.join(self.db_root, n[: -len(suf)]), BUILDING)
         return [n for n in os.listdir(self.db_root)
                 if os.path.isdir(os.path.join(self.db_root, n)) and n != "checkpoints" and not n.endswith(BUILDING)
-                and not n.endswith(st.OLD)]
+                and not n.endswith(st.OLD) and not st.is_legacy_set_aside(self.db_root, n)]
+
+    def _is_building(self, name):
+        with self._building_lock:
+            return name in self._building_names
 
     def load_database(self, database_name):
         """core_system.py:90-119"""
         if not database_name:
             return "❌ Please provide a database name"
         db_path = os.path.join(self.db_root, database_name)
-        if database_name != self._building_name:
+        if not self._is_building(database_name):
             st.recover(db_path, BUILDING)
         if not os.path.exists(db_path):
             return f"❌ Database not found: {database_name}"
@@ -158,6 +168,8 @@ class SimpleReverso:
             # an unfinished build of the same name and its checkpoint note go with it
             shutil.rmtree(db_path + BUILDING, ignore_errors=True)
             shutil.rmtree(db_path + st.OLD, ignore_errors=True)
+            if st.is_legacy_set_aside(self.db_root, database_name + st.OLD_LEGACY):
+                shutil.rmtree(db_path + st.OLD_LEGACY, ignore_errors=True)
             st.remove_checkpoint(os.path.join(self.db_root, "checkpoints", f"{database_name}_checkpoint"))
             return f"✅ Deleted database: {database_name}"
         except Exception as e:
@@ -362,12 +374,16 @@ class SimpleReverso:
         """core_system.py:461-648, with batched embedding and a working checkpoint."""
         # while this call builds <name>.building, a list_databases / load_database from another thread (a UI refresh) must
         # not adopt that directory as a crashed build's left-over (store.recover): the call swaps it in itself
-        self._building_name = database_name
+        with self._building_lock:
+            mine = database_name not in self._building_names      # (a second overlapping build of the SAME name: the first
+            self._building_names.add(database_name)               #  one to enter keeps the entry until it returns)
         try:
             return self._create_database(folder_path, database_name, text_prompt, use_direct_pe, progress_callback,
                                          resume_from_checkpoint, include_subfolders)
         finally:
-            self._building_name = None
+            if mine:
+                with self._building_lock:
+                    self._building_names.discard(database_name)
 
     def _create_database(self, folder_path, database_name, text_prompt, use_direct_pe, progress_callback,
                          resume_from_checkpoint, include_subfolders):

@@ -194,6 +194,7 @@ struct revo_vit {
     float* splitk_ws = nullptr;        // fp32 partial planes of the split-K residual GEMMs
     float2* ln_stats = nullptr;        // [rows][width / 256] (mean, M2) per 256-column slice: the folded LayerNorm's row statistics
     int ln_parts = 0;                  // width / 256 when the fold applies (width % 256 == 0, <= 6 slices), else 0
+    unsigned long long* ln_tele = nullptr;   // [4] telemetry of the folded LayerNorm's consumers (kernels.h GemmArgs::lnc_tele; revo_vit_stats)
 
     template <class T> int dalloc(T** out, size_t count) {
         void* p = nullptr;
@@ -451,6 +452,8 @@ extern "C" int32_t revo_vit_create(const revo_vit_cfg* cfg, const revo_tensor* w
     v->ln_parts = (W % 256 == 0 && W / 256 <= 6) ? W / 256 : 0;
     if (v->ln_parts) CHECK_RC(v->dalloc(&v->ln_stats, rows * (size_t)v->ln_parts));
     if (v->ln_parts) CHECK_RC(v->dalloc(&v->xlo, rows * W));
+    CHECK_RC(v->dalloc(&v->ln_tele, 4));
+    REVO_HIP_CHECK(hipMemset(v->ln_tele, 0, 4 * sizeof(unsigned long long)));
     REVO_HIP_CHECK(hipDeviceSynchronize());
     *out = v.release();
     return 0;
@@ -464,6 +467,18 @@ extern "C" int32_t revo_vit_destroy(revo_vit* vit) {
     API_END
 }
 extern "C" int32_t revo_vit_seq_len(const revo_vit* vit) { return vit ? vit->S : -1; }
+extern "C" int32_t revo_vit_stats(revo_vit* vit, double* out4, int32_t reset, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(vit && out4, "vit_stats: null argument");
+    REVO_ON_DEVICE(vit->device);
+    unsigned long long c[4] = {0, 0, 0, 0};
+    REVO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    REVO_HIP_CHECK(hipMemcpy(c, vit->ln_tele, sizeof(c), hipMemcpyDeviceToHost));
+    if (reset) REVO_HIP_CHECK(hipMemset(vit->ln_tele, 0, sizeof(c)));
+    out4[0] = (double)c[0]; out4[1] = (double)c[1]; out4[2] = (double)c[2]; out4[3] = (double)revo::LNC_TELE_RATIO;
+    return 0;
+    API_END
+}
 #ifdef REVO_EXPERIMENTS   // parity-test hooks: librevo_exp.so only (include/revo.h)
 extern "C" int32_t revo_vit_set_debug_layers(revo_vit* vit, int32_t n) {
     REVO_REQUIRE(vit, "null handle");
@@ -596,7 +611,7 @@ static int vit_forward_range(revo_vit* vv, const void* images_all, int32_t image
                       ? vv->xlo + r0 * W : nullptr;
     bool x_planes = false;
     auto ln_before = [&](const float* csum, GemmArgs& a) {
-        if (h_state == H_XB) { a.lnc_stats = stats; a.lnc_parts = vv->ln_parts; a.lnc_c = csum; a.lnc_eps = c.ln_eps; }
+        if (h_state == H_XB) { a.lnc_stats = stats; a.lnc_parts = vv->ln_parts; a.lnc_c = csum; a.lnc_eps = c.ln_eps; a.lnc_tele = vv->ln_tele; }
     };
     auto normalise_if_needed = [&]() -> int {
         if (h_state != H_NONE) return 0;
@@ -1286,13 +1301,14 @@ extern "C" int32_t revo_op_gemm_resid_ln(const void* a, int64_t lda, const void*
 }
 extern "C" int32_t revo_op_gemm_ln_in(int32_t epi, const void* a, int64_t lda, const void* b, int64_t ldb, int32_t m, int32_t n,
                                       int32_t k, void* c, int64_t ldc, const float* bias, const float* csum, const void* stats,
-                                      int32_t parts, float eps, void* stream) {
+                                      int32_t parts, float eps, void* tele, void* stream) {
     API_BEGIN
     REVO_REQUIRE(epi == revo::EPI_BF16 || epi == revo::EPI_BF16_GELU, "op_gemm_ln_in: epilogue must be 0 (bf16) or 1 (bf16 + GELU)");
     REVO_REQUIRE(a && b && c && csum && stats, "op_gemm_ln_in: null argument");
     revo::GemmArgs g{};
     g.A = (const bf16_t*)a; g.lda = lda; g.B = (const bf16_t*)b; g.ldb = ldb; g.M = m; g.N = n; g.K = k; g.C = c; g.ldc = ldc;
     g.bias = bias; g.lnc_stats = (const float2*)stats; g.lnc_parts = parts; g.lnc_c = csum; g.lnc_eps = eps;
+    g.lnc_tele = (unsigned long long*)tele;
     return revo::launch_gemm(epi, g, (hipStream_t)stream);
     API_END
 }

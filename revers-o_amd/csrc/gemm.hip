@@ -582,7 +582,9 @@ __device__ __forceinline__ void lnc_issue_stats(const GemmArgs& p, int m0, char*
 // BEFORE the main loop: one thread per tile row merges the row's partials into (rstd, -mean rstd).  No barrier of its own:
 // a wave reads only slots it requested itself (behind its own counted wait: the statistics are older than the K-tile
 // DMA the main loop's first wait leaves in flight), and the epilogue reads lds_mr behind the main loop's barriers.
-__device__ __forceinline__ void lnc_merge_rows(const GemmArgs& p, const char* lds_raw, float2* lds_mr, int wave, int /*lane*/, bool one_ktile) {
+// tele (wave-uniform; the tile is the launch's column tile 0 and the caller asked for telemetry): rows_left = M - m0.
+__device__ __forceinline__ void lnc_merge_rows(const GemmArgs& p, const char* lds_raw, float2* lds_mr, int wave, int /*lane*/, bool one_ktile,
+                                               bool tele = false, int rows_left = 0) {
     if (wave >= 4) return;
     // (the lane id is read from the hardware here: derived from the kernel's `lane` it became one more value alive across
     //  the main loop, and hipcc spilled accumulator registers INSIDE the K loop of the RoPE kernel)
@@ -615,6 +617,19 @@ __device__ __forceinline__ void lnc_merge_rows(const GemmArgs& p, const char* ld
         else if (p.lnc_parts == 6) merge_n(std::integral_constant<int, 6>{});
         else lnf_merge((const float2*)lds_raw + t * p.lnc_parts, p.lnc_parts, p.lnc_eps, r, m);
         lds_mr[t] = make_float2(r, m);
+        if (tele) {
+            // one wave = 64 rows: one to three no-return atomics per wave of a column-tile-0 workgroup (rows past the matrix edge
+            // read zero statistics: |mean| rstd = 0, not counted)
+            const int live = rows_left - wave * 64 < 0 ? 0 : (rows_left - wave * 64 > 64 ? 64 : rows_left - wave * 64);
+            const float am = lane < live ? __builtin_fabsf(m) : 0.f;
+            const unsigned long long big = __builtin_amdgcn_ballot_w64(am > LNC_TELE_RATIO);
+            const unsigned long long huge = __builtin_amdgcn_ballot_w64(am > 4.0f * LNC_TELE_RATIO);
+            if (lane == 0 && live > 0) {                  // (ballots and counts are scalar: no vector register lives past here)
+                atomicAdd(p.lnc_tele, (unsigned long long)live);
+                if (big) atomicAdd(p.lnc_tele + 1, (unsigned long long)__builtin_popcountll(big));
+                if (huge) atomicAdd(p.lnc_tele + 2, (unsigned long long)__builtin_popcountll(huge));
+            }
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
@@ -749,7 +764,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256_kernel(GemmArgs p) {
     if (!(DBG & 2)) {
         if (lnc) lnc_issue_stats(p, m0, smem + G256_LDS, wave, lane);
         g256_issue_prologue(A, B, smem, p.K, wave);
-        if (lnc) lnc_merge_rows(p, smem + G256_LDS, lds_mr, wave, lane, p.K <= 64);
+        if (lnc) lnc_merge_rows(p, smem + G256_LDS, lds_mr, wave, lane, p.K <= 64, p.lnc_tele != nullptr && n0 == 0, p.M - m0);
         gemm256_mainloop(A, B, smem, p.K, wave, lane, acc);
     }
     if (DBG & 1) {
@@ -835,7 +850,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
             g256_issue_half(A, 1, 128, G256_A(smem, 1), wave);
         }
         // this tile's rows: (rstd, -mean rstd) into LDS while its second K-tile is on its way (no barrier of its own)
-        if (lnc && !(REVO_LNC_ABLATE & 1)) lnc_merge_rows(p, lds_raw, lds_mr, wave, lane, p.K <= 64);
+        if (lnc && !(REVO_LNC_ABLATE & 1)) lnc_merge_rows(p, lds_raw, lds_mr, wave, lane, p.K <= 64, p.lnc_tele != nullptr && n0 == 0, p.M - m0);
         f32x4 acc[8][4];
 #pragma unroll
         for (int m = 0; m < 8; ++m)

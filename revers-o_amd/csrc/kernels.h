@@ -55,11 +55,17 @@ struct GemmArgs {
     // xp_hi must be lnf_xb).  *lnf_done = 1 also says that xp_out was honoured.
     bf16_t* xp_hi; bf16_t* xp_lo; long xp_ld; int xp_in, xp_out;
     const float2* lnc_stats; int lnc_parts; const float* lnc_c; float lnc_eps;
+    // Telemetry of the folded consumer (optional; device, 3 x u64): the A operand is bf16(x) UN-CENTRED, so the fold's
+    // error against LayerNorm-then-round grows with |mean| / std of a row (tests/test_gpu_ln_fold.py records the curve).
+    // The 256 x 256 kernels' column-tile-0 workgroups -- each row of the launch exactly once -- add: [0] rows merged,
+    // [1] rows with |mean| * rstd > LNC_TELE_RATIO, [2] rows with |mean| * rstd > 4 * LNC_TELE_RATIO.
+    unsigned long long* lnc_tele;
 #ifdef REVO_EXPERIMENTS
     int stagger_cycles, stagger_groups;   // timing experiment (persistent kernel): phase groups, see gemm256p_kernel
     unsigned long long* stamps; int stamp_items;   // diagnostic (gemm256pp_kernel): [workgroup][item][4] 100 MHz time stamps
 #endif
 };
+constexpr float LNC_TELE_RATIO = 8.0f;
 // true when launch_gemm would run the 256 x 256 kernel with the row-coalesced epilogue for these sizes
 bool gemm_uses_wide_epilogue(int M, int N, long lda, long ldb, long ldc);
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t st);

@@ -120,6 +120,15 @@ class VitEngine:
                                                       int(bool(normalize)), st), "revo_vit_forward")
         return out
 
+    def ln_fold_stats(self, reset=False):
+        """Telemetry of the LayerNorm folded into qkv / fc1 (include/revo.h revo_vit_stats; synchronises the current stream):
+        rows whose statistics the consuming GEMMs merged since the last reset, how many of them had |mean| / std above
+        ``ratio`` (and above four times it) -- the regime in which the fold's rounding error exceeds the LayerNorm kernel's."""
+        out = (C.c_double * 4)()
+        with self._lock, torch.cuda.device(self.device):
+            _lib.check(self._lib.revo_vit_stats(self._h, out, int(bool(reset)), _lib.current_stream()), "revo_vit_stats")
+        return {"rows": int(out[0]), "rows_above_ratio": int(out[1]), "rows_above_4x_ratio": int(out[2]), "ratio": float(out[3])}
+
     # -- parity-test hook -----------------------------------------------------
     def residual_after(self, images, n_layers):
         """fp32 residual stream [B, S, W] after ln_pre and the first n blocks."""
@@ -172,6 +181,7 @@ class Gallery:
         self.capacity = int(capacity)
         self.device = _as_device(device)
         self._lock = threading.Lock()
+        self._total_rows = 0                      # set_total_rows: rows of the sharded gallery this handle is a shard of (0: none)
         # experiments=True: a handle of librevo_exp.so, the only library in which a search can be forced through (or
         # kept from) its exact fallbacks (set_search_mode: parity tests and timing scripts)
         self.experiments = bool(experiments) or _lib.product_is_experiment_build()
@@ -302,11 +312,9 @@ class Gallery:
         are views into that buffer, laid out for :func:`merge_topk_packed`."""
         Q, k = int(n_queries), int(k)
         cert = None
-        if out_packed is None and getattr(self, "_total_rows", 0) > len(self) and search_estimates(k):
-            # the scan dropped rows against an ESTIMATED level: only the packed block's certificate (merge_topk_packed(...,
-            # certify=True) + search_exact) makes the result exhaustive -- the C ABI refuses the call too
-            raise _lib.RevoError("search_finish: this shard estimates the whole gallery's admission level (set_total_rows): "
-                                 "out_packed is required, and the merge must certify (merge_topk_packed(certify=True))")
+        # (after a scan that dropped rows against an ESTIMATED level -- set_total_rows on a shard large enough to estimate --
+        #  only the packed block's certificate makes the result exhaustive: revo_search_finish itself refuses
+        #  cert = NULL then, status -2, and says so; a shard that never estimated is served either way)
         if out_packed is not None:
             idx = out_packed[: Q * k * 8].view(torch.int64).view(Q, k)
             scores = out_packed[Q * k * 8: Q * k * 12].view(torch.float32).view(Q, k)

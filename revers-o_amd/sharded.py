@@ -117,8 +117,11 @@ class ShardedSearch:
         self._gbuf = {}                    # gather targets, reused from search to search
         self.offset, self.total_rows = self._exchange_offsets()
         self._tell_total()
+        # eight landing places (pinned where there is a device; plain host words on the CPU tier, which runs the same
+        # slot bookkeeping so that the gloo tests cover it)
+        self._pinned = [torch.zeros((1,), dtype=torch.int32) for _ in range(8)]
         if torch.cuda.is_available():
-            self._pinned = [torch.zeros((1,), dtype=torch.int32).pin_memory() for _ in range(8)]
+            self._pinned = [t.pin_memory() for t in self._pinned]
         self._inflight = [None] * 8
 
     def _gather_buf(self, tag, shape, dtype, device):
@@ -265,14 +268,24 @@ class ShardedSearch:
         ``result()`` waits for the count of uncertified queries and, only if there are any, runs the second round.
         A caller with a stream of query batches enqueues batch i + 1 before asking for batch i's result: the device never
         waits for the host between searches (``search()`` = ``search_async().result()`` does, once per call).
-        Every rank must issue the same calls in the same order (the collectives are matched by order)."""
+        Every rank must issue the same calls in the same order (the collectives are matched by order).
+        ``queries`` must stay unmodified until ``result()`` has returned: a pending search whose shard state has been
+        overwritten by a later one re-searches its uncertified rows from this tensor."""
         Q = queries.shape[0]
         top_m = self.top_m(k)
         if self.world == 1:
             return PendingSearch(self, self.backend.search(queries, k, threshold), None, None, queries, k, threshold, 0)
         if self._timing is not None:
             self._timed_searches += 1
+        # The landing place this search will use may still belong to a search eight back that was never asked for its
+        # result: finish that one NOW, before the shard handle's candidates become this search's.  Its result() may run
+        # a repair search of its own (which advances _gen and takes the handle), so the slot is looked up again
+        # afterwards -- flushed behind candidates(), as this did before, the repair overwrote this search's candidates
+        # and the PendingSearch below was filed under the repair's generation.
+        while self._inflight[(self._gen + 1) % len(self._pinned)] is not None:
+            self._inflight[(self._gen + 1) % len(self._pinned)].result()
         self._gen += 1                                                           # the shard handle's candidates are this search's now
+        gen = self._gen                                                          # (one value for the slot AND the PendingSearch)
         mine = self.backend.candidates(queries, k, top_m)                        # [Q, top_m] int32
         estimated = bool(self._estimating and self.backend.estimates(k))
         if estimated:
@@ -287,22 +300,18 @@ class ShardedSearch:
         allp = self._gather_buf("packed", (self.world * packed.numel(),), torch.uint8, packed.device)
         self._all_gather(allp, packed, "packed")                                 # exchange 2: packed per-rank top-k
         scores, idx, counts, unc = self.backend.merge(allp, self.world, Q, k, threshold, certify=True)
-        host_n, ev = None, None
+        # the count goes to (pinned) host memory behind the merge; nobody waits for it here
+        slot = gen % len(self._pinned)               # (free: see the flush above)
+        host_n, ev = self._pinned[slot], None
         if unc[0].is_cuda:
-            # the count goes to pinned host memory behind the merge; nobody waits for it here
-            slot = self._gen % len(self._pinned)
-            if self._inflight[slot] is not None:
-                self._inflight[slot].result()        # eight searches back and never asked for: finish it before its landing place is reused
-            host_n = self._pinned[slot]
             host_n.copy_(unc[0], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            p = PendingSearch(self, (scores, idx, counts), unc, (host_n, ev), queries, k, threshold, self._gen)
-            p._estimated = estimated
-            self._inflight[slot] = p
-            return p
-        p = PendingSearch(self, (scores, idx, counts), unc, (host_n, ev), queries, k, threshold, self._gen)
+        else:
+            host_n.copy_(unc[0].reshape(1))          # CPU backends (tests)
+        p = PendingSearch(self, (scores, idx, counts), unc, (host_n, ev), queries, k, threshold, gen)
         p._estimated = estimated
+        self._inflight[slot] = p
         return p
 
     def _second_round(self, res, unc, n, k, threshold):
@@ -339,14 +348,12 @@ class PendingSearch:
         host_n, ev = self._host
         if ev is not None:
             ev.synchronize()
-            n = int(host_n[0])
-            # give the landing place back BEFORE anything below starts another search: with eight searches pending the
-            # repair search of this one would find "itself" in its slot and ask it for its result again
-            slot = self._gen % len(o._inflight)
-            if o._inflight[slot] is self:
-                o._inflight[slot] = None
-        else:
-            n = int(self._unc[0][0])                                             # CPU backends (tests)
+        n = int(host_n[0])
+        # give the landing place back BEFORE anything below starts another search: with eight searches pending the
+        # repair search of this one would find "itself" in its slot and ask it for its result again
+        slot = self._gen % len(o._inflight)
+        if o._inflight[slot] is self:
+            o._inflight[slot] = None
         o.last_uncertified = n
         if self._note and self._estimated:          # (a limit-50 search's second rounds say nothing about the estimate)
             o._note_second_rounds(n, int(self._queries.shape[0]))
@@ -363,12 +370,16 @@ class PendingSearch:
                 o.redone_searches += 1
                 scores, idx, counts = self._res
                 rows = torch.sort(self._unc[1][:n])[0].long()
-                sub = o.search_async(self._queries[rows].contiguous(), self._k, self._thr)
+                # the repair batch is padded to a power of two (its last row repeated): the gather and result buffers are
+                # cached by shape, and one shape per uncertified count would push the steady-state shapes out of the caches
+                nb = 1 << max(0, int(n) - 1).bit_length()
+                pad = torch.cat([rows, rows[-1:].expand(nb - n)]) if nb > n else rows
+                sub = o.search_async(self._queries[pad].contiguous(), self._k, self._thr)
                 sub._note = False                       # the rate of uncertified queries is counted once per query
                 s2, i2, c2 = sub.result()
-                scores[rows] = s2
-                idx[rows] = i2
-                counts[rows] = c2
+                scores[rows] = s2[:n]
+                idx[rows] = i2[:n]
+                counts[rows] = c2[:n]
                 o.last_uncertified = n
                 self._res = (scores, idx, counts)
         self._done = True

@@ -46,6 +46,22 @@ def _fsync_dir(path):
 
 
 OLD = ".revo-old"          # the set-aside previous database during a swap (a suffix no user database name is likely to end in)
+OLD_LEGACY = ".old"        # what earlier builds called it: a crash under one of those may have left <db>.old behind -- recover(),
+                           # list_databases and delete_database recognise it for one release (only next to a database name that
+                           # is missing or was made by this package: a user database that happens to be called "x.old" and has
+                           # no sibling "x" story is left alone, see is_legacy_set_aside)
+
+
+def is_legacy_set_aside(root, name):
+    """True if directory ``name`` = "<db>.old" under ``root`` is a previous build's set-aside copy rather than a user's
+    database: it carries this package's manifest and either <db> is missing (the crash it was left by) or <db> is one of
+    this package's databases too (a swap that died before the set-aside copy was removed)."""
+    if not name.endswith(OLD_LEGACY) or name.endswith(OLD):
+        return False
+    base = os.path.join(root, name[: -len(OLD_LEGACY)])
+    if not os.path.isfile(os.path.join(root, name, MANIFEST)):
+        return False
+    return (not os.path.isdir(base)) or os.path.isfile(os.path.join(base, MANIFEST))
 
 
 def _is_complete(path):
@@ -81,7 +97,7 @@ def recover(db_path, building_suffix=".building"):
     next to it is put back under its name.  Returns what was adopted, or None."""
     if os.path.isdir(db_path):
         return None
-    for cand, what in ((db_path + building_suffix, "build"), (db_path + OLD, "old")):
+    for cand, what in ((db_path + building_suffix, "build"), (db_path + OLD, "old"), (db_path + OLD_LEGACY, "old")):
         man = os.path.join(cand, MANIFEST)
         if os.path.isfile(man):
             try:

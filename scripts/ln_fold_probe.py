@@ -31,7 +31,7 @@ for name, M, N, K, epi in (("qkv", 36928, 3072, 1024, 0), ("fc1", 36928, 4096, 1
     out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
     st = _lib.current_stream()
     plain = lambda: _lib.check(lib.revo_op_gemm(epi, _lib.ptr(h), K, _lib.ptr(w), K, M, N, K, _lib.ptr(out), N, _lib.ptr(bias), None, st))
-    fold = lambda: _lib.check(lib.revo_op_gemm_ln_in(epi, _lib.ptr(xb), K, _lib.ptr(w), K, M, N, K, _lib.ptr(out), N, _lib.ptr(bias), _lib.ptr(csum), _lib.ptr(stats), K // 256, 1e-5, st))
+    fold = lambda: _lib.check(lib.revo_op_gemm_ln_in(epi, _lib.ptr(xb), K, _lib.ptr(w), K, M, N, K, _lib.ptr(out), N, _lib.ptr(bias), _lib.ptr(csum), _lib.ptr(stats), K // 256, 1e-5, None, st))
     r = {"plain_ms": [], "folded_ms": []}
     for _ in range(3):
         r["plain_ms"].append(round(timed(plain), 4)); r["folded_ms"].append(round(timed(fold), 4))

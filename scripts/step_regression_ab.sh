@@ -3,7 +3,7 @@
 # The other library: build an older commit in a scratch worktree and keep the .so under _bisect/ (git-ignored, travels with gpurun):
 #   git worktree add /tmp/wt <commit> && make -C /tmp/wt/revers-o_amd/csrc -j8 all && mkdir -p _bisect/prev && cp /tmp/wt/revers-o_amd/librevo.so _bisect/prev/ && git worktree remove --force /tmp/wt
 OLD=${1:-_bisect/prev/librevo.so}
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --ingest-images 0 --search-queries 0"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-calibration --ingest-images 0 --search-queries 0"
 for r in 1 2; do
   REVO_LIBRARY_PATH=$OLD python bench.py $ARGS 2>/dev/null > gpurun_out/step_old_$r.json
   python bench.py $ARGS 2>/dev/null > gpurun_out/step_new_$r.json

@@ -110,3 +110,20 @@ def test_process_group_timeout_and_ipc_mode_are_set_on_both_launch_paths():
     head = src[: src.index("import torch")]
     assert 'os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")' in head
     assert src.count("init_process_group(") == 2 and src.count("timeout=tmo") == 2
+
+
+def test_allgather_budget_field():
+    """`search_query_batch.allgather_budget_ms` of an N > 1 line: what the >= 6x target of north_star leaves for the exchanges
+    of one search, from the run's own numbers.  The rehearsed 8-shard stage times of profiles/r05_sharded_stage_8.json as the
+    worked example: 18.38 ms on one GPU, 2.73 ms per rank of which 0.06 assumed for the exchange."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    b = bench.allgather_budget(18.38, 2.73, 0.06)
+    assert abs(b["allowed_ms_per_search"] - 18.38 / 6) < 1e-12 and abs(b["per_rank_compute_ms"] - 2.67) < 1e-12
+    assert abs(b["allgather_budget_ms"] - (18.38 / 6 - 2.67)) < 1e-12 and 0.39 < b["allgather_budget_ms"] < 0.40
+    assert b["meets_target"] and abs(b["speedup_measured"] - 18.38 / 2.73) < 1e-12
+    slow = bench.allgather_budget(18.38, 3.5, 0.9)
+    assert not slow["meets_target"] and slow["allgather_budget_ms"] > 0          # compute fits, the exchange is what misses
+    worse = bench.allgather_budget(18.38, 3.5, 0.1)
+    assert worse["allgather_budget_ms"] < 0                                      # the compute alone misses the target

@@ -45,6 +45,12 @@ def test_bench_contract_one_gpu(dev):
     d = _json_line(p.stdout)
     _check_contract(d, 1)
     assert d["ingest"]["ok"] and d["ingest"]["images"] == 24 and d["ingest"]["images_per_s"] > 0, d["ingest"]     # the reported ingest leg
+    # the box-speed probes run right before the timed region (profiles/calibration_reference.json: the constants they are held against)
+    c = d["calibration"]
+    assert 500.0 < c["mfma_probe_tflops"] < 2600.0 and 2.0 < c["hbm_copy_tbs"] < 8.1, c
+    assert c["attention_ms_per_launch"] > 0
+    if c.get("reference"):
+        assert d["value_at_reference_box"] == pytest.approx(d["value"] / c["mfma_probe_vs_reference"], rel=1e-9)
     assert d["certificate"]["uncertified_queries_last_step"] >= 0 and "uncertified_queries" in d["search_query_batch"]
 
 
@@ -58,6 +64,9 @@ def test_bench_contract_two_ranks_on_one_gpu(dev):
     _check_contract(d, 2)
     sq = d["search_query_batch"]
     assert sq["one_gpu_ms_same_process"] > 0 and sq["speedup_vs_1gpu_model"] > 0      # rank 0's 1-GPU run of the same search
+    ab = sq["allgather_budget"]                                                          # what the >= 6x target leaves for the exchanges
+    assert sq["allgather_budget_ms"] == ab["allgather_budget_ms"] == pytest.approx(ab["allowed_ms_per_search"] - ab["per_rank_compute_ms"])
+    assert ab["exchange_ms_per_search_measured"] > 0 and ab["per_rank_compute_ms"] < sq["sharded_ms"]
     assert "cpu_baseline" not in d and "ingest" not in d                                 # N = 1 only
 
 

@@ -444,7 +444,7 @@ def test_two_threads_share_one_instance(tmp_path, dev):
                     assert r.current_database == "simple_reverso_loaded"              # the build has not replaced it
                 rounds += 1
             out["rounds"] = rounds
-            out["still_building"] = r._building_name == "big" and ta.is_alive()      # the queries did overlap the build
+            out["still_building"] = r._is_building("big") and ta.is_alive()      # the queries did overlap the build
             r.request_stop()                         # ui.py:109
         except Exception as e:
             errors.append(e)

@@ -209,6 +209,17 @@ def _shard_worker(rank, world, port, tmp, N, D, Q, k, noise=0.0):
         assert 2.0 < rep["exchanges_per_search"] <= 3.0
     else:
         assert ss.redone_searches == redone0 and rep["searches"] == 2 and rep["exchanges_per_search"] == 2.0
+    # Eleven searches pending, none asked for (more than the eight landing places): the ninth has to finish the first before
+    # it takes over its slot -- and the first, uncertified under a noisy scan, runs a repair search of its own inside that
+    # flush.  Each search asks a different subset of the queries, so a result filed under the wrong search (or second rounds
+    # run against another search's candidates) shows as wrong rows.
+    subsets = [list(range(j % 3, per * world, 1 + j % 2)) for j in range(11)]
+    pend = [ss.search_async(allq[sub].contiguous(), k, None) for sub in subsets]
+    for sub, p in reversed(list(zip(subsets, pend))):
+        s, i, c = p.result()
+        assert np.array_equal(i.numpy(), out["None"][1][sub]) and np.array_equal(c.numpy(), out["None"][2][sub])
+        assert np.array_equal(s.numpy(), out["None"][0][sub])
+    assert all(x is None for x in ss._inflight)
     np.savez(os.path.join(tmp, f"rank{rank}.npz"), **{f"{t}_{n}": v for t, (a, b, c) in out.items()
                                                         for n, v in (("s", a), ("i", b), ("c", c))})
     dist.barrier()
@@ -304,3 +315,58 @@ def test_swap_in_and_recover_after_a_crash_in_the_final_swap(tmp_path):
     # only an unfinished build: nothing is adopted
     shutil.rmtree(db)
     assert st.recover(db) is None and not os.path.exists(db)
+
+
+def test_legacy_set_aside_suffix_is_recovered_hidden_and_deleted(tmp_path):
+    """A crash under an earlier build left <db>.old (the suffix was renamed to .revo-old): for one release recover() still
+    adopts it, list_databases hides it and delete_database removes it -- but a user's own directory called "x.old" that
+    is not one of this package's databases stays a database."""
+    r = _bare_facade(tmp_path)
+    os.makedirs(r.db_root)
+
+    def make(name, complete=True):
+        path = os.path.join(r.db_root, name)
+        os.makedirs(path)
+        with open(os.path.join(path, st.MANIFEST), "w") as f:
+            f.write(json.dumps({"format": 2, "collection": name, "dim": 64}) + "\n")
+            if complete:
+                f.write(json.dumps({"complete": True, "rows": 0}) + "\n")
+    make("alpha.old")                                    # the crash: alpha itself is gone
+    os.makedirs(os.path.join(r.db_root, "notes.old"))    # a user's directory (no manifest): never touched
+    assert sorted(r.list_databases()) == ["alpha", "notes.old"]
+    assert not os.path.exists(os.path.join(r.db_root, "alpha.old"))
+    make("alpha.old")                                    # a swap that died before the set-aside copy was removed
+    assert sorted(r.list_databases()) == ["alpha", "notes.old"]
+    assert r.delete_database("alpha").startswith("✅")
+    assert not os.path.exists(os.path.join(r.db_root, "alpha.old")) and os.path.isdir(os.path.join(r.db_root, "notes.old"))
+
+
+def test_overlapping_builds_keep_their_names_until_each_returns(tmp_path):
+    """Two create_database calls on one instance (UI threads): the first to finish must not clear the other's entry."""
+    r = _bare_facade(tmp_path)
+    r._building_names, r._building_lock = set(), __import__("threading").Lock()
+    import threading
+    gate_a, gate_b = threading.Event(), threading.Event()
+    seen = {}
+
+    def fake(self_, folder, name, *a):
+        if name == "a":
+            gate_a.wait(5)
+        else:
+            seen["a_while_b"] = r._is_building("a")
+            gate_b.wait(5)
+        return name
+    r._create_database = fake.__get__(r)
+    ta = threading.Thread(target=lambda: r.create_database("f", "a"))
+    tb = threading.Thread(target=lambda: r.create_database("f", "b"))
+    ta.start(); tb.start()
+    import time
+    for _ in range(200):
+        if r._is_building("a") and r._is_building("b"):
+            break
+        time.sleep(0.01)
+    assert r._is_building("a") and r._is_building("b")
+    gate_a.set(); ta.join(5)
+    assert not r._is_building("a") and r._is_building("b")        # (was: one slot, reset by the first finisher)
+    gate_b.set(); tb.join(5)
+    assert not r._is_building("b") and seen["a_while_b"]

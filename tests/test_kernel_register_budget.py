@@ -118,7 +118,10 @@ def test_body_gemm_kernels_stay_within_their_allocation():
     # kernel's K loop: that is what the next test is for).
     # (later in round 5: tile coordinates moved to scalar registers right after their integer divisions, the epilogue's lane
     #  id read from the hardware behind the main loop in the GELU / residual forms: 6 -> 2, 2 -> 0, 10 -> 7, 8 -> 7)
-    for epi, bmr, allowed in ((1, 256, 2), (2, 256, 0), (2, 192, 0), (5, 256, 7), (0, 256, 7)):
+    # (round 6: the folded consumer's telemetry -- two ballots and up to three scalar atomics per column-tile-0 wave, one more
+    #  kernel argument -- costs the GELU form one more parked register, 2 -> 3, outside the K loop; step A/B'd against the
+    #  round-5 library)
+    for epi, bmr, allowed in ((1, 256, 3), (2, 256, 0), (2, 192, 0), (5, 256, 7), (0, 256, 7)):
         u = _find(d, "gemm256p_kernel", f"ILi{epi}ELi{bmr}ELi0E")
         assert u["VGPRs"] <= 256 and u["VGPRs Spill"] <= allowed, (epi, bmr, u)
     # the residual stream in two bf16 planes: one instantiation per format pair (XP 1..3).  With the formats as run-time

@@ -93,6 +93,26 @@ def test_rope_identity_at_cls_and_norm_preserving():
     assert torch.equal(ang[:, 0::2], ang[:, 1::2])
 
 
+def test_rope_pair_rotation_equals_an_independent_implementation():
+    """The one sub-block of the oracle that was pinned only to its own identities: the interleaved-pair rotation.
+    ``transformers`` ships GPT-J's ``rotate_every_two`` / ``apply_rotary_pos_emb`` -- the same convention ((x0, x1) ->
+    (-x1, x0), one angle per consecutive pair), written independently of this repository.  Exact equality in fp64 on
+    random tensors, for every variant's angle table.  (What stays recall is the 2-D LAYOUT of the table -- x half, y
+    half, +1 grid offset, zero row for cls -- not the rotation.)"""
+    gptj = pytest.importorskip("transformers.models.gptj.modeling_gptj")
+    g = torch.Generator().manual_seed(11)
+    for name in ("PE-Tiny-T14-56", "PE-Core-B16-224", "PE-Core-L14-336", "PE-Core-G14-448"):
+        cfg = reverso_amd.get_config(name)
+        ang = pe_vit.rope_angles(cfg, torch.float64)                       # [S, hd], pairs share one angle
+        x = torch.randn(2, 3, cfg.seq, cfg.head_dim, generator=g, dtype=torch.float64)      # [B, H, S, hd]
+        assert torch.equal(pe_vit.rotate_pairs(x), gptj.rotate_every_two(x))
+        half = ang[:, 0::2]
+        assert torch.equal(half, ang[:, 1::2])
+        sin, cos = half.sin()[None].expand(2, -1, -1), half.cos()[None].expand(2, -1, -1)   # [B, S, hd / 2]
+        want = gptj.apply_rotary_pos_emb(x.permute(0, 2, 1, 3), sin, cos).permute(0, 2, 1, 3)   # GPT-J: [B, S, H, hd]
+        assert torch.equal(pe_vit.apply_rope(x, ang), want)
+
+
 def test_known_answer_search_cases():
     D = 64
     eye = np.eye(D, dtype=np.float32)
