@@ -252,6 +252,9 @@ int32_t revo_search_set_mode(revo_gallery* g, int32_t mode);
  * workgroups in step), 2..4 = that many groups, a workgroup of group g doing the first (g + 1) / groups of its first tile at the start and the
  * rest of that tile last.  Result-preserving (bit-identical). */
 int32_t revo_op_set_phase_groups(int32_t groups);
+/* 0: the persistent body GEMMs' bf16 epilogues on the round-5 kernel (LDS-transposed stores, drained before the next main loop);
+ * 1 (default): the queued-stores kernel.  Same bits either way (A/B timing, parity of the two kernels). */
+int32_t revo_op_set_qstores(int32_t on);
 /* diagnostic: device array [workgroups][items][4] of uint64 the phased kernel fills with 100 MHz time stamps (main loop
  * begin, main loop end, epilogue issued) and the piece's rows, for its first `items` pieces per workgroup; NULL = off */
 int32_t revo_debug_gemm_stamps(void* buf, int32_t items);

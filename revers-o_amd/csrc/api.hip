@@ -1341,6 +1341,12 @@ extern "C" int32_t revo_op_set_ln_fold(int32_t on) {
     revo::gemm_set_ln_fold(on);
     return 0;
 }
+// 0: the bf16 epilogues on gemm256p_kernel (a tile's stores drained before the next main loop: the round-5 kernels); 1: default,
+// gemm256q_kernel (stores left in flight through the next tile's first K-tile).  Same results either way.
+extern "C" int32_t revo_op_set_qstores(int32_t on) {
+    revo::gemm_set_qstores(on);          // (2: queued, stores dropped -- timing experiment, WRONG RESULTS)
+    return 0;
+}
 // phase groups of the persistent 256 x 256 GEMM (gemm.hip gemm256pp_kernel): 0 = the launcher's choice, 1 = off, 2..4 forced
 extern "C" int32_t revo_op_set_phase_groups(int32_t groups) {
     REVO_REQUIRE(groups >= 0 && groups <= 4, "set_phase_groups: 0 (heuristic), 1 (off) or 2..4");

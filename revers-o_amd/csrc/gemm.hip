@@ -555,11 +555,15 @@ constexpr int LNC_RAW_BYTES = 256 * 6 * 8 + 1024, LNC_MR_BYTES = 256 * 8;    // 
 constexpr int G256P_LN_OFF = 98304 + 5 * 9216;                                // persistent kernel: above the last slab (144384)
 static_assert(G256P_LN_OFF + LNC_RAW_BYTES + LNC_MR_BYTES <= 163840, "");
 constexpr int G256_LDS_LN = G256_LDS + LNC_RAW_BYTES + LNC_MR_BYTES;          // one-tile kernel: above the operand image
+constexpr int G256Q_BC_OFF = G256_LDS_LN + LNC_MR_BYTES;                      // queued-stores kernel: (rstd, -mean rstd) in two buffers, then
+constexpr int G256Q_LDS = G256Q_BC_OFF + 2 * 2048;                            // bias | column sums of a tile's 256 columns, two buffers
+static_assert(G256Q_LDS <= 163840, "");
 // DMA of the statistics of rows [m0, m0 + 256): one 1-KiB piece per wave-instruction, pieces dealt over the 8 waves.  Issued
 // BEFORE operand DMA the main loop's counted waits cover (vmcnt retires in issue order), read after the main loop's barriers.
 // (lane ids are made opaque in these helpers: the main loop runs at the 256-VGPR limit, and an address the compiler computes
 //  ahead of it is spilled and reloaded behind it -- a scratch load whose wait also drains the DMA queue and every older store)
-__device__ __forceinline__ void lnc_issue_stats(const GemmArgs& p, int m0, char* lds_raw, int wave, int /*lane*/) {
+template <class ARGS>      // GemmArgs, or the same struct read through the kernarg segment (gemm256q_kernel)
+__device__ __forceinline__ void lnc_issue_stats(const ARGS& p, int m0, char* lds_raw, int wave, int /*lane*/) {
     if (wave >= 4) return;
     int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // (see lnc_merge_rows)
     asm volatile("" : "+v"(lane) :: "memory");
@@ -583,7 +587,10 @@ __device__ __forceinline__ void lnc_issue_stats(const GemmArgs& p, int m0, char*
 // a wave reads only slots it requested itself (behind its own counted wait: the statistics are older than the K-tile
 // DMA the main loop's first wait leaves in flight), and the epilogue reads lds_mr behind the main loop's barriers.
 // tele (wave-uniform; the tile is the launch's column tile 0 and the caller asked for telemetry): rows_left = M - m0.
-__device__ __forceinline__ void lnc_merge_rows(const GemmArgs& p, const char* lds_raw, float2* lds_mr, int wave, int /*lane*/, bool one_ktile,
+// VM: vector-memory instructions this wave has issued BEHIND its statistics pieces that may stay in flight (the ordinary
+// kernels: the four halves of K-tile 1's A operand; the queued-stores kernel: the previous tile's sixteen stores).
+template <int VM = 4, class ARGS = GemmArgs>
+__device__ __forceinline__ void lnc_merge_rows(const ARGS& p, const char* lds_raw, float2* lds_mr, int wave, int /*lane*/, bool one_ktile,
                                                bool tele = false, int rows_left = 0) {
     if (wave >= 4) return;
     // (the lane id is read from the hardware here: derived from the kernel's `lane` it became one more value alive across
@@ -591,7 +598,7 @@ __device__ __forceinline__ void lnc_merge_rows(const GemmArgs& p, const char* ld
     int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(lane) :: "memory");
     if (one_ktile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM) : "memory");
     const int t = wave * 64 + lane;
     if (t < 256) {
         float r, m;
@@ -625,9 +632,14 @@ __device__ __forceinline__ void lnc_merge_rows(const GemmArgs& p, const char* ld
             const unsigned long long big = __builtin_amdgcn_ballot_w64(am > LNC_TELE_RATIO);
             const unsigned long long huge = __builtin_amdgcn_ballot_w64(am > 4.0f * LNC_TELE_RATIO);
             if (lane == 0 && live > 0) {                  // (ballots and counts are scalar: no vector register lives past here)
-                atomicAdd(p.lnc_tele, (unsigned long long)live);
-                if (big) atomicAdd(p.lnc_tele + 1, (unsigned long long)__builtin_popcountll(big));
-                if (huge) atomicAdd(p.lnc_tele + 2, (unsigned long long)__builtin_popcountll(huge));
+                // the counters' address in vector registers DEFINED HERE: addressed off the scalar pointer, the atomics took a
+                // zero offset register that hipcc hoisted out of the persistent loop and parked in scratch around it -- and
+                // every scratch access near the DMA queue is a drain of it
+                unsigned long long* tp = p.lnc_tele;
+                asm volatile("" : "+v"(tp));
+                atomicAdd(tp, (unsigned long long)live);
+                if (big) atomicAdd(tp + 1, (unsigned long long)__builtin_popcountll(big));
+                if (huge) atomicAdd(tp + 2, (unsigned long long)__builtin_popcountll(huge));
             }
         }
     }
@@ -913,6 +925,294 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
     }
 }
 
+
+// ---- Persistent 256 x 256 kernel with QUEUED STORES (bf16 epilogues: plain, GELU, RoPE; 256-row tiles, N % 256 == 0, K >= 128).
+// gemm256p_kernel's phases run in series on every CU at the same moments: a tile's stores are pushed out (3.4 us at the
+// per-CU store rate), and the next main loop's first wait for an operand requested behind them also waits for every one
+// of them to be acknowledged (loads, DMA and stores retire in order: ~1.8 us of drain inside qkv's main loop,
+// profiles/r05_gemm_phase_groups.json).  Here
+//   * the epilogue never touches the operand image: a tile's values go from the accumulators to 16-byte row chunks in
+//     REGISTERS (bias / folded LayerNorm / GELU / RoPE on the accumulator layout, v_cvt_pk_bf16_f32, then two
+//     v_permlane16_swap_b32 per fragment pair: lanes l and l ^ 16 hold columns c..c+3 and c+4..c+7 of one row and trade
+//     halves, so that each ends up with 8 consecutive columns of one fragment) -- no LDS slab, no transposing reads;
+//   * so the next tile's first K-tile and a half (both operands of K-tile 0, A of K-tile 1) are requested right behind the
+//     main loop's last barrier, before any epilogue arithmetic, and have the whole epilogue to land;
+//   * the tile's 16 stores per wave are issued back to back at the very end, as bounds-checked buffer stores (rows past
+//     the matrix edge are dropped by the descriptor: the instruction count never depends on the data), and
+//     gemm256_mainloop<..., QS = 16> enters on a counted wait that leaves them in flight through its first K-tile.
+// Queue of one wave, oldest first, when the main loop starts:  [K-tile 0: 8] [A of K-tile 1: 4] [stores: 16].  The first
+// tile of a workgroup issues 16 dropped stores (an empty descriptor) so that every tile meets the same counts.  LDS: the operand image, and above it the folded LayerNorm's statistics as in gemm256_kernel.
+// Per element the arithmetic is gemm256_epilogue's (same operations, same order: bias or rstd * acc + (c * mr + b'),
+// GELU, bf16 rounding BEFORE the rotation); only the route to memory differs -- 64-byte row segments per store
+// instruction instead of 128-byte ones, two adjacent instructions completing each 128-byte line.
+constexpr int G256Q_STORES = 16;
+template <int EPI>
+__global__ __launch_bounds__(G256_THREADS, 2) void gemm256q_kernel(GemmArgs p, int nslot) {
+    static_assert(EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE, "");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = p.N >> 8;
+    const int tiles_m = (p.M + 255) >> 8;
+    const int gy = p.gy, gx = 8 / gy;
+    const int xcd = blockIdx.x & 7;
+    const int xi = __builtin_amdgcn_readfirstlane(xcd / gy), xj = xcd - xi * gy;
+    const int pm = __builtin_amdgcn_readfirstlane((tiles_m + gx - 1) / gx), pn = __builtin_amdgcn_readfirstlane((tiles_n + gy - 1) / gy);
+    const int m_lo = xi * pm, n_lo = xj * pn;
+    const int m_cnt = (tiles_m - m_lo) < pm ? (tiles_m - m_lo) : pm;
+    const int n_cnt = (tiles_n - n_lo) < pn ? (tiles_n - n_lo) : pn;
+    const int total = (m_cnt > 0 && n_cnt > 0) ? m_cnt * n_cnt : 0;
+    int slot = blockIdx.x >> 3;
+    if (slot >= total) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+
+    int sq = __builtin_amdgcn_readfirstlane(slot / n_cnt);
+    int m0 = (m_lo + sq) * 256, n0 = (n_lo + (slot - sq * n_cnt)) * 256;
+    const bool lnc = p.lnc_stats != nullptr;
+    char* lds_raw = smem + G256_LDS;
+    // (rstd, -mean rstd) of a tile's rows, two buffers used in turn: the merge for tile i + 1 (behind tile i's stores) may
+    // overtake another wave's reads for tile i (at the head of its epilogue) -- no barrier between a tile's stores and the
+    // next main loop
+    float2* lds_mr = (float2*)(smem + G256_LDS + LNC_RAW_BYTES);
+    float2* lds_mr_next = lds_mr + 256;
+    // bias and column sums of a tile's 256 columns travel to LDS with the tile's first operands (one 1-KiB DMA each, waves 4
+    // and 5; an EMPTY descriptor -- the vector is absent -- delivers zeros): the epilogue then starts without a load to wait
+    // for.  Two buffers in turn, like lds_mr: a wave may request tile i + 1's while another still reads tile i's.
+    char* lds_bc = smem + G256Q_BC_OFF;
+    char* lds_bc_next = lds_bc + 2048;
+    auto issue_bias_csum = [&](const float* bias, const float* csum, int N, int n0_, char* dst, int lane_) {
+        if (wave == 4 || wave == 5) {                       // wave-uniform
+            const float* src = wave == 4 ? bias : csum;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + n0_), 0, src ? (N - n0_ < 256 ? N - n0_ : 256) * 4 : 0, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + (wave - 4) * 1024), 16,
+                                                     (uint32_t)(lane_ * 16), 0, 0, 0);
+        }
+    };
+    if (lnc) lnc_issue_stats(p, m0, lds_raw, wave, lane);
+    issue_bias_csum(p.bias, lnc ? p.lnc_c : nullptr, p.N, n0, lds_bc, lane);
+    G256Operand A, B;
+    g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane);
+    g256_operand_init(B, p.B, p.ldb, p.N, n0, wave, lane);
+    g256_issue_prologue(A, B, smem, p.K, wave);
+    G256_FENCE();
+    {   // the first tile's stand-ins for a previous tile's stores: an empty descriptor drops them
+        const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0, 0x00020000);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < G256Q_STORES; ++i)          // (distinct offsets: identical stores would be merged into one)
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){0u, 0u, 0u, 0u}, none, i * 16, 0, 0);
+    }
+    G256_FENCE();
+#ifdef REVO_EXPERIMENTS
+    int tiles_done = 0;
+#endif
+    // (rstd, -mean rstd) of the first tile's rows; the wait leaves the 16 youngest instructions in flight, here the stand-ins.
+    // Without a folded LayerNorm every row gets (1, 0): the epilogue below has ONE form, rstd * acc + (c * mr + b) with c = 0
+    // -- the bits of acc + b -- instead of two forms joined by selects whose constant sides (zero vectors) hipcc kept in a
+    // dozen registers across the main loop.
+    if (lnc) lnc_merge_rows<G256Q_STORES>(p, lds_raw, lds_mr, wave, lane, false, p.lnc_tele != nullptr && n0 == 0, p.M - m0);
+    else if (threadIdx.x < 512) lds_mr[threadIdx.x] = make_float2(1.f, 0.f);        // both buffers (read behind the main loop's barriers)
+    for (;;) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef REVO_EXPERIMENTS
+        // diagnostic stamps (scripts/gemm_qstamps.py): 100 MHz clock at main loop begin / end, epilogue arithmetic done, stores issued
+        unsigned long long t_a = 0, t_b = 0, t_c = 0;
+        if (p.stamps) t_a = __builtin_amdgcn_s_memrealtime();
+#endif
+        gemm256_mainloop<0, false, false, G256Q_STORES>(A, B, smem, p.K, wave, lane, acc);
+#ifdef REVO_EXPERIMENTS
+        if (p.stamps) t_b = __builtin_amdgcn_s_memrealtime();
+#endif
+
+        // ------------------------------------------------------------------ epilogue, in registers
+        // The kernel's arguments are read again from the kernarg segment here (through a pointer the compiler cannot see
+        // through): kept in scalar registers across the main loop, the pointers and sizes the epilogue and the next tile's
+        // set-up need -- some forty registers on top of the two operands' eight descriptors -- overflowed the scalar file
+        // into vector-register lanes, and the main loop, which runs at the 256-VGPR limit, spilled accumulators for them.
+        const __attribute__((address_space(4))) GemmArgs* pk = (const __attribute__((address_space(4))) GemmArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(pk));
+        const __attribute__((address_space(4))) GemmArgs& q = *pk;
+        int lane_e;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        const int lr = lane_e & 15, lq = lane_e >> 4;
+        const int wr = wave >> 2, wc = wave & 3;
+        const int m0_done = m0, n0_done = n0;
+        const int nb = n0_done + wc * 64;                           // this wave's first column
+        slot += nslot;
+        const bool more = slot < total;
+        // (0) (rstd, -mean rstd) of this lane's eight fragment rows, out of LDS before ANY vector-memory request of the
+        //     epilogue: hipcc guards an LDS read with s_waitcnt vmcnt(0) while DMA it knows of may be outstanding (it cannot
+        //     tell the operand image from the statistics, nor see the main loop's counted waits) -- here that wait is free
+        float2 st8[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) st8[m] = lds_mr[wr * 128 + m * 16 + lr];
+        //     ... and the tile's bias and column sums (requested with its first operands)
+        f32x4 bias4[4], c4[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            bias4[n] = *(const f32x4*)(lds_bc + (wc * 64 + n * 16 + lq * 4) * 4);
+            c4[n] = *(const f32x4*)(lds_bc + 1024 + (wc * 64 + n * 16 + lq * 4) * 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        G256_FENCE();
+        // (1) what the RoPE form needs from memory, requested BEFORE the next tile's operands
+        // RoPE table: entry (token, pair) as (cos, sin); a lane's fragment holds two pairs of one token: one 16-byte load
+        // per fragment, through a descriptor (32-bit offsets).  Token of fragment row m: tok0 + 16 m (mod S).
+        const bool rot = EPI == EPI_BF16_ROPE && nb < q.rope_cols;            // wave-uniform (rope_cols % 64 == 0: launcher)
+        __amdgpu_buffer_rsrc_t rtab = __builtin_amdgcn_make_buffer_rsrc((void*)q.rope_cs, 0, EPI == EPI_BF16_ROPE ? q.rope_S * (q.rope_hd >> 1) * 8 : 0, 0x00020000);
+        int tok = 0, cpair[4] = {0, 0, 0, 0};
+        if (EPI == EPI_BF16_ROPE) {
+            tok = (m0_done + wr * 128 + lr) % q.rope_S;
+            int c0 = (nb + lq * 4) % q.rope_hd;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                cpair[n] = (c0 >> 1) * 8;                                     // byte offset of the pair inside a token's row
+                c0 += 16;
+                if (c0 >= q.rope_hd) c0 -= q.rope_hd;
+            }
+        }
+        const int tok_row_bytes = (q.rope_hd >> 1) * 8;
+        f32x4 rt[2][2][4];                                                    // [buffer][m of the quarter][fragment]
+        auto rope_load = [&](auto bufc) {                                     // the next quarter (two fragment rows) into buffer `buf`
+            constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    rt[buf][mm][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rtab, tok * tok_row_bytes + cpair[n], 0, 0));
+                tok += 16;
+                if (tok >= q.rope_S) tok -= q.rope_S;
+            }
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        if (rot) { rope_load(I0{}); rope_load(I1{}); }
+        // ... and waited for HERE, before any DMA is in flight: hipcc's wait counts leave LDS-DMA instructions out, so a
+        // wait it places for one of these loads behind the requests below (vmcnt(5), (4), ... (0), as it did) is a wait for
+        // the DMA as well.  The empty asm statements are "uses": the waits land in front of them.
+        if (rot) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(rt[i][mm][n]));
+        }
+        G256_FENCE();
+        // (2) the next tile: statistics, then its first K-tile and a half (the image is free: the main loop ended behind a
+        //     barrier, and nothing below touches it)
+        if (more) {
+            sq = __builtin_amdgcn_readfirstlane(slot / n_cnt);
+            m0 = (m_lo + sq) * 256;
+            n0 = (n_lo + (slot - sq * n_cnt)) * 256;
+            if (lnc) lnc_issue_stats(q, m0, lds_raw, wave, lane_e);
+            issue_bias_csum(q.bias, lnc ? q.lnc_c : nullptr, q.N, n0, lds_bc_next, lane_e);
+            g256_operand_init(A, q.A, q.lda, q.M, m0, wave, lane_e);
+            g256_operand_init(B, q.B, q.ldb, q.N, n0, wave, lane_e);
+            g256_issue_prologue(A, B, smem, q.K, wave);
+        }
+        G256_FENCE();
+        // (3) accumulators -> bf16 row chunks.  out[m][P]: row m * 16 + lr, 8 columns from (2 P + (lq & 1)) * 16 + (lq >> 1) * 8
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        // (4) ... and each quarter's four stores right behind its arithmetic: a CU takes stores at ~30 GB/s (128 KB per tile:
+        //     4-5 us, profiles/r06_gemm_queued_stores.json), several times longer than the arithmetic in front of them -- issued
+        //     as a block of 16 at the end, every wave sat in its store instructions while nothing else ran.  One descriptor
+        //     per tile: rows past the matrix edge lie beyond num_records and are dropped, so all 16 instructions are issued
+        //     (and counted) whatever the tile holds.
+        const long rows_here = (long)q.M - m0_done < 256 ? (long)q.M - m0_done : 256;
+#ifdef REVO_EXPERIMENTS
+        const bool drop_stores = (q.stagger_groups & 0x100) != 0;          // timing experiment: the stores are issued but move nothing
+#else
+        constexpr bool drop_stores = false;
+#endif
+        const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((bf16_t*)q.C + (long)m0_done * q.ldc + n0_done), 0, drop_stores ? 0 : (int)((rows_here - 1) * q.ldc * 2 + 512), 0x00020000);
+        const int rstep = (int)(q.ldc * 32);                                   // 16 rows, bytes
+        int voff = (wr * 128 + lr) * (int)(q.ldc * 2) + (wc * 64 + (lq & 1) * 16 + (lq >> 1) * 8) * 2;
+        auto quarter = [&](auto qc, auto bufc) {
+            u32x4 out[2][2];
+            constexpr int q = decltype(qc)::value, buf = decltype(bufc)::value;
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                constexpr int dummy_ = 0; (void)dummy_;
+                const int m = q * 2 + mm;
+                const float2 st = st8[m];
+                uint32_t d[4][2];
+#pragma unroll
+                for (int n0f = 0; n0f < 4; n0f += 2) {
+                    f32x4 v[2];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) v[n] = acc[m][n0f + n] * st.x + (c4[n0f + n] * st.y + bias4[n0f + n]);
+                    if (EPI == EPI_BF16_GELU) gelu_erf4xn<2>(v);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        uint32_t w0 = pack_bf16x2(v[n][0], v[n][1]), w1 = pack_bf16x2(v[n][2], v[n][3]);
+                        if (EPI == EPI_BF16_ROPE) {
+                            if (rot) {                 // K5 on the bf16-rounded values, as every other path rotates them
+                                const f32x4 tc = rt[buf][mm][n0f + n];
+                                const float a0 = __uint_as_float(w0 << 16), a1 = __uint_as_float(w0 & 0xffff0000u);
+                                const float b0 = __uint_as_float(w1 << 16), b1 = __uint_as_float(w1 & 0xffff0000u);
+                                w0 = pack_bf16x2(a0 * tc[0] - a1 * tc[1], a1 * tc[0] + a0 * tc[1]);
+                                w1 = pack_bf16x2(b0 * tc[2] - b1 * tc[3], b1 * tc[2] + b0 * tc[3]);
+                            }
+                        }
+                        d[n0f + n][0] = w0;
+                        d[n0f + n][1] = w1;
+                    }
+                }
+#pragma unroll
+                for (int P = 0; P < 2; ++P) {
+                    // rows 1 and 3 of the first register trade places with rows 0 and 2 of the second (rows of 16 lanes): an even
+                    // row keeps its own half of fragment 2 P and receives its neighbour's; an odd row likewise for 2 P + 1
+                    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(d[2 * P][0], d[2 * P + 1][0], false, false);
+                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(d[2 * P][1], d[2 * P + 1][1], false, false);
+                    out[mm][P] = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+                }
+            }
+            G256_FENCE();
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                // qkv and the MLP hidden activations are written once and read once by the next kernel: non-temporal
+                // (aux = 2), as gemm256_epilogue stores them
+                constexpr int aux = (EPI == EPI_BF16_ROPE || EPI == EPI_BF16_GELU) ? 2 : 0;
+                __builtin_amdgcn_raw_buffer_store_b128(out[mm][0], crs, voff, 0, aux);
+                __builtin_amdgcn_raw_buffer_store_b128(out[mm][1], crs, voff + 64, 0, aux);
+                voff += rstep;
+            }
+            G256_FENCE();
+        };
+#ifdef REVO_EXPERIMENTS
+        if (q.stamps) t_c = __builtin_amdgcn_s_memrealtime();          // (epilogue set-up done: loads waited for, DMA requested)
+#endif
+        quarter(I0{}, I0{});
+        if (rot) rope_load(I0{});
+        quarter(I1{}, I1{});
+        if (rot) rope_load(I1{});
+        quarter(I2{}, I0{});
+        quarter(I3{}, I1{});
+        G256_FENCE();
+#ifdef REVO_EXPERIMENTS
+        if (q.stamps && wave == 0 && lane_e == 0 && tiles_done < q.stamp_items) {
+            unsigned long long* dst = q.stamps + ((size_t)blockIdx.x * q.stamp_items + tiles_done) * 4;
+            dst[0] = t_a; dst[1] = t_b; dst[2] = t_c; dst[3] = __builtin_amdgcn_s_memrealtime();
+        }
+        ++tiles_done;
+#endif
+        if (!more) break;
+        if (lnc) {
+            // the next tile's rows, into the other buffer: the wait leaves the 16 youngest instructions -- the stores -- in
+            // flight; the statistics pieces are the oldest
+            lnc_merge_rows<G256Q_STORES>(q, lds_raw, lds_mr_next, wave, lane_e, false, q.lnc_tele != nullptr && n0 == 0, q.M - m0);
+        }
+        { float2* t = lds_mr; lds_mr = lds_mr_next; lds_mr_next = t; }
+        { char* t = lds_bc; lds_bc = lds_bc_next; lds_bc_next = t; }
+    }
+}
+
 #ifdef REVO_EXPERIMENTS
 // Phased form of the persistent kernel -- EXPERIMENT LIBRARY ONLY: measured in round 5 and not adopted (DESIGN_HISTORY.md,
 // profiles/r05_gemm_phase_groups.json: bit-identical, 5-12 % slower on three of the four body GEMMs, +-0 on out-proj).
@@ -1194,6 +1494,45 @@ static int launch_256p(const GemmArgs& a, hipStream_t st) {
 static int g_dbg = 0;          // timing experiments only (EPI_BF16, librevo_exp.so): 1 = no epilogue stores, 2 = no main loop
 void gemm_set_debug(int d) { g_dbg = d; }
 #endif
+// the persistent kernel with queued stores (gemm256q_kernel): bf16 epilogues on whole 256-column tiles
+static int g_qstores = 1;      // timing experiments only: 0 = gemm256p_kernel for every epilogue
+void gemm_set_qstores(int on) { g_qstores = on; }
+template <int EPI>
+static bool use_256q(const GemmArgs& a) {
+    if (!(EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE) || !g_qstores) return false;
+    if (a.N % 256 || a.K < 128 || (a.ldc & 7) || 256l * a.ldc * 2 >= (1l << 31)) return false;
+    if (EPI == EPI_BF16_ROPE && (a.rope_cols % 64 || (long)a.rope_S * (a.rope_hd >> 1) * 8 >= (1l << 31))) return false;
+    // RoPE: measured, not adopted (profiles/r06_gemm_queued_stores.json): the rotation's 32 table loads per lane must be
+    // waited for behind the next tile's DMA requests, and hipcc's wait counts leave LDS-DMA out -- every such wait is a
+    // wait for the DMA too; and with its short arithmetic the form gains nothing from stores issued early (the plain
+    // bf16 form: +-0).  qkv stays on gemm256p_kernel unless the switch says 3.
+    if (EPI == EPI_BF16_ROPE && g_qstores != 3) return false;
+    return true;
+}
+template <int EPI>
+static int launch_256q(const GemmArgs& a, hipStream_t st) {
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE) {
+        GemmArgs b = a;
+#ifdef REVO_EXPERIMENTS
+        b.stamps = g_stamps; b.stamp_items = g_stamp_items;
+        b.stagger_cycles = 0; b.stagger_groups = g_qstores == 2 ? 0x100 : 0;       // 2: the stores are issued but dropped (timing only)
+#endif
+        const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
+        int gy = tiles_n >= 12 ? 4 : (tiles_n >= 8 ? 2 : 1);
+        if (g_force_gy) gy = g_force_gy;
+        b.gy = gy;
+        const int gx = 8 / gy;
+        const int region = ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
+        const int nslot = region < 32 ? region : 32;          // 32 CUs per XCD
+        REVO_FUNC_LDS((gemm256q_kernel<EPI>), G256Q_LDS);
+        hipLaunchKernelGGL((gemm256q_kernel<EPI>), dim3(8 * nslot), dim3(G256_THREADS), G256Q_LDS, st, b, nslot);
+        REVO_HIP_CHECK(hipGetLastError());
+        return 0;
+    } else {
+        revo_set_error("gemm: internal: queued stores with a non-bf16 epilogue");
+        return -3;
+    }
+}
 template <int EPI>
 static int launch_256(const GemmArgs& a, hipStream_t st) {
 #ifdef REVO_EXPERIMENTS
@@ -1205,7 +1544,14 @@ static int launch_256(const GemmArgs& a, hipStream_t st) {
         }
     }
 #endif
-    if (g_persistent && a.K >= 128 && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) > 256) return launch_256p<EPI>(a, st);
+    if (g_persistent && a.K >= 128 && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) > 256) {
+#ifdef REVO_EXPERIMENTS
+        if (use_256q<EPI>(a) && g_phase_groups <= 1 && g_stagger_cycles == 0) return launch_256q<EPI>(a, st);      // (its own stamps: revo_debug_gemm_stamps)
+#else
+        if (use_256q<EPI>(a)) return launch_256q<EPI>(a, st);
+#endif
+        return launch_256p<EPI>(a, st);
+    }
     return launch_256d<EPI, 0>(a, st);
 }
 

@@ -185,12 +185,21 @@ __device__ __forceinline__ void g256_issue_prologue_deep(const G256Operand& A, c
 // ordinary schedule B of tile t + 1 is requested half a tile ahead: with MFMA work for 64 query rows only a K-tile takes
 // about as long as the CU's share of HBM delivers its 32 KiB (1.3 us), less than a DMA's latency, and the loop ran at
 // one gallery K-tile per latency: 5.3 of the 6.3 TB/s a copy reaches.
-template <int ROWS = 0, bool RT = false, bool DEEP = false>
+// QS > 0 (queued stores: gemm.hip gemm256q_kernel): behind g256_issue_prologue the caller has issued exactly QS more
+// vector-memory instructions -- the previous output tile's stores -- which the first wait leaves in flight:
+// vmcnt(4 + QS) instead of vmcnt(4).  They retire with the wait at the end of K-tile 0 (B of tile 1, requested behind
+// them inside the loop, is what that wait is for): one K-tile after they were issued instead of before the first MFMA.
+// Nothing inside the loop changes.  (Requesting tile 1's B ahead of the stores as well gives them two K-tiles, but tile 0
+// must then skip its B requests and count differently: with those run-time tests of t == 0 hipcc peeled the first trip,
+// parked an accumulator in scratch around it and reloaded it behind an s_waitcnt vmcnt(0) -- once per output tile, a
+// drain of the DMA queue where this mode is meant to remove one.)  Needs K >= 128.
+template <int ROWS = 0, bool RT = false, bool DEEP = false, int QS = 0>
 __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G256Operand& B, char* smem, int K,
                                                  int wave, int lane, f32x4 (&acc)[8][4], bool tall = false,
                                                  bool rt_lo = true, bool rt_hi = true) {
     static_assert(ROWS == 0 || ROWS == 64 || ROWS == 128 || ROWS == 192, "");
     static_assert(!RT || ROWS == 0, "the run-time row mode has no compile-time one");
+    static_assert(QS == 0 || (!DEEP && QS + 4 <= 63), "queued stores: the ordinary schedule, and a count vmcnt can hold");
     const bool wact = wave < 4;
 #define G256_LO(...) do { if (RT ? rt_lo : (ROWS == 0 || ROWS == 192 || wact)) { __VA_ARGS__; } } while (0)
 #define G256_HI(...) do { if (RT ? rt_hi : (ROWS == 0 || ((ROWS == 128 || ROWS == 192) && wact))) { __VA_ARGS__; } } while (0)
@@ -200,7 +209,9 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
     G256Addr ad;
     g256_addr_init(ad, wave, lane);
 
-    if (nt > 1) {
+    if (QS) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + QS) : "memory");
+    } else if (nt > 1) {
         if (DEEP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {

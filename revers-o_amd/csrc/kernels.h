@@ -140,6 +140,7 @@ void gemm_set_min_tiles256(int n);  // timing experiments only (default 100)
 void gemm_set_ring(int on, int max_tiles);   // timing experiments only (default on, 256 tiles)
 void gemm_set_splitk(int on);       // timing experiments only (1 = default)
 void gemm_set_persistent(int on);   // timing experiments only (1 = default)
+void gemm_set_qstores(int on);      // timing experiments only (1 = default): 0 = the bf16 epilogues on gemm256p_kernel (stores drained before the next main loop)
 void gemm_set_rows192(int on);      // timing experiments only (1 = default)
 void gemm_set_ln_fold(int on);      // timing experiments only (1 = default): 0 = LayerNorm kernels instead of the folded form, 2 = folded with an fp32 stream
 bool gemm_ln_planes_enabled();

@@ -455,8 +455,74 @@ def test_gemm_repeat_determinism_large_grids(lib, dev, gemm_tile):
             assert all(torch.equal(o, outs[0]) for o in outs[1:]), (M, N, K, epi)
 
 
+@pytest.mark.parametrize("M,K,epi,lnfold,with_bias", [(36928, 1024, 0, True, True), (36928, 1024, 1, True, True),      # qkv- / fc1-shaped
+                                                     (33000, 128, 0, False, True), (33100, 320, 1, False, False),     # two K-tiles; five, no bias
+                                                     (70000, 192, 1, True, True), (36928, 1024, 5, True, True)])      # three K-tiles; RoPE
+def test_gemm_queued_stores_kernel_equals_the_drained_one(dev, gemm_tile, M, K, epi, lnfold, with_bias):
+    """gemm256q_kernel (round 6: a tile's values go from the accumulators to 16-byte row chunks in registers -- two
+    v_permlane16_swap per fragment pair instead of an LDS transpose -- and its stores stay in flight through the next tile's
+    first K-tile) against gemm256p_kernel (stores transposed through LDS and drained before the next main loop): the same
+    bits, for every bf16 epilogue, with and without the folded LayerNorm and the bias, with rows past the matrix edge in the
+    last tile row (dropped by the store descriptor) and with two to sixteen K-tiles; and against fp32 torch."""
+    if gemm_tile != 0:
+        pytest.skip("runs once: the switch lives in librevo_exp.so")
+    lib = _lib.load_exp()
+    N = 2560 if K != 1024 else (3072 if epi != 1 else 4096)
+    g = torch.Generator(device=dev).manual_seed(M + K + epi)
+    x = torch.randn(M, K, generator=g, device=dev) * (torch.rand(M, 1, generator=g, device=dev) * 2 + 0.3) + torch.randn(M, 1, generator=g, device=dev)
+    a = x.bfloat16()
+    b = (torch.randn(N, K, generator=g, device=dev) * 0.05).bfloat16()
+    bias = torch.randn(N, generator=g, device=dev) if with_bias else None
+    st = _lib.current_stream()
+    csum = b.float().sum(1)
+    stats = None
+    if lnfold and K % 256 == 0:
+        xs = x.view(M, K // 256, 256)
+        mm = xs.mean(2)
+        stats = torch.stack([mm, ((xs - mm[..., None]) ** 2).sum(2)], dim=-1).contiguous()
+    S, hd = 577, 64
+    cs = torch.randn(S, hd // 2, 2, generator=g, device=dev)
+
+    def run():
+        c = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        if epi == 5:
+            _lib.check(lib.revo_op_gemm_rope(_lib.ptr(a), K, _lib.ptr(b), K, M, N, K, _lib.ptr(c), N, _lib.ptr(bias), _lib.ptr(cs), S, hd,
+                                             2 * N // 3, st), "gemm_rope")
+        elif stats is not None:
+            _lib.check(lib.revo_op_gemm_ln_in(epi, _lib.ptr(a), K, _lib.ptr(b), K, M, N, K, _lib.ptr(c), N, _lib.ptr(bias), _lib.ptr(csum),
+                                              _lib.ptr(stats), K // 256, 1e-5, None, st), "gemm_ln_in")
+        else:
+            _lib.check(lib.revo_op_gemm(epi, _lib.ptr(a), K, _lib.ptr(b), K, M, N, K, _lib.ptr(c), N, _lib.ptr(bias), None, st), "gemm")
+        torch.cuda.synchronize()
+        return c
+    try:
+        _lib.check(lib.revo_op_set_qstores(0))
+        drained = run()
+        _lib.check(lib.revo_op_set_qstores(3 if epi == 5 else 1))      # (3: the RoPE form too -- built and bit-identical, not the default)
+        queued = [run() for _ in range(3)]
+    finally:
+        _lib.check(lib.revo_op_set_qstores(1))
+    assert torch.isfinite(queued[0].float()).all()
+    assert all(torch.equal(q, queued[0]) for q in queued[1:])          # repeatable
+    assert torch.equal(queued[0], drained)
+    rows = torch.cat([torch.arange(0, 300, device=dev), torch.arange(M - 300, M, device=dev)])
+    ref = a[rows].double() @ b.double().T
+    if stats is not None and epi != 5:
+        xd = x[rows].double()
+        mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+        ref = (ref - mean * csum.double()) / torch.sqrt(var + 1e-5)
+    if bias is not None:
+        ref = ref + bias.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi != 5:
+        err = (queued[0][rows].double() - ref).abs().max().item()
+        assert err <= 0.006 * ref.abs().max().item() + 2e-3, err
+
+
 @pytest.mark.parametrize("M,S,H,hd", [(577, 577, 4, 64), (1970, 197, 12, 64), (2364, 197, 12, 64), (4616, 577, 4, 64),
-                                      (1024, 1024, 2, 96), (36928, 577, 2, 64), (130, 65, 2, 64)])
+                                      (1024, 1024, 2, 96), (36928, 577, 2, 64), (130, 65, 2, 64),
+                                      (36928, 577, 4, 64), (32768, 1024, 8, 96)])        # the last two: whole 256-column tiles (queued-stores kernel)
 def test_gemm_with_fused_rope_equals_gemm_then_rope(lib, dev, gemm_tile, M, S, H, hd):
     """The QKV projection with RoPE in the epilogue (any tile family) == the plain projection followed by the
     stand-alone RoPE kernel, bit for bit, and is the same on every repeat."""

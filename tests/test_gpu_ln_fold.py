@@ -219,14 +219,15 @@ def test_consuming_gemm_applies_the_row_statistics(lib, dev, M, N, K, epi):
     assert e_fold <= 2.5 * e_plain + 1e-4, (e_fold, e_plain)      # rows with an offset of the order of their spread: same class of error
 
 
-@pytest.mark.parametrize("epi", [0, 1])
-def test_fold_error_against_the_row_offset(lib, dev, epi):
+@pytest.mark.parametrize("M,N,epi", [(4096, 3072, 0), (4096, 3072, 1), (16384, 3072, 0)])     # one-tile 256 x 256 kernel; persistent (queued stores): whole rounds,
+                                                                                             # no leftover rows on other kernels (those are not sampled)
+def test_fold_error_against_the_row_offset(lib, dev, M, N, epi):
     """The regime the fold is weakest in: A = bf16(x) is NOT centred, so bf16 spends its 8 bits on a row's common offset.
     Rows with offsets of 0 / 2 / 8.5 / 33 standard deviations (each block of rows at one offset), folded consumer against
     LayerNorm kernel -> bf16 -> plain GEMM, both against the fp64 LayerNorm + linear: the ratio e_fold / e_plain per offset is
     printed (DESIGN.md quotes it) and held to a bound a trained checkpoint would be held to, and the consumer's telemetry
     (include/revo.h revo_vit_stats: rows with |mean| * rstd > 8) counts exactly the rows of the 8.5- and 33-sigma blocks."""
-    M, N, K = 4096, 1024, 1024                       # 16 x 4 tiles: the one-tile 256 x 256 kernel
+    K = 1024
     offs = [0.0, 2.0, 8.5, 33.0]                      # (8.5 / 33: safely on the far side of the telemetry's ratios 8 and 32)
     g = torch.Generator(device=dev).manual_seed(77 + epi)
     z = torch.randn(M, K, generator=g, device=dev)

@@ -134,6 +134,14 @@ def test_body_gemm_kernels_stay_within_their_allocation():
     for epi in (0, 1, 2, 5):
         u = _find(d, "gemm256_kernel", f"ILi{epi}ELi0E")
         assert u["VGPRs Spill"] == 0, (epi, u)
+    # gemm256q_kernel<EPI> (round 6, queued stores; fc1's GELU form and the plain bf16 form run on it): NOTHING parked.  Its
+    # epilogue keeps the next tile's DMA and this tile's stores in flight while it computes, and every scratch access is
+    # guarded by an s_waitcnt vmcnt(0) that drains both (hipcc's wait counts leave LDS-DMA out) -- the first builds parked
+    # 11-28 registers (zero vectors of two-sided selects, a lane id kept across the main loop, a zero offset of the telemetry
+    # atomics) and lost what the kernel was built for.  (The RoPE form, EPI 5, is built but not the default: 128 spilled.)
+    for epi in (0, 1):
+        u = _find(d, "gemm256q_kernel", f"ILi{epi}E")
+        assert u["VGPRs"] <= 256 and u["VGPRs Spill"] == 0 and u["ScratchSize"] == 0, (epi, u)
 
 
 def test_no_scratch_traffic_inside_the_k_loop_of_the_body_gemms():
