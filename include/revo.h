@@ -258,12 +258,16 @@ int32_t revo_op_set_qstores(int32_t on);
 /* diagnostic: device array [workgroups][items][4] of uint64 the phased kernel fills with 100 MHz time stamps (main loop
  * begin, main loop end, epilogue issued) and the piece's rows, for its first `items` pieces per workgroup; NULL = off */
 int32_t revo_debug_gemm_stamps(void* buf, int32_t items);
+/* diagnostic: device array [workgroups][2] of uint64 the body attention kernel fills with the shader-clock ticks and the 100 MHz
+ * ticks of each workgroup's lifetime (their ratio x 100 MHz = the clock the chip holds under this kernel); NULL = off */
+int32_t revo_debug_attention_clock(void* buf);
 /* 0 = size heuristic (default), 128 or 256 = force that GEMM tile */
 int32_t revo_op_set_gemm_tile(int32_t tile);
 /* bits 4-7 = force the XCD arrangement (N-stripes 1, 2, 4 or 8; 0 = heuristic), bits 8-11 = force the attention
  * waves per workgroup, bit 12 = disable the GEMM tail split, bit 16 = one workgroup per tile instead of the persistent
  * 256 x 256 GEMM, bit 17 = no split-K for the leftover rows of a residual GEMM, bit 18 = 256 x 256 tiles also for
- * problems with fewer than 100 of them, bit 19 = the two-buffer 128 x 64 kernel instead of its six-deep-ring form;
+ * problems with fewer than 100 of them, bit 19 = the two-buffer 128 x 64 kernel instead of its six-deep-ring form,
+ * bit 20 = head_dim-64 attention on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (round 6's MFMA-shape experiment);
  * 0 = normal */
 int32_t revo_op_set_variant(int32_t flags);
 /* 0 = ln_1 / ln_2 as LayerNorm kernels in front of their GEMMs instead of the folded form (A/B timing, parity of one

@@ -88,6 +88,7 @@ EXPERIMENT_SIGNATURES = {
     "revo_op_set_phase_groups": (_i32, [_i32]),
     "revo_op_set_qstores": (_i32, [_i32]),
     "revo_debug_gemm_stamps": (_i32, [_p, _i32]),
+    "revo_debug_attention_clock": (_i32, [_p]),
     "revo_op_set_variant": (_i32, [_i32]),
     "revo_op_set_ln_fold": (_i32, [_i32]),
     "revo_op_set_gemm_debug": (_i32, [_i32]),

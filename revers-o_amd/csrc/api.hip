@@ -1333,6 +1333,7 @@ extern "C" int32_t revo_op_set_variant(int32_t flags) {
     revo::gemm_set_min_tiles256(((flags >> 18) & 1) ? 0 : 100);
     revo::gemm_set_ring(((flags >> 19) & 1) ? 0 : 1, 0);
     revo::gemm_set_rows192(((flags >> 3) & 1) ? 0 : 1);
+    revo::attention_set_shape16((flags >> 20) & 1);
     return 0;
 }
 // 0: every ln_1 / ln_2 runs as its own LayerNorm kernel (A/B timing and parity of the folded form against it); 1: default
@@ -1351,6 +1352,11 @@ extern "C" int32_t revo_op_set_qstores(int32_t on) {
 extern "C" int32_t revo_op_set_phase_groups(int32_t groups) {
     REVO_REQUIRE(groups >= 0 && groups <= 4, "set_phase_groups: 0 (heuristic), 1 (off) or 2..4");
     revo::gemm_set_phase_groups(groups);
+    return 0;
+}
+// diagnostic: device array [workgroups][2] of u64 the body attention kernel fills with (shader-clock ticks, 100 MHz ticks) per workgroup
+extern "C" int32_t revo_debug_attention_clock(void* buf) {
+    revo::attention_set_clock_buffer((unsigned long long*)buf);
     return 0;
 }
 // diagnostic: buf = device array [workgroups][items][4] of u64 (100 MHz stamps: main loop begin, main loop end, epilogue

@@ -104,8 +104,16 @@ __device__ __forceinline__ void att_dma_issue(const AttDmaSrc& src, char* dst, u
 template <int HD, int NW, int DBG = 0, bool STAG = false>
 __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                           bf16_t* __restrict__ out, long ldo, int S, int H, float c,
-                                                          int q_rot, int k_lo) {
+                                                          int q_rot, int k_lo
+#ifdef REVO_EXPERIMENTS
+                                                          , unsigned long long* clk     // diagnostic (attention_set_clock_buffer): [workgroup][2] shader-clock / 100 MHz ticks of its lifetime
+#endif
+                                                          ) {
     static_assert(HD == 64 || HD == 96, "body attention kernel is built for head_dim 64 (B16, L14) and 96 (G14)");
+#ifdef REVO_EXPERIMENTS
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if (clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     constexpr int dbg = DBG;
     constexpr int KS = HD / 16;          // k-steps over d for S^T
     constexpr int DB = HD / 32;          // 32-wide d blocks of O^T
@@ -474,9 +482,24 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
     }
 #undef ATT_ISSUE_TILE
 #undef ATT_WAIT_TILE
+#ifdef REVO_EXPERIMENTS
+    if (clk && threadIdx.x == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* dst = clk + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        dst[0] = t1 - clk_t0;
+        dst[1] = r1 - clk_r0;
+    }
+#endif
 }
 
 
+#ifdef REVO_EXPERIMENTS
+static unsigned long long* g_attn_clk = nullptr;
+void attention_set_clock_buffer(unsigned long long* buf) { g_attn_clk = buf; }
+#define ATT_CLK_ARG , g_attn_clk
+#else
+#define ATT_CLK_ARG
+#endif
 template <int HD, int NW>
 static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, float c, int q_rot,
                            int k_lo, hipStream_t st) {
@@ -485,12 +508,12 @@ static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, in
 #ifdef REVO_EXPERIMENTS
     if constexpr (HD == 64 && NW == 8) {
         if (getenv("REVO_ATTN_STAG")) {            // A/B of the half-tile stagger (scripts/experiments/r5_attn_stagger.sh)
-            hipLaunchKernelGGL((attn_fwd_kernel<HD, NW, 0, true>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo);
+            hipLaunchKernelGGL((attn_fwd_kernel<HD, NW, 0, true>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo ATT_CLK_ARG);
             return;
         }
         if (const char* e = getenv("REVO_ATTN_DBG")) {
             switch (atoi(e)) {
-#define ATT_DBG_CASE(D) case D: hipLaunchKernelGGL((attn_fwd_kernel<HD, NW, D>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo); return;
+#define ATT_DBG_CASE(D) case D: hipLaunchKernelGGL((attn_fwd_kernel<HD, NW, D>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo ATT_CLK_ARG); return;
                 ATT_DBG_CASE(1) ATT_DBG_CASE(2) ATT_DBG_CASE(3) ATT_DBG_CASE(4) ATT_DBG_CASE(7) ATT_DBG_CASE(8) ATT_DBG_CASE(16)
                 ATT_DBG_CASE(24) ATT_DBG_CASE(28) ATT_DBG_CASE(31) ATT_DBG_CASE(32) ATT_DBG_CASE(64) ATT_DBG_CASE(96)
 #undef ATT_DBG_CASE
@@ -499,7 +522,7 @@ static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, in
         }
     }
 #endif
-    hipLaunchKernelGGL((attn_fwd_kernel<HD, NW>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo);
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, NW>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo ATT_CLK_ARG);
 }
 
 static int g_attn_force_nw = 0;   // timing experiments only

@@ -145,6 +145,12 @@ void gemm_set_rows192(int on);      // timing experiments only (1 = default)
 void gemm_set_ln_fold(int on);      // timing experiments only (1 = default): 0 = LayerNorm kernels instead of the folded form, 2 = folded with an fp32 stream
 bool gemm_ln_planes_enabled();
 void attention_force_nw(int nw);   // timing experiments only (0 = heuristic)
+void attention_set_shape16(int on); // head_dim 64: 1 = the v_mfma_f32_16x16x32_bf16 kernel (attn16_fwd_kernel), 0 = the 32x32x16 one
+#ifdef REVO_EXPERIMENTS
+// diagnostic: every workgroup of the body attention kernel writes (shader-clock ticks, 100 MHz ticks) of its lifetime to
+// buf[workgroup][2] (device; null = off): the clock the chip holds under this kernel (MI355X_MICROARCH.md, DVFS item 6)
+void attention_set_clock_buffer(unsigned long long* buf);
+#endif
 
 // ---------------------------------------------------------------- top-k ----
 struct ScanArgs {

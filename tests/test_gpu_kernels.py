@@ -228,6 +228,46 @@ def test_attention_huge_logits(lib, dev, S, hd, scale):
     assert err <= 0.04, err
 
 
+@pytest.mark.parametrize("B,S,H,scale", [(2, 577, 2, 0), (1, 197, 3, 0), (3, 17, 2, 0), (1, 64, 1, 0), (1, 65, 1, 0), (2, 128, 2, 0), (1, 129, 1, 0),
+                                         (1, 1, 1, 0), (1, 1024, 2, 0), (2, 16, 2, 0), (64, 577, 16, 0),
+                                         (2, 577, 2, 8.0), (2, 260, 2, 12.0), (2, 577, 2, 30.0)])
+def test_attention_mfma_16x16x32_kernel(dev, gemm_tile, B, S, H, scale):
+    """attn16_fwd_kernel (round 6's MFMA-shape experiment: head_dim 64 on v_mfma_f32_16x16x32_bf16 -- a query's scores in four
+    lanes, probabilities fed back as the B operand in key-slot order, V rows swizzled for 4 x 16 transposing reads) against an fp64
+    softmax, on every shape the 32x32x16 kernel is tested on (ragged last key tile, one row, class-token prelude, the rotated
+    row order, logits over hundreds of octaves: the reference-moving rare path) and against that kernel itself."""
+    if gemm_tile != 0:
+        pytest.skip("runs once: the switch lives in librevo_exp.so")
+    lib = _lib.load_exp()
+    hd = 64
+    W = H * hd
+    g = torch.Generator(device="cpu").manual_seed(S * 31 + H)
+    qkv = torch.randn(B * S, 3 * W, generator=g)
+    if scale:
+        qkv[:, : 2 * W] *= scale
+        qkv[:, W:W + hd] += torch.linspace(0, scale, B * S)[:, None] * torch.sign(qkv[0, :hd])[None]
+    qkv = qkv.to(dev).bfloat16()
+    outs = {}
+    try:
+        for flag in (0, 1 << 20):
+            _lib.check(lib.revo_op_set_variant(flag))
+            out = torch.full((B * S, W), float("nan"), device=dev, dtype=torch.bfloat16)
+            _lib.check(lib.revo_op_attention(_lib.ptr(qkv), 3 * W, _lib.ptr(out), W, B, S, H, hd, _lib.current_stream()))
+            torch.cuda.synchronize()
+            outs[flag] = out
+    finally:
+        _lib.check(lib.revo_op_set_variant(0))
+    nb = min(B, 3)
+    x = qkv[: nb * S].double().reshape(nb, S, 3, H, hd)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1) @ v).transpose(1, 2).reshape(nb * S, W)
+    new, old = outs[1 << 20], outs[0]
+    assert torch.isfinite(new.float()).all()
+    tol = 0.04 if scale else 0.03
+    assert (new[: nb * S].double() - ref).abs().max().item() <= tol
+    assert (new.float() - old.float()).abs().max().item() <= tol           # the whole batch against the shipped kernel
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 1024, 1024), (64, 4096, 1024), (64, 1024, 4096), (1, 256, 256), (7, 260, 512),
                                    (33, 1000, 768), (64, 1024, 1280)])
 def test_gemm_skinny_all_epilogues(lib, dev, gemm_tile, M, N, K):
