@@ -493,6 +493,334 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
 }
 
 
+
+// ---- The same body attention on v_mfma_f32_16x16x32_bf16 (head_dim 64; round 6, the MFMA-shape experiment the CDNA guide
+// asks for: "the chip can hold a higher clock on one shape than on the other -- build both at the same output tile per wave,
+// keep the faster by wall").  Same workgroup, same K/V ring and DMA, same 32 query rows and 64-key tiles per wave, same
+// optimistic softmax; what changes is who holds what:
+//   S^T block = 16 keys x 16 queries: lane (li = lane & 15, lq = lane >> 4) holds query li of query block nb (two per wave)
+//     and keys 16 mb + 4 lq + i, i = 0..3, of key block mb (four per tile): a query's 64 scores of a tile sit in FOUR lanes
+//     (lq = 0..3), 16 each.  Row sums stay per-lane partials (added over the four lanes once, at the end); the reference m
+//     is per query block.
+//   P^T as the B operand of O^T = V^T . P^T needs, per lane, 8 key slots k = 8 lq + j of a 32-key step: slot j of step kk :=
+//     key 16 (2 kk + (j >> 2)) + 4 lq + (j & 3) -- exactly the keys this lane's accumulators of blocks 2 kk and 2 kk + 1 hold:
+//     the packed probabilities go straight back in, no shuffle.  V^T fragments follow the same slot order: two
+//     ds_read_b64_tr_b16 per (step, 16-wide d block), each transposing 4 keys x 16 d.
+//   V rows are swizzled for that read (chunk ^= ((key >> 1) & 3) << 1: the eight rows a 32-lane LDS cycle touches fall into
+//     four different 32-byte windows per row parity); K rows keep (key >> 1) & 7 (conflict-free for this read order too).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW >= 6 ? 4 : 1) void attn16_fwd_kernel(const bf16_t* __restrict__ qkv, long ld,
+                                                          bf16_t* __restrict__ out, long ldo, int S, int H, float c,
+                                                          int q_rot, int k_lo
+#ifdef REVO_EXPERIMENTS
+                                                          , unsigned long long* clk
+#endif
+                                                          ) {
+#ifdef REVO_EXPERIMENTS
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if (clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    constexpr int HD = 64, ROWB = 128, TILE = 64 * ROWB, BUF = 2 * TILE, LOOK = 2, NBUF = LOOK + 1;
+    constexpr int NI = BUF / 1024, NPW = (NI + NW - 1) / NW, NDUMMY = NPW * NW - NI, LPR = ROWB / 16, RPI = 64 / LPR;
+    __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF + NDUMMY * 1024];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 15, lq = lane >> 4;
+    int bh, qblk;
+    {
+        const int nq = gridDim.x, nbh = gridDim.y, L = blockIdx.y * nq + blockIdx.x;
+        const int full = (nbh / 8) * 8;
+        if (L < full * nq) {
+            const int xcd = L & 7, slot = L >> 3;
+            bh = (slot / nq) * 8 + xcd;
+            qblk = slot % nq;
+        } else {
+            const int rr = L - full * nq;
+            bh = full + rr / nq;
+            qblk = rr % nq;
+        }
+    }
+    const int b = bh / H, h = bh - b * H;
+    const int W = H * HD;
+    const long rowbase = (long)b * S;
+    const int q0 = qblk * (NW * 32) + wave * 32;
+    const bool wave_active = q0 < S;
+    const bf16_t* kg = qkv + W + h * HD;
+    const bf16_t* vg = qkv + 2 * W + h * HD;
+
+    bf16x8 qf[2][2];                          // [query block][k-step over d]: query 16 nb + li, d = 32 ks + 8 lq + j
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int qp = q0 + nb * 16 + li < S ? q0 + nb * 16 + li : S - 1;
+        const int qrow = q_rot ? (qp + 1 < S ? qp + 1 : 0) : qp;
+        const bf16_t* qptr = qkv + (rowbase + qrow) * ld + h * HD + 8 * lq;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[nb][ks] = *(const bf16x8*)(qptr + 32 * ks);
+    }
+
+    const int nkeys = S - k_lo;
+    const int nt = (nkeys + 63) / 64;
+    AttDmaSrc dma_src;
+    att_dma_init(dma_src, kg + (rowbase + k_lo) * ld, (int)(((long)(nkeys - 1) * ld + W + HD) * 2));
+    uint32_t dma_voff[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int j = wave + NW * i;
+        const int row = j * RPI + lane / LPR;
+        const int cp = lane % LPR;
+        const int isv = row >= 64, key = row & 63;
+        const int swz = isv ? (((key >> 1) & 3) << 1) : ((key >> 1) & 7);
+        const int ch = cp ^ swz;
+        dma_voff[i] = (j < NI) ? (uint32_t)(((long)key * ld + (isv ? W : 0)) * 2 + ch * 16) : 0x80000000u;
+    }
+    const uint32_t tile_bytes = (uint32_t)(64 * ld * 2);
+#define ATT_ISSUE_TILE(slot, t)                                                                 \
+    do {                                                                                        \
+        char* dst_ = lds + (slot) * BUF + wave * 1024;                                          \
+        _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                       \
+            char* d_ = (NDUMMY == 0 || wave + NW * i < NI) ? dst_ + i * NW * 1024               \
+                                                           : lds + NBUF * BUF + (wave + NW * i - NI) * 1024; \
+            att_dma_issue(dma_src, d_, dma_voff[i], (uint32_t)(t) * tile_bytes);                \
+        }                                                                                       \
+    } while (0)
+#define ATT_WAIT_TILE(u)                                                                                  \
+    do {                                                                                                  \
+        const int inflight_ = ((u) + LOOK - 1 < nt ? LOOK - 1 : nt - 1 - (u));                             \
+        if (inflight_ >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");                    \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+    } while (0)
+
+    uint32_t kaddr[2], vaddr[4];
+    {
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds;
+        const int sw = (li >> 1) & 7;                         // the same for keys li, li + 16, ...
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kaddr[ks] = lds0 + li * ROWB + (((4 * ks + lq) ^ sw) << 4);
+        const int tq = li >> 2, tp = li & 3;
+        const int sv = ((2 * lq + (tq >> 1)) & 3) << 1;       // swizzle of keys 4 lq + tq (+ multiples of 16)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            vaddr[d] = lds0 + TILE + (4 * lq + tq) * ROWB + (((2 * d + (tp >> 1)) ^ sv) << 4) + (tp & 1) * 8;
+    }
+
+    f32x4 oacc[4][2];                         // [d block][query block]: d = 16 db + 4 lq + i
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) oacc[d][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < LOOK; ++u)
+        if (u < nt) ATT_ISSUE_TILE(u, u);
+
+    if (k_lo == 1 && wave_active) {
+        // rank-1 prelude with key row 0: this lane holds q[d] for d = 32 ks + 8 lq + j; a query's dot product is spread over its four lanes
+        const bf16_t* k0p = kg + rowbase * ld + 8 * lq;
+        float sdot[2] = {0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const s16x8 kk = *(const s16x8*)(k0p + 32 * ks);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const s16x8 qq = __builtin_bit_cast(s16x8, qf[nb][ks]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sdot[nb] = fmaf(bf16_to_f32((bf16_t)qq[j]), bf16_to_f32((bf16_t)kk[j]), sdot[nb]);
+            }
+        }
+        const bf16_t* v0p = vg + rowbase * ld;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            sdot[nb] += __shfl_xor(sdot[nb], 16, 64);
+            sdot[nb] += __shfl_xor(sdot[nb], 32, 64);
+            m_run[nb] = sdot[nb] * c;
+            l_run[nb] = lq == 0 ? 1.0f : 0.0f;               // the four lanes' partial sums are added at the end
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const s16x4 vv = *(const s16x4*)(v0p + d * 16 + 4 * lq);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) oacc[d][nb][j] = bf16_to_f32((bf16_t)vv[j]);
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(qf[nb][ks]));
+
+    uint32_t pw[4][2][2];                     // [key block][query block][pair]: packed probabilities
+    uint64_t vt0[4][2], vt1[4][2];            // V^T fragments of one 32-key step: [d block][first / second 16 keys]
+    auto v_issue = [&](auto off_c, uint64_t (&v)[4][2]) __attribute__((always_inline)) {
+        constexpr int OFF = decltype(off_c)::value;       // ring slot + 32-key step (bytes)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            v[d][0] = att_tr_read<OFF>(vaddr[d]);
+            v[d][1] = att_tr_read<OFF + 16 * ROWB>(vaddr[d]);
+        }
+    };
+    auto v_wait = [&](uint64_t (&v)[4][2]) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[3][0]), "+v"(v[3][1]));
+    };
+    auto pv_step = [&](auto kk_c, uint64_t (&v)[4][2]) __attribute__((always_inline)) {
+        constexpr int KK = decltype(kk_c)::value;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            uint4 pk;
+            pk.x = pw[2 * KK][nb][0];
+            pk.y = pw[2 * KK][nb][1];
+            pk.z = pw[2 * KK + 1][nb][0];
+            pk.w = pw[2 * KK + 1][nb][1];
+            const bf16x8 pb = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                oacc[d][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_v_frag(v[d][0], v[d][1]), pb, oacc[d][nb], 0, 0, 0);
+        }
+    };
+    auto tile_step = [&](auto slot_c, const int t) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int SB = SLOT * BUF;
+        ATT_WAIT_TILE(t);
+        __builtin_amdgcn_s_barrier();
+        if (t + LOOK < nt) ATT_ISSUE_TILE((SLOT + LOOK) % NBUF, t + LOOK);
+        if (!wave_active) return;
+        f32x4 sacc[4][2];
+        att_u32x4 kf[4];
+        auto scores = [&]() __attribute__((always_inline)) {
+            // fragment i: key block i / 2, k-step i % 2; each feeds two MFMAs (the two query blocks)
+#define ATT_KOFF(i) (SB + ((i) / 2) * 16 * ROWB)
+            kf[0] = att_read_b128<ATT_KOFF(0)>(kaddr[0]);
+            kf[1] = att_read_b128<ATT_KOFF(1)>(kaddr[1]);
+            kf[2] = att_read_b128<ATT_KOFF(2)>(kaddr[0]);
+            kf[3] = att_read_b128<ATT_KOFF(3)>(kaddr[1]);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) sacc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define ATT_KSTEP(i)                                                                                              \
+    {                                                                                                             \
+        if constexpr ((i) + 4 <= 8) att_k_wait<3>(kf[(i) % 4]);                                                   \
+        else att_k_wait<8 - 1 - (i)>(kf[(i) % 4]);                                                                \
+        _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                                          \
+            sacc[(i) / 2][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[(i) % 4]), qf[nb][(i) % 2], \
+                                                                        sacc[(i) / 2][nb], 0, 0, 0);               \
+        if constexpr ((i) + 4 < 8) kf[(i) % 4] = att_read_b128<ATT_KOFF((i) + 4)>(kaddr[(i) % 2]);                \
+    }
+            ATT_KSTEP(0) ATT_KSTEP(1) ATT_KSTEP(2) ATT_KSTEP(3) ATT_KSTEP(4) ATT_KSTEP(5) ATT_KSTEP(6) ATT_KSTEP(7)
+#undef ATT_KSTEP
+#undef ATT_KOFF
+            if (t == nt - 1 && (nkeys & 63)) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int key_ = t * 64 + mb * 16 + 4 * lq + i;
+                        if (key_ >= nkeys) { sacc[mb][0][i] = -INFINITY; sacc[mb][1][i] = -INFINITY; }
+                    }
+            }
+        };
+        scores();
+        v_issue(std::integral_constant<int, SB>{}, vt0);            // keys 0..31 of the tile, ahead of the exponentials
+        f32x2 ps2[2];
+        auto exps = [&]() __attribute__((always_inline)) {
+            const f32x2 c2_ = {c, c};
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const f32x2 m2_ = {m_run[nb], m_run[nb]};
+                ps2[nb] = (f32x2){0.f, 0.f};
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x2 sv_ = {sacc[mb][nb][2 * j], sacc[mb][nb][2 * j + 1]};
+                        const f32x2 e_ = sv_ * c2_ - m2_;
+                        const f32x2 pv_ = {__builtin_amdgcn_exp2f(e_.x), __builtin_amdgcn_exp2f(e_.y)};
+                        ps2[nb] += pv_;
+                        pw[mb][nb][j] = pack_bf16x2(pv_.x, pv_.y);
+                    }
+            }
+        };
+        exps();
+        float ps[2] = {ps2[0].x + ps2[0].y, ps2[1].x + ps2[1].y};
+        if (!__all(ps[0] < 0x1p80f && ps[1] < 0x1p80f)) {
+            asm volatile("" ::: "memory");
+            scores();           // rare path: the scores were consumed in place, compute them again
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sacc[mb][nb][i]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+                const float m_new = fmaxf(m_run[nb], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_new);      // 0 when m_run was -inf
+                m_run[nb] = m_new;
+                l_run[nb] *= alpha;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) oacc[d][nb] *= alpha;
+            }
+            exps();
+            ps[0] = ps2[0].x + ps2[0].y;
+            ps[1] = ps2[1].x + ps2[1].y;
+        }
+        l_run[0] += ps[0];
+        l_run[1] += ps[1];
+        v_wait(vt0);
+        v_issue(std::integral_constant<int, SB + 32 * ROWB>{}, vt1);
+        pv_step(std::integral_constant<int, 0>{}, vt0);
+        v_wait(vt1);
+        pv_step(std::integral_constant<int, 1>{}, vt1);
+    };
+    for (int t = 0; t < nt; t += NBUF) {
+        tile_step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nt) tile_step(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < nt) tile_step(std::integral_constant<int, 2>{}, t + 2);
+    }
+
+    __builtin_amdgcn_s_barrier();                // every wave is out of the ring
+    if (wave_active) {
+        constexpr int RS = 144;
+        char* slab = lds + wave * (32 * RS);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            float l_tot = l_run[nb] + __shfl_xor(l_run[nb], 16, 64);
+            l_tot += __shfl_xor(l_tot, 32, 64);
+            const float inv = 1.0f / l_tot;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint2 o;
+                o.x = pack_bf16x2(oacc[d][nb][0] * inv, oacc[d][nb][1] * inv);
+                o.y = pack_bf16x2(oacc[d][nb][2] * inv, oacc[d][nb][3] * inv);
+                *(uint2*)(slab + (nb * 16 + li) * RS + (d * 16 + 4 * lq) * 2) = o;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rl = it * 8 + (lane >> 3);
+            const uint4 v = *(const uint4*)(slab + rl * RS + (lane & 7) * 16);
+            const int qp = q0 + rl;
+            if (qp < S) {
+                const int qr = q_rot ? (qp + 1 < S ? qp + 1 : 0) : qp;
+                *(uint4*)(out + (rowbase + qr) * ldo + h * HD + (lane & 7) * 8) = v;
+            }
+        }
+    }
+#undef ATT_ISSUE_TILE
+#undef ATT_WAIT_TILE
+#ifdef REVO_EXPERIMENTS
+    if (clk && threadIdx.x == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* dst = clk + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        dst[0] = t1 - clk_t0;
+        dst[1] = r1 - clk_r0;
+    }
+#endif
+}
+
 #ifdef REVO_EXPERIMENTS
 static unsigned long long* g_attn_clk = nullptr;
 void attention_set_clock_buffer(unsigned long long* buf) { g_attn_clk = buf; }
@@ -500,6 +828,8 @@ void attention_set_clock_buffer(unsigned long long* buf) { g_attn_clk = buf; }
 #else
 #define ATT_CLK_ARG
 #endif
+static int g_attn_shape16 = 0;     // 1 = head_dim 64 on attn16_fwd_kernel (v_mfma_f32_16x16x32_bf16)
+void attention_set_shape16(int on) { g_attn_shape16 = on; }
 template <int HD, int NW>
 static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, int B, int S, int H, float c, int q_rot,
                            int k_lo, hipStream_t st) {
@@ -522,6 +852,12 @@ static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, in
         }
     }
 #endif
+    if constexpr (HD == 64) {
+        if (g_attn_shape16) {
+            hipLaunchKernelGGL((attn16_fwd_kernel<NW>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo ATT_CLK_ARG);
+            return;
+        }
+    }
     hipLaunchKernelGGL((attn_fwd_kernel<HD, NW>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo ATT_CLK_ARG);
 }
 
