@@ -508,7 +508,7 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
 //     ds_read_b64_tr_b16 per (step, 16-wide d block), each transposing 4 keys x 16 d.
 //   V rows are swizzled for that read (chunk ^= ((key >> 1) & 3) << 1: the eight rows a 32-lane LDS cycle touches fall into
 //     four different 32-byte windows per row parity); K rows keep (key >> 1) & 7 (conflict-free for this read order too).
-template <int NW>
+template <int NW, int DBG = 0>
 __global__ __launch_bounds__(NW * 64, NW >= 6 ? 4 : 1) void attn16_fwd_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                           bf16_t* __restrict__ out, long ldo, int S, int H, float c,
                                                           int q_rot, int k_lo
@@ -675,7 +675,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 6 ? 4 : 1) void attn16_fwd_kernel(co
             const bf16x8 pb = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
             for (int d = 0; d < 4; ++d)
-                oacc[d][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_v_frag(v[d][0], v[d][1]), pb, oacc[d][nb], 0, 0, 0);
+                oacc[d][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((DBG & 2) ? att_v_frag(0x3f803f803f803f80ull, 0x3f803f803f803f80ull) : att_v_frag(v[d][0], v[d][1]),
+                                                                      pb, oacc[d][nb], 0, 0, 0);
         }
     };
     auto tile_step = [&](auto slot_c, const int t) __attribute__((always_inline)) {
@@ -705,6 +706,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 6 ? 4 : 1) void attn16_fwd_kernel(co
         _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                                          \
             sacc[(i) / 2][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[(i) % 4]), qf[nb][(i) % 2], \
                                                                         sacc[(i) / 2][nb], 0, 0, 0);               \
+        asm volatile("" :: "v"(kf[(i) % 4]));      /* the fragment outlives both MFMAs: neither may take its registers as destination */ \
         if constexpr ((i) + 4 < 8) kf[(i) % 4] = att_read_b128<ATT_KOFF((i) + 4)>(kaddr[(i) % 2]);                \
     }
             ATT_KSTEP(0) ATT_KSTEP(1) ATT_KSTEP(2) ATT_KSTEP(3) ATT_KSTEP(4) ATT_KSTEP(5) ATT_KSTEP(6) ATT_KSTEP(7)
@@ -738,7 +740,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 6 ? 4 : 1) void attn16_fwd_kernel(co
                         const f32x2 e_ = sv_ * c2_ - m2_;
                         const f32x2 pv_ = {__builtin_amdgcn_exp2f(e_.x), __builtin_amdgcn_exp2f(e_.y)};
                         ps2[nb] += pv_;
-                        pw[mb][nb][j] = pack_bf16x2(pv_.x, pv_.y);
+                        pw[mb][nb][j] = (DBG & 1) ? 0x3f803f80u : pack_bf16x2(pv_.x, pv_.y);
                     }
             }
         };
@@ -854,6 +856,18 @@ static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, in
 #endif
     if constexpr (HD == 64) {
         if (g_attn_shape16) {
+#ifdef REVO_EXPERIMENTS
+            if constexpr (NW == 8) {
+                if (const char* e = getenv("REVO_ATTN16_DBG")) {
+                    switch (atoi(e)) {
+                        case 1: hipLaunchKernelGGL((attn16_fwd_kernel<NW, 1>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo ATT_CLK_ARG); return;
+                        case 2: hipLaunchKernelGGL((attn16_fwd_kernel<NW, 2>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo ATT_CLK_ARG); return;
+                        case 3: hipLaunchKernelGGL((attn16_fwd_kernel<NW, 3>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo ATT_CLK_ARG); return;
+                        default: break;
+                    }
+                }
+            }
+#endif
             hipLaunchKernelGGL((attn16_fwd_kernel<NW>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo ATT_CLK_ARG);
             return;
         }

@@ -1019,12 +1019,12 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256q_kernel(GemmArgs p, i
             for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #ifdef REVO_EXPERIMENTS
         // diagnostic stamps (scripts/gemm_qstamps.py): 100 MHz clock at main loop begin / end, epilogue arithmetic done, stores issued
-        unsigned long long t_a = 0, t_b = 0, t_c = 0;
-        if (p.stamps) t_a = __builtin_amdgcn_s_memrealtime();
+        unsigned long long t_a = 0, t_b = 0, t_c = 0, c_a = 0;
+        if (p.stamps) { t_a = __builtin_amdgcn_s_memrealtime(); c_a = __builtin_amdgcn_s_memtime(); }
 #endif
         gemm256_mainloop<0, false, false, G256Q_STORES>(A, B, smem, p.K, wave, lane, acc);
 #ifdef REVO_EXPERIMENTS
-        if (p.stamps) t_b = __builtin_amdgcn_s_memrealtime();
+        if (p.stamps) { t_b = __builtin_amdgcn_s_memrealtime(); c_a = __builtin_amdgcn_s_memtime() - c_a; }      // shader-clock cycles of the main loop
 #endif
 
         // ------------------------------------------------------------------ epilogue, in registers
@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256q_kernel(GemmArgs p, i
 #ifdef REVO_EXPERIMENTS
         if (q.stamps && wave == 0 && lane_e == 0 && tiles_done < q.stamp_items) {
             unsigned long long* dst = q.stamps + ((size_t)blockIdx.x * q.stamp_items + tiles_done) * 4;
-            dst[0] = t_a; dst[1] = t_b; dst[2] = t_c; dst[3] = __builtin_amdgcn_s_memrealtime();
+            dst[0] = t_a; dst[1] = t_b; dst[2] = (q.stagger_groups & 0x200) ? c_a : t_c; dst[3] = __builtin_amdgcn_s_memrealtime();
         }
         ++tiles_done;
 #endif
@@ -1506,7 +1506,7 @@ static bool use_256q(const GemmArgs& a) {
     // waited for behind the next tile's DMA requests, and hipcc's wait counts leave LDS-DMA out -- every such wait is a
     // wait for the DMA too; and with its short arithmetic the form gains nothing from stores issued early (the plain
     // bf16 form: +-0).  qkv stays on gemm256p_kernel unless the switch says 3.
-    if (EPI == EPI_BF16_ROPE && g_qstores != 3) return false;
+    if (EPI == EPI_BF16_ROPE && (g_qstores & 7) != 3) return false;
     return true;
 }
 template <int EPI>
@@ -1515,7 +1515,9 @@ static int launch_256q(const GemmArgs& a, hipStream_t st) {
         GemmArgs b = a;
 #ifdef REVO_EXPERIMENTS
         b.stamps = g_stamps; b.stamp_items = g_stamp_items;
-        b.stagger_cycles = 0; b.stagger_groups = g_qstores == 2 ? 0x100 : 0;       // 2: the stores are issued but dropped (timing only)
+        b.stagger_cycles = 0;
+        b.stagger_groups = ((g_qstores & 7) == 2 ? 0x100 : 0)        // 2: the stores are issued but dropped (timing only)
+                           | ((g_qstores & 8) ? 0x200 : 0);          // + 8: stamp item 2 = shader-clock cycles of the main loop (its clock)
 #endif
         const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
         int gy = tiles_n >= 12 ? 4 : (tiles_n >= 8 ? 2 : 1);

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, reverso_amd
 from reverso_amd import _lib
 lib=_lib.load(); dev=torch.device("cuda",0)
-for (B,S,H) in [(64,577,16),(8,577,16),(64,577,2),(32,1024,16)]:
+for (B,S,H) in [(64,577,16)]:
     hd=64; W=H*hd
     g=torch.Generator(device="cpu").manual_seed(S*31+H)
     qkv=torch.randn(B*S,3*W,generator=g).to(dev).bfloat16()
@@ -22,5 +22,5 @@ for (B,S,H) in [(64,577,16),(8,577,16),(64,577,2),(32,1024,16)]:
         idx=(d>0.02).nonzero()
         bad.append([tuple(x) for x in idx.tolist()][:6])
     same=[bool(torch.equal(outs[0],o)) for o in outs[1:]]
-    print((B,S,H), "repeat-identical:", same, "bad (img,tok,head) per run:", bad, flush=True)
+    print(os.environ.get("REVO_ATTN16_DBG"), (B,S,H), "repeat-identical:", same, "n differing elems vs run0:", [int((o!=outs[0]).sum()) for o in outs[1:]], flush=True)
 lib.revo_op_set_variant(0)
