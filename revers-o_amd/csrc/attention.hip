@@ -508,6 +508,19 @@ __global__ __launch_bounds__(NW * 64, (HD == 64 && NW >= 6) ? 4 : 1) void attn_f
 //     ds_read_b64_tr_b16 per (step, 16-wide d block), each transposing 4 keys x 16 d.
 //   V rows are swizzled for that read (chunk ^= ((key >> 1) & 3) << 1: the eight rows a 32-lane LDS cycle touches fall into
 //     four different 32-byte windows per row parity); K rows keep (key >> 1) & 7 (conflict-free for this read order too).
+// acc += A . B with the accumulator IN PLACE (vDst == SrcC), as inline asm.  Through the builtin hipcc 7.2 picks registers for
+// v_mfma_f32_16x16x32_bf16 that the hardware does not honour under load: (a) with a literal 0 as SrcC it gave the first MFMA
+// of a chain the registers of its own A operand as destination (v_mfma v[50:53], v[50:53], v[10:13], 0 -- the 16x16 forms
+// carry no early-clobber in LLVM), (b) it continued a chain into a DIFFERENT destination (v_mfma v[94:97], .., v[66:69]) with
+// one s_nop between producer and consumer.  Either way a few rows per launch came out different from run to run (up to 1 M
+// of 38 M output elements with constant P and V; profiles/r06_attention_mfma_shape.json).  In place, back to back, is the
+// form the body GEMM runs billions of times.  The asm hides the MFMA from the hazard recogniser: att16_mfma_settle() puts
+// the wait states between the last MFMA and the first vector instruction that reads an accumulator.
+__device__ __forceinline__ void att16_mfma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void att16_mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
 template <int NW, int DBG = 0>
 __global__ __launch_bounds__(NW * 64, NW >= 6 ? 4 : 1) void attn16_fwd_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                           bf16_t* __restrict__ out, long ldo, int S, int H, float c,
@@ -675,8 +688,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 6 ? 4 : 1) void attn16_fwd_kernel(co
             const bf16x8 pb = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
             for (int d = 0; d < 4; ++d)
-                oacc[d][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((DBG & 2) ? att_v_frag(0x3f803f803f803f80ull, 0x3f803f803f803f80ull) : att_v_frag(v[d][0], v[d][1]),
-                                                                      pb, oacc[d][nb], 0, 0, 0);
+                att16_mfma(oacc[d][nb], (DBG & 2) ? att_v_frag(0x3f803f803f803f80ull, 0x3f803f803f803f80ull) : att_v_frag(v[d][0], v[d][1]), pb);
         }
     };
     auto tile_step = [&](auto slot_c, const int t) __attribute__((always_inline)) {
@@ -704,14 +716,13 @@ __global__ __launch_bounds__(NW * 64, NW >= 6 ? 4 : 1) void attn16_fwd_kernel(co
         if constexpr ((i) + 4 <= 8) att_k_wait<3>(kf[(i) % 4]);                                                   \
         else att_k_wait<8 - 1 - (i)>(kf[(i) % 4]);                                                                \
         _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                                          \
-            sacc[(i) / 2][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[(i) % 4]), qf[nb][(i) % 2], \
-                                                                        sacc[(i) / 2][nb], 0, 0, 0);               \
-        asm volatile("" :: "v"(kf[(i) % 4]));      /* the fragment outlives both MFMAs: neither may take its registers as destination */ \
+            att16_mfma(sacc[(i) / 2][nb], __builtin_bit_cast(bf16x8, kf[(i) % 4]), qf[nb][(i) % 2]);               \
         if constexpr ((i) + 4 < 8) kf[(i) % 4] = att_read_b128<ATT_KOFF((i) + 4)>(kaddr[(i) % 2]);                \
     }
             ATT_KSTEP(0) ATT_KSTEP(1) ATT_KSTEP(2) ATT_KSTEP(3) ATT_KSTEP(4) ATT_KSTEP(5) ATT_KSTEP(6) ATT_KSTEP(7)
 #undef ATT_KSTEP
 #undef ATT_KOFF
+            att16_mfma_settle();
             if (t == nt - 1 && (nkeys & 63)) {
                 asm volatile("" ::: "memory");
 #pragma unroll
@@ -763,7 +774,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 6 ? 4 : 1) void attn16_fwd_kernel(co
                 m_run[nb] = m_new;
                 l_run[nb] *= alpha;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) oacc[d][nb] *= alpha;
+                for (int d = 0; d < 4; ++d) oacc[d][nb] *= alpha;       // (the previous tile's P.V MFMAs settled long ago: a whole scores() lies in between)
             }
             exps();
             ps[0] = ps2[0].x + ps2[0].y;
@@ -783,6 +794,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 6 ? 4 : 1) void attn16_fwd_kernel(co
         if (t + 2 < nt) tile_step(std::integral_constant<int, 2>{}, t + 2);
     }
 
+    att16_mfma_settle();
     __builtin_amdgcn_s_barrier();                // every wave is out of the ring
     if (wave_active) {
         constexpr int RS = 144;
