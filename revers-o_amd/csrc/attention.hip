@@ -685,7 +685,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 6 ? 4 : 1) void attn16_fwd_kernel(co
             pk.y = pw[2 * KK][nb][1];
             pk.z = pw[2 * KK + 1][nb][0];
             pk.w = pw[2 * KK + 1][nb][1];
-            const bf16x8 pb = __builtin_bit_cast(bf16x8, pk);
+            bf16x8 pb = __builtin_bit_cast(bf16x8, pk);
+            asm volatile("s_nop 1" : "+v"(pb));      // (the packs that produce pb are vector-unit writes: see scores())
 #pragma unroll
             for (int d = 0; d < 4; ++d)
                 att16_mfma(oacc[d][nb], (DBG & 2) ? att_v_frag(0x3f803f803f803f80ull, 0x3f803f803f803f80ull) : att_v_frag(v[d][0], v[d][1]), pb);
@@ -711,6 +712,10 @@ __global__ __launch_bounds__(NW * 64, NW >= 6 ? 4 : 1) void attn16_fwd_kernel(co
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) sacc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // (the zeros are vector-unit writes and the asm MFMAs that read them are invisible to the hazard recogniser: two
+            //  wait states in between, once per tile)
+            asm volatile("s_nop 1" : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[1][0]), "+v"(sacc[1][1]), "+v"(sacc[2][0]),
+                                     "+v"(sacc[2][1]), "+v"(sacc[3][0]), "+v"(sacc[3][1]));
 #define ATT_KSTEP(i)                                                                                              \
     {                                                                                                             \
         if constexpr ((i) + 4 <= 8) att_k_wait<3>(kf[(i) % 4]);                                                   \
