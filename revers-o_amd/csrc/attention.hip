@@ -871,9 +871,9 @@ static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, in
         }
     }
 #endif
+#ifdef REVO_EXPERIMENTS           // (the 16x16x32 kernel is an experiment: measured and not adopted, profiles/r06_attention_mfma_shape.json)
     if constexpr (HD == 64) {
         if (g_attn_shape16) {
-#ifdef REVO_EXPERIMENTS
             if constexpr (NW == 8) {
                 if (const char* e = getenv("REVO_ATTN16_DBG")) {
                     switch (atoi(e)) {
@@ -884,11 +884,11 @@ static void launch_attn_nw(const bf16_t* qkv, long ld, bf16_t* out, long ldo, in
                     }
                 }
             }
-#endif
             hipLaunchKernelGGL((attn16_fwd_kernel<NW>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo ATT_CLK_ARG);
             return;
         }
     }
+#endif
     hipLaunchKernelGGL((attn_fwd_kernel<HD, NW>), grid, block, 0, st, qkv, ld, out, ldo, S, H, c, q_rot, k_lo ATT_CLK_ARG);
 }
 
