@@ -69,8 +69,9 @@ int32_t revo_vit_seq_len(const revo_vit* vit);
 /* Run-time telemetry of the LayerNorm folded into the GEMMs around it (batch-sized forwards: ln_1 / ln_2 are not kernels;
  * qkv / fc1 read A = bf16(x) UN-CENTRED and apply rstd * (acc - mean * csum) + b' in their epilogues).  The form is the same
  * function as LayerNorm-then-GEMM, but its rounding error grows with |mean| / std of a row (bf16(x) spends its 8 bits on
- * the common offset): 1.0 x the LayerNorm kernel's error at offset 0, 1.0 x at 2 sigma, ~1.4 x at 8 sigma, ~4 x at 32
- * sigma (tests/test_gpu_ln_fold.py::test_fold_error_against_the_row_offset records the curve and holds it to a bound).  The
+ * the common offset): measured rms error against the fp64 LayerNorm + linear, relative to LayerNorm kernel -> bf16 -> GEMM:
+ * 1.00 x at offset 0, 1.5 x at 2 sigma, 4.9 x at 8.5 sigma, 18.7 x at 33 sigma -- about 0.57 x the offset in sigmas
+ * (tests/test_gpu_ln_fold.py::test_fold_error_against_the_row_offset records the curve and holds it to a bound).  The
  * reference normalises in the activations' precision before the matmul (oracle/pe_vit.py:146-155 <- core_system.py:341), so on
  * a trained checkpoint this is the number to look at first if embeddings drift: out4 = { rows the consuming GEMMs merged
  * statistics for since the last reset (each row of each folded LayerNorm of each forward, counted once; rows that the

@@ -1409,6 +1409,11 @@ static const char* check_args(const GemmArgs& a) {
     return nullptr;
 }
 
+// XCD arrangement of the 256 x 256 kernels: N stripes per 8 XCDs (the other factor of 8 = M stripes).  Re-measured in round 6 with
+// the current kernels, alternated per layer shape (scripts/gemm_gy_sweep.py, profiles/r06_gemm_gy_sweep.json): up to 7 column
+// tiles every XCD sweeps all of N for its M stripe; from 8 on two N stripes (L14 qkv, 12 tiles: -2.9 % against the four
+// stripes round 4 chose; fc1, 16: -1.8 %; G14 qkv, 18: -3.4 %); four only from 24 on (G14 fc1, 35 tiles: -1.7 %).
+static int xcd_stripes(int tiles_n) { return tiles_n >= 24 ? 4 : (tiles_n >= 8 ? 2 : 1); }
 static int g_force_gy = 0;     // timing experiments only: force the XCD arrangement (1, 2, 4, 8)
 void gemm_force_gy(int gy) { g_force_gy = gy; }
 template <int EPI, int DBG>
@@ -1419,7 +1424,7 @@ static int launch_256d(const GemmArgs& a, hipStream_t st) {
     // L2 resident and cut the fabric traffic (qkv 933 -> 1122, fc1 859 -> 920, 8192^3 1322 -> 1453 TF)
     GemmArgs b = a;
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
-    int gy = tiles_n >= 12 ? 4 : (tiles_n >= 8 ? 2 : 1);
+    int gy = xcd_stripes(tiles_n);
     if (g_force_gy) gy = g_force_gy;
     b.gy = gy;
     const int gx = 8 / gy;
@@ -1450,7 +1455,7 @@ static int launch_256p(const GemmArgs& a, hipStream_t st) {
     b.stamps = g_stamps; b.stamp_items = g_stamp_items;
 #endif
     const int tiles_m = BMR == 256 ? (a.M + 255) / 256 : a.t192_tiles, tiles_n = (a.N + 255) / 256;
-    int gy = tiles_n >= 12 ? 4 : (tiles_n >= 8 ? 2 : 1);
+    int gy = xcd_stripes(tiles_n);
     if (g_force_gy) gy = g_force_gy;
     b.gy = gy;
     const int gx = 8 / gy;
@@ -1520,7 +1525,7 @@ static int launch_256q(const GemmArgs& a, hipStream_t st) {
                            | ((g_qstores & 8) ? 0x200 : 0);          // + 8: stamp item 2 = shader-clock cycles of the main loop (its clock)
 #endif
         const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
-        int gy = tiles_n >= 12 ? 4 : (tiles_n >= 8 ? 2 : 1);
+        int gy = xcd_stripes(tiles_n);
         if (g_force_gy) gy = g_force_gy;
         b.gy = gy;
         const int gx = 8 / gy;

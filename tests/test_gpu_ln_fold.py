@@ -267,7 +267,8 @@ def test_fold_error_against_the_row_offset(lib, dev, M, N, epi):
         ratios[o] = e_fold / e_plain
         print(f"offset {o:5.1f} sigma: rms error folded {e_fold:.3e}, LayerNorm kernel + GEMM {e_plain:.3e}, ratio {ratios[o]:.2f}")
     # the bound: no worse than the ordinary path at no offset, and growing no faster than the offset itself
-    assert ratios[0.0] <= 1.15 and ratios[2.0] <= 2.5 and ratios[8.5] <= 9.0 and ratios[33.0] <= 34.0, ratios
+    # (measured: 1.00 / 1.51 / 4.88 / 18.7 -- about 0.57 x the offset in sigmas; include/revo.h revo_vit_stats quotes it)
+    assert ratios[0.0] <= 1.1 and ratios[2.0] <= 2.0 and ratios[8.5] <= 6.5 and ratios[33.0] <= 24.0, ratios
     t = tele.cpu().tolist()
     assert t[0] == M and t[1] == 2 * blk and t[2] == blk, t        # every row once; > 8: the 8.5- and 33-sigma blocks; > 32: the last
 
