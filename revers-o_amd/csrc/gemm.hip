@@ -3,7 +3,6 @@
 // the fp32 residual stream, patch-embed position add).  K2/K4/K7/K8/K10 of
 // SURVEY.md §2b; replaces the F.linear / conv2d calls the upstream PE module
 // dispatches from encode_image (reference call site core_system.py:442).
-#include <cstddef>
 #include <type_traits>
 #include "gemm_core.h"
 #include "gemm256_core.h"
@@ -566,8 +565,8 @@ static_assert(G256Q_LDS <= 163840, "");
 template <class ARGS>      // GemmArgs, or the same struct read through the kernarg segment (gemm256q_kernel)
 __device__ __forceinline__ void lnc_issue_stats(const ARGS& p, int m0, char* lds_raw, int wave, int /*lane*/) {
     if (wave >= 4) return;
-    int lane;                                                                                  // (see lnc_merge_rows)
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane) :: "memory");
+    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // (see lnc_merge_rows)
+    asm volatile("" : "+v"(lane) :: "memory");
     // wave w requests the slots of rows 64 w .. 64 w + 63 -- the rows its own threads merge (lnc_merge_rows): its own
     // vmcnt wait is then all the ordering the merge needs (a piece that runs past the wave's share re-writes the next
     // wave's first bytes with the same values)
@@ -596,11 +595,8 @@ __device__ __forceinline__ void lnc_merge_rows(const ARGS& p, const char* lds_ra
     if (wave >= 4) return;
     // (the lane id is read from the hardware here: derived from the kernel's `lane` it became one more value alive across
     //  the main loop, and hipcc spilled accumulator registers INSIDE the K loop of the RoPE kernel)
-    // (as asm: the builtin's result is loop-invariant to hipcc, which computed it once in front of a persistent kernel's tile
-    //  loop, parked it in scratch around the main loop and reloaded it here behind an s_waitcnt vmcnt(0) -- a drain of the
-    //  previous tile's stores and of the next tile's DMA, in the one place built to leave them in flight)
-    int lane;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane) :: "memory");
+    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane) :: "memory");
     if (one_ktile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM) : "memory");
     const int t = wave * 64 + lane;
@@ -976,13 +972,13 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256q_kernel(GemmArgs p, i
     // (rstd, -mean rstd) of a tile's rows, two buffers used in turn: the merge for tile i + 1 (behind tile i's stores) may
     // overtake another wave's reads for tile i (at the head of its epilogue) -- no barrier between a tile's stores and the
     // next main loop
-    int par = 0;                                   // which of the two buffers this tile reads (one scalar instead of four pointers)
-#define Q_LDS_MR(P) ((float2*)(smem + G256_LDS + LNC_RAW_BYTES) + (P) * 256)
-#define Q_LDS_BC(P) (smem + G256Q_BC_OFF + (P) * 2048)
-    float2* const lds_mr0 = Q_LDS_MR(0);
+    float2* lds_mr = (float2*)(smem + G256_LDS + LNC_RAW_BYTES);
+    float2* lds_mr_next = lds_mr + 256;
     // bias and column sums of a tile's 256 columns travel to LDS with the tile's first operands (one 1-KiB DMA each, waves 4
     // and 5; an EMPTY descriptor -- the vector is absent -- delivers zeros): the epilogue then starts without a load to wait
     // for.  Two buffers in turn, like lds_mr: a wave may request tile i + 1's while another still reads tile i's.
+    char* lds_bc = smem + G256Q_BC_OFF;
+    char* lds_bc_next = lds_bc + 2048;
     auto issue_bias_csum = [&](const float* bias, const float* csum, int N, int n0_, char* dst, int lane_) {
         if (wave == 4 || wave == 5) {                       // wave-uniform
             const float* src = wave == 4 ? bias : csum;
@@ -992,7 +988,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256q_kernel(GemmArgs p, i
         }
     };
     if (lnc) lnc_issue_stats(p, m0, lds_raw, wave, lane);
-    issue_bias_csum(p.bias, lnc ? p.lnc_c : nullptr, p.N, n0, Q_LDS_BC(0), lane);
+    issue_bias_csum(p.bias, lnc ? p.lnc_c : nullptr, p.N, n0, lds_bc, lane);
     G256Operand A, B;
     g256_operand_init(A, p.A, p.lda, p.M, m0, wave, lane);
     g256_operand_init(B, p.B, p.ldb, p.N, n0, wave, lane);
@@ -1013,22 +1009,9 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256q_kernel(GemmArgs p, i
     // Without a folded LayerNorm every row gets (1, 0): the epilogue below has ONE form, rstd * acc + (c * mr + b) with c = 0
     // -- the bits of acc + b -- instead of two forms joined by selects whose constant sides (zero vectors) hipcc kept in a
     // dozen registers across the main loop.
-    if (lnc) lnc_merge_rows<G256Q_STORES>(p, lds_raw, lds_mr0, wave, lane, false, p.lnc_tele != nullptr && n0 == 0, p.M - m0);
-    else if (threadIdx.x < 512) lds_mr0[threadIdx.x] = make_float2(1.f, 0.f);        // both buffers (read behind the main loop's barriers)
+    if (lnc) lnc_merge_rows<G256Q_STORES>(p, lds_raw, lds_mr, wave, lane, false, p.lnc_tele != nullptr && n0 == 0, p.M - m0);
+    else if (threadIdx.x < 512) lds_mr[threadIdx.x] = make_float2(1.f, 0.f);        // both buffers (read behind the main loop's barriers)
     for (;;) {
-        // the next tile, known BEFORE this tile's main loop: its last two K-tiles request the next tile's first operands
-        // (gemm256_mainloop, XT = 2), re-pointing A and B in place
-        const int m0_done = m0, n0_done = n0;
-        slot += nslot;
-        const bool more = slot < total;
-        if (more) {
-            sq = __builtin_amdgcn_readfirstlane(slot / n_cnt);
-            m0 = (m_lo + sq) * 256;
-            n0 = (n_lo + (slot - sq * n_cnt)) * 256;
-        }
-        const G256Next nx = {(g256_karg_ptr)__builtin_amdgcn_kernarg_segment_ptr(), (int)offsetof(GemmArgs, A), (int)offsetof(GemmArgs, lda),
-                             (int)offsetof(GemmArgs, M), (int)offsetof(GemmArgs, B), (int)offsetof(GemmArgs, ldb), (int)offsetof(GemmArgs, N),
-                             m0, 256, n0, more};
         f32x4 acc[8][4];
 #pragma unroll
         for (int m = 0; m < 8; ++m)
@@ -1039,7 +1022,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256q_kernel(GemmArgs p, i
         unsigned long long t_a = 0, t_b = 0, t_c = 0, c_a = 0;
         if (p.stamps) { t_a = __builtin_amdgcn_s_memrealtime(); c_a = __builtin_amdgcn_s_memtime(); }
 #endif
-        gemm256_mainloop<0, false, false, G256Q_STORES, 2>(A, B, smem, p.K, wave, lane, acc, false, true, true, &nx);
+        gemm256_mainloop<0, false, false, G256Q_STORES>(A, B, smem, p.K, wave, lane, acc);
 #ifdef REVO_EXPERIMENTS
         if (p.stamps) { t_b = __builtin_amdgcn_s_memrealtime(); c_a = __builtin_amdgcn_s_memtime() - c_a; }      // shader-clock cycles of the main loop
 #endif
@@ -1056,26 +1039,25 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256q_kernel(GemmArgs p, i
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
         const int lr = lane_e & 15, lq = lane_e >> 4;
         const int wr = wave >> 2, wc = wave & 3;
+        const int m0_done = m0, n0_done = n0;
         const int nb = n0_done + wc * 64;                           // this wave's first column
+        slot += nslot;
+        const bool more = slot < total;
         // (0) (rstd, -mean rstd) of this lane's eight fragment rows, out of LDS before ANY vector-memory request of the
         //     epilogue: hipcc guards an LDS read with s_waitcnt vmcnt(0) while DMA it knows of may be outstanding (it cannot
         //     tell the operand image from the statistics, nor see the main loop's counted waits) -- here that wait is free
         float2 st8[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) st8[m] = Q_LDS_MR(par)[wr * 128 + m * 16 + lr];
+        for (int m = 0; m < 8; ++m) st8[m] = lds_mr[wr * 128 + m * 16 + lr];
         //     ... and the tile's bias and column sums (requested with its first operands)
         f32x4 bias4[4], c4[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            bias4[n] = *(const f32x4*)(Q_LDS_BC(par) + (wc * 64 + n * 16 + lq * 4) * 4);
-            c4[n] = *(const f32x4*)(Q_LDS_BC(par) + 1024 + (wc * 64 + n * 16 + lq * 4) * 4);
+            bias4[n] = *(const f32x4*)(lds_bc + (wc * 64 + n * 16 + lq * 4) * 4);
+            c4[n] = *(const f32x4*)(lds_bc + 1024 + (wc * 64 + n * 16 + lq * 4) * 4);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         G256_FENCE();
-#ifdef REVO_EXPERIMENTS
-        unsigned long long t_s1 = 0, t_s2 = 0;
-        if (q.stamps) t_s1 = __builtin_amdgcn_s_memrealtime();         // (arguments re-read, statistics / bias / column sums out of LDS)
-#endif
         // (1) what the RoPE form needs from memory, requested BEFORE the next tile's operands
         // RoPE table: entry (token, pair) as (cos, sin); a lane's fragment holds two pairs of one token: one 16-byte load
         // per fragment, through a descriptor (32-bit offsets).  Token of fragment row m: tok0 + 16 m (mod S).
@@ -1120,16 +1102,17 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256q_kernel(GemmArgs p, i
                     for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(rt[i][mm][n]));
         }
         G256_FENCE();
-        // (2) the next tile's row statistics, bias and column sums
+        // (2) the next tile: statistics, then its first K-tile and a half (the image is free: the main loop ended behind a
+        //     barrier, and nothing below touches it)
         if (more) {
-            // (its first K-tile and a half are already on their way: requested by the main loop's last two K-tiles)
+            sq = __builtin_amdgcn_readfirstlane(slot / n_cnt);
+            m0 = (m_lo + sq) * 256;
+            n0 = (n_lo + (slot - sq * n_cnt)) * 256;
             if (lnc) lnc_issue_stats(q, m0, lds_raw, wave, lane_e);
-            issue_bias_csum(q.bias, lnc ? q.lnc_c : nullptr, q.N, n0, Q_LDS_BC(par ^ 1), lane_e);
-#ifdef REVO_EXPERIMENTS
-            G256_FENCE();
-            if (q.stamps) t_s2 = __builtin_amdgcn_s_memrealtime();     // (statistics / bias requests: done)
-            G256_FENCE();
-#endif
+            issue_bias_csum(q.bias, lnc ? q.lnc_c : nullptr, q.N, n0, lds_bc_next, lane_e);
+            g256_operand_init(A, q.A, q.lda, q.M, m0, wave, lane_e);
+            g256_operand_init(B, q.B, q.ldb, q.N, n0, wave, lane_e);
+            g256_issue_prologue(A, B, smem, q.K, wave);
         }
         G256_FENCE();
         // (3) accumulators -> bf16 row chunks.  out[m][P]: row m * 16 + lr, 8 columns from (2 P + (lq & 1)) * 16 + (lq >> 1) * 8
@@ -1215,11 +1198,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256q_kernel(GemmArgs p, i
 #ifdef REVO_EXPERIMENTS
         if (q.stamps && wave == 0 && lane_e == 0 && tiles_done < q.stamp_items) {
             unsigned long long* dst = q.stamps + ((size_t)blockIdx.x * q.stamp_items + tiles_done) * 4;
-            // item 2: the set-up's end; with the switch: the main loop's shader-clock cycles, or the set-up's three parts (20 bits each)
-            unsigned long long mid = t_c;
-            if (q.stagger_groups & 0x200) mid = c_a;
-            if (q.stagger_groups & 0x400) mid = ((t_s1 - t_b) & 0xfffff) | (((t_s2 > t_s1 ? t_s2 - t_s1 : 0) & 0xfffff) << 20) | (((t_c - (t_s2 > t_s1 ? t_s2 : t_s1)) & 0xfffff) << 40);
-            dst[0] = t_a; dst[1] = t_b; dst[2] = mid; dst[3] = __builtin_amdgcn_s_memrealtime();
+            dst[0] = t_a; dst[1] = t_b; dst[2] = (q.stagger_groups & 0x200) ? c_a : t_c; dst[3] = __builtin_amdgcn_s_memrealtime();
         }
         ++tiles_done;
 #endif
@@ -1227,13 +1206,12 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256q_kernel(GemmArgs p, i
         if (lnc) {
             // the next tile's rows, into the other buffer: the wait leaves the 16 youngest instructions -- the stores -- in
             // flight; the statistics pieces are the oldest
-            lnc_merge_rows<G256Q_STORES>(q, lds_raw, Q_LDS_MR(par ^ 1), wave, lane_e, false, q.lnc_tele != nullptr && n0 == 0, q.M - m0);
+            lnc_merge_rows<G256Q_STORES>(q, lds_raw, lds_mr_next, wave, lane_e, false, q.lnc_tele != nullptr && n0 == 0, q.M - m0);
         }
-        par ^= 1;
+        { float2* t = lds_mr; lds_mr = lds_mr_next; lds_mr_next = t; }
+        { char* t = lds_bc; lds_bc = lds_bc_next; lds_bc_next = t; }
     }
 }
-#undef Q_LDS_MR
-#undef Q_LDS_BC
 
 #ifdef REVO_EXPERIMENTS
 // Phased form of the persistent kernel -- EXPERIMENT LIBRARY ONLY: measured in round 5 and not adopted (DESIGN_HISTORY.md,
@@ -1527,7 +1505,7 @@ void gemm_set_qstores(int on) { g_qstores = on; }
 template <int EPI>
 static bool use_256q(const GemmArgs& a) {
     if (!(EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE) || !g_qstores) return false;
-    if (a.N % 256 || a.K < 256 || a.K % 128 || (a.ldc & 7) || 256l * a.ldc * 2 >= (1l << 31)) return false;     // (cross-tile prefetch: an even number of K-tiles)
+    if (a.N % 256 || a.K < 128 || (a.ldc & 7) || 256l * a.ldc * 2 >= (1l << 31)) return false;
     if (EPI == EPI_BF16_ROPE && (a.rope_cols % 64 || (long)a.rope_S * (a.rope_hd >> 1) * 8 >= (1l << 31))) return false;
     // RoPE: measured, not adopted (profiles/r06_gemm_queued_stores.json): the rotation's 32 table loads per lane must be
     // waited for behind the next tile's DMA requests, and hipcc's wait counts leave LDS-DMA out -- every such wait is a
@@ -1544,8 +1522,7 @@ static int launch_256q(const GemmArgs& a, hipStream_t st) {
         b.stamps = g_stamps; b.stamp_items = g_stamp_items;
         b.stagger_cycles = 0;
         b.stagger_groups = ((g_qstores & 7) == 2 ? 0x100 : 0)        // 2: the stores are issued but dropped (timing only)
-                           | ((g_qstores & 8) ? 0x200 : 0)           // + 8: stamp item 2 = shader-clock cycles of the main loop (its clock)
-                           | ((g_qstores & 16) ? 0x400 : 0);         // + 16: stamp item 2 = the epilogue set-up's three parts
+                           | ((g_qstores & 8) ? 0x200 : 0);          // + 8: stamp item 2 = shader-clock cycles of the main loop (its clock)
 #endif
         const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
         int gy = xcd_stripes(tiles_n);

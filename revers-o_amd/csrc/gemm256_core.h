@@ -56,40 +56,6 @@ __device__ __forceinline__ void g256_operand_init(G256Operand& op, const bf16_t*
     op.voff = (uint32_t)(r * ld * 2 + c * 16);
 }
 
-// The same windows for another tile of the same matrix: descriptors only (scalar arithmetic), the lane's offset does not change.
-__device__ __forceinline__ void g256_operand_retarget(G256Operand& op, const bf16_t* base, long ld, long rows, int row0,
-                                                      int tile_rows = 256) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        long left = rows - (row0 + 64 * j);
-        left = left < 0 ? 0 : (left > 64 ? 64 : left);
-        if (left > tile_rows - 64 * j) left = tile_rows - 64 * j < 0 ? 0 : tile_rows - 64 * j;
-        op.rsrc[j] = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)(row0 + 64 * j) * ld), 0,
-                                                       (int)(left * ld * 2), 0x00020000);
-    }
-}
-// Where a persistent kernel's NEXT output tile lies (gemm256_mainloop's cross-tile prefetch, XT)
-// The matrices' addresses and sizes are NOT carried in registers: the loop reads them from the kernel-argument segment at the
-// moment it re-points an operand (once per output tile, through a pointer the compiler cannot see through).  Carried across
-// the K loop -- a dozen scalars on top of the two operands' eight descriptors and the DMA destinations -- they overflowed the
-// scalar file: 44 v_readlane per K-tile pair inside the loop.
-typedef const __attribute__((address_space(4))) char* g256_karg_ptr;
-struct G256Next {
-    g256_karg_ptr karg;                              // the kernel's argument segment
-    int off_a, off_lda, off_a_rows;                  // byte offsets in it: A's address (8 bytes), its leading dimension (long), its row count (int)
-    int off_b, off_ldb, off_b_rows;
-    int a_row0, a_tile_rows, b_row0;                 // the next tile's first rows of A and of B (its columns)
-    bool valid;                                      // there is a next tile (wave-uniform)
-};
-__device__ __forceinline__ void g256_operand_retarget_karg(G256Operand& op, g256_karg_ptr karg, int off_ptr, int off_ld, int off_rows,
-                                                           int row0, int tile_rows) {
-    asm volatile("" : "+s"(karg));
-    const bf16_t* base = *(const bf16_t* const __attribute__((address_space(4)))*)(karg + off_ptr);
-    const long ld = *(const __attribute__((address_space(4))) long*)(karg + off_ld);
-    const int rows = *(const __attribute__((address_space(4))) int*)(karg + off_rows);
-    g256_operand_retarget(op, base, ld, rows, row0, tile_rows);
-}
-
 // one half-tile (128 rows x 64 k): two 16-byte-per-lane DMA instructions per thread
 __device__ __forceinline__ void g256_issue_half(const G256Operand& op, int half, int kbyte, char* region, int wave) {
 #pragma unroll
@@ -197,87 +163,6 @@ __device__ __forceinline__ void g256_issue_prologue_deep(const G256Operand& A, c
     }
 }
 
-// The LAST two K-tiles (nt - 2: even, stage 0; nt - 1: odd, stage 1) of an output tile whose workgroup has another tile to
-// do: gemm256_mainloop's schedule with the next output tile's first operands requested where these two tiles have none of
-// their own to request (XT: see gemm256_mainloop).  A function of its own, in front of nothing but the loop's exit, so
-// that the steady loop carries none of its scalars (as branches inside the loop they cost 32-44 v_readlane per trip).
-// Entered with the reads of tile nt - 2's first operands issued (as every even tile is), returns as the loop does.
-template <int ROWS, int XT>
-__device__ __forceinline__ void g256_last_two_tiles_xt(G256Operand& A, G256Operand& B, char* smem, int nt, int wave, G256Frags& f,
-                                                       const G256Addr& ad, f32x4 (&acc)[8][4], bool tall, const G256Next* nxp) {
-    static_assert(ROWS == 0 || ROWS == 192, "");
-    const bool wact = wave < 4;
-#define G256X_LO(...) do { __VA_ARGS__; } while (0)
-#define G256X_HI(...) do { if (ROWS == 0 || wact) { __VA_ARGS__; } } while (0)
-#define G256X_HT(...) do { if (ROWS == 192 && !wact && tall) { __VA_ARGS__; } } while (0)
-    const int t = nt - 2;
-    // ------------------------------------------------------------ even tile nt - 2, stage 0
-    // P0
-    G256X_HI(g256_read_a<64, 0>(f.ahi, ad.a););
-    G256X_HT(g256_read_a1<64, 0>(f.ahi, ad.a););
-    g256_issue_half(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
-    G256_FENCE();
-    G256X_LO(g256_cluster<0, 0>(f.alo, f.blo, acc););
-    G256_FENCE();
-    // P1
-    G256X_LO(g256_read_b<32, 0>(f.bhi, ad.b););
-    g256_issue_half(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
-    G256_FENCE();
-    G256X_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
-    G256X_HT(g256_cluster1<4, 0>(f.ahi, f.blo, acc););
-    G256_FENCE();
-    // P2: every wave has retired its A reads of stage 0; A is done with this output tile -> the next tile's K-tile 0
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    g256_operand_retarget_karg(A, nxp->karg, nxp->off_a, nxp->off_lda, nxp->off_a_rows, nxp->a_row0, nxp->a_tile_rows);
-    g256_issue_half(A, 0, 0, G256_A(smem, 0), wave);
-    G256_FENCE();
-    G256X_HI(g256_cluster<4, 2>(f.ahi, f.bhi, acc););
-    G256X_HT(g256_cluster1<4, 2>(f.ahi, f.bhi, acc););
-    G256_FENCE();
-    // P3: publish tile nt - 1, start reading it (the four requests of the next tile's A stay in flight)
-    g256_issue_half(A, 1, 0, G256_A(smem, 0), wave);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    G256X_HI(g256_read_a<64, 1>(f.ahi, ad.a););
-    G256X_HT(g256_read_a1<64, 1>(f.ahi, ad.a););
-    G256X_LO(g256_read_b<0, 1>(f.blo, ad.b););
-    G256_FENCE();
-    G256X_LO(g256_cluster<0, 2>(f.alo, f.bhi, acc););
-    G256_FENCE();
-    // ------------------------------------------------------------ odd tile nt - 1, stage 1: B is done with this output tile
-    // P0'
-    G256X_LO(g256_read_a<0, 1>(f.alo, ad.a););
-    g256_operand_retarget_karg(B, nxp->karg, nxp->off_b, nxp->off_ldb, nxp->off_b_rows, nxp->b_row0, 256);
-    g256_issue_half(B, 0, 0, G256_B(smem, 0), wave);
-    G256_FENCE();
-    G256X_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
-    G256X_HT(g256_cluster1<4, 0>(f.ahi, f.blo, acc););
-    G256_FENCE();
-    // P1'
-    G256X_LO(g256_read_b<32, 1>(f.bhi, ad.b););
-    g256_issue_half(B, 1, 0, G256_B(smem, 0), wave);
-    G256_FENCE();
-    G256X_LO(g256_cluster<0, 0>(f.alo, f.blo, acc););
-    G256_FENCE();
-    // P2'
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (XT == 2) g256_issue_half(A, 0, 128, G256_A(smem, 1), wave);          // the next tile's K-tile 1
-    G256_FENCE();
-    G256X_LO(g256_cluster<0, 2>(f.alo, f.bhi, acc););
-    G256_FENCE();
-    // P3'
-    if (XT == 2) g256_issue_half(A, 1, 128, G256_A(smem, 1), wave);
-    G256_FENCE();
-    G256X_HI(g256_cluster<4, 2>(f.ahi, f.bhi, acc););
-    G256X_HT(g256_cluster1<4, 2>(f.ahi, f.bhi, acc););
-    G256_FENCE();
-#undef G256X_LO
-#undef G256X_HI
-#undef G256X_HT
-}
-
 // K % 64 == 0, K >= 64.  acc must be zero-initialised (or hold the running sum) by the caller,
 // and g256_issue_prologue(A, B, ...) must have been issued by this wave (any vector-memory
 // operations issued after it only make the first wait below more conservative).
@@ -308,26 +193,13 @@ __device__ __forceinline__ void g256_last_two_tiles_xt(G256Operand& A, G256Opera
 // must then skip its B requests and count differently: with those run-time tests of t == 0 hipcc peeled the first trip,
 // parked an accumulator in scratch around it and reloaded it behind an s_waitcnt vmcnt(0) -- once per output tile, a
 // drain of the DMA queue where this mode is meant to remove one.)  Needs K >= 128.
-// XT > 0 (cross-tile prefetch, persistent kernels; K a multiple of 128, K >= 256): the loop's last two K-tiles have nothing of
-// their own left to request -- they request the NEXT output tile's first operands instead, in the very slots of the schedule
-// where a K-tile t + 2 / t + 1 would be requested (A of K-tile 0 behind the last even tile's barrier, B of K-tile 0 in the last
-// tile's first two phases, and with XT = 2 A of K-tile 1 behind the last tile's barrier): the dozen DMA requests a persistent
-// kernel used to issue in a block between two main loops (1.1 us of blocked issue per tile, stamped) ride between MFMA
-// clusters like every other request.  The operands' descriptors are re-pointed IN PLACE when their last use for this tile is
-// behind (A: in front of the last even tile's third phase; B: in front of the last tile's first) -- no second set of scalar
-// registers.  On return A and B describe the next tile (nx.valid), its K-tile 0 and (XT = 2) A of K-tile 1 are on their way,
-// and the caller must not request them again.  XT = 1 leaves stage 1 alone (callers whose epilogue uses it as scratch).
-template <int ROWS = 0, bool RT = false, bool DEEP = false, int QS = 0, int XT = 0>
-__device__ __forceinline__ void gemm256_mainloop(const G256Operand& A_, const G256Operand& B_, char* smem, int K,
+template <int ROWS = 0, bool RT = false, bool DEEP = false, int QS = 0>
+__device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G256Operand& B, char* smem, int K,
                                                  int wave, int lane, f32x4 (&acc)[8][4], bool tall = false,
-                                                 bool rt_lo = true, bool rt_hi = true, const G256Next* nxp = nullptr) {
+                                                 bool rt_lo = true, bool rt_hi = true) {
     static_assert(ROWS == 0 || ROWS == 64 || ROWS == 128 || ROWS == 192, "");
     static_assert(!RT || ROWS == 0, "the run-time row mode has no compile-time one");
     static_assert(QS == 0 || (!DEEP && QS + 4 <= 63), "queued stores: the ordinary schedule, and a count vmcnt can hold");
-    static_assert(XT == 0 || (!DEEP && !RT), "cross-tile prefetch: the ordinary schedule");
-    G256Operand& A = const_cast<G256Operand&>(A_);      // (re-pointed in place when XT: the callers' objects are not const)
-    G256Operand& B = const_cast<G256Operand&>(B_);
-    const bool xt = XT != 0 && nxp->valid;              // wave-uniform
     const bool wact = wave < 4;
 #define G256_LO(...) do { if (RT ? rt_lo : (ROWS == 0 || ROWS == 192 || wact)) { __VA_ARGS__; } } while (0)
 #define G256_HI(...) do { if (RT ? rt_hi : (ROWS == 0 || ((ROWS == 128 || ROWS == 192) && wact))) { __VA_ARGS__; } } while (0)
@@ -350,11 +222,9 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A_, const G2
     G256_LO(g256_read_b<0, 0>(f.blo, ad.b););
     G256_FENCE();
 
-    // two K-tiles per trip; an odd trailing tile is peeled so the loop has a single exit.  With a next output tile to
-    // prefetch (XT) the last trip is g256_last_two_tiles_xt's.
+    // two K-tiles per trip; an odd trailing tile is peeled so the loop has a single exit
     int t = 0;
-    const int nt_loop = xt ? nt - 2 : nt;
-    for (; t + 1 < nt_loop; t += 2) {
+    for (; t + 1 < nt; t += 2) {
         // ------------------------------------------------------------ even tile t, stage 0
         {
             const bool n1 = t + 1 < nt, n2 = t + 2 < nt;
@@ -435,12 +305,6 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A_, const G2
             G256_HI(g256_cluster<4, 2>(f.ahi, f.bhi, acc););
             G256_HT(g256_cluster1<4, 2>(f.ahi, f.bhi, acc););
             G256_FENCE();
-        }
-    }
-    if constexpr (XT != 0) {
-        if (xt) {
-            g256_last_two_tiles_xt<ROWS, XT>(A, B, smem, nt, wave, f, ad, acc, tall, nxp);
-            t = nt;
         }
     }
     if (t < nt) {
