@@ -565,8 +565,8 @@ static_assert(G256Q_LDS <= 163840, "");
 template <class ARGS>      // GemmArgs, or the same struct read through the kernarg segment (gemm256q_kernel)
 __device__ __forceinline__ void lnc_issue_stats(const ARGS& p, int m0, char* lds_raw, int wave, int /*lane*/) {
     if (wave >= 4) return;
-    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // (see lnc_merge_rows)
-    asm volatile("" : "+v"(lane) :: "memory");
+    int lane;                                                                                  // (see lnc_merge_rows)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane) :: "memory");
     // wave w requests the slots of rows 64 w .. 64 w + 63 -- the rows its own threads merge (lnc_merge_rows): its own
     // vmcnt wait is then all the ordering the merge needs (a piece that runs past the wave's share re-writes the next
     // wave's first bytes with the same values)
@@ -595,8 +595,11 @@ __device__ __forceinline__ void lnc_merge_rows(const ARGS& p, const char* lds_ra
     if (wave >= 4) return;
     // (the lane id is read from the hardware here: derived from the kernel's `lane` it became one more value alive across
     //  the main loop, and hipcc spilled accumulator registers INSIDE the K loop of the RoPE kernel)
-    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(lane) :: "memory");
+    // (as asm: the builtin's result is loop-invariant to hipcc, which may compute it once in front of a persistent kernel's tile
+    //  loop, park it in scratch around the main loop and reload it here behind an s_waitcnt vmcnt(0) -- a drain of the previous
+    //  tile's stores and of the next tile's DMA)
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane) :: "memory");
     if (one_ktile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM) : "memory");
     const int t = wave * 64 + lane;
