@@ -36,14 +36,22 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(const bf16x8* __restric
 }
 
 __global__ __launch_bounds__(256) void probe_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16) {
-    // four 16-byte loads in flight per lane before the first store (one per trip measured 4.8 TB/s: latency, not bandwidth)
-    const long stride = (long)gridDim.x * 256;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    // a workgroup copies contiguous 64-KiB chunks (4096 x 16 bytes), eight loads per lane in flight before the first store
+    // (one load per trip at a 16-MiB stride measured 4.3-4.8 TB/s: latency and DRAM page misses, not bandwidth)
+    const long chunks = n16 >> 12;
+    for (long c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const uint4* s = src + (c << 12) + threadIdx.x;
+        uint4* d = dst + (c << 12) + threadIdx.x;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = s[(h * 8 + i) * 256];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[(h * 8 + i) * 256] = v[i];
+        }
     }
-    for (; i < n16; i += stride) dst[i] = src[i];
+    for (long i = (chunks << 12) + (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) dst[i] = src[i];
 }
 
 }  // namespace revo
@@ -62,7 +70,7 @@ extern "C" int64_t revo_probe_mfma_flops(int32_t blocks, int32_t iters) {
 extern "C" int32_t revo_probe_copy(void* dst, const void* src, int64_t bytes, void* stream) {
     REVO_REQUIRE(dst && src && bytes >= 16 && bytes % 16 == 0, "probe_copy: bad arguments");
     REVO_REQUIRE((((uintptr_t)dst | (uintptr_t)src) & 15) == 0, "probe_copy: buffers must be 16-byte aligned");
-    hipLaunchKernelGGL(revo::probe_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst,
+    hipLaunchKernelGGL(revo::probe_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst,
                        (long)(bytes / 16));
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
