@@ -929,6 +929,83 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256p_kernel(GemmArgs p, i
 }
 
 
+// ---- queued-stores kernel: the rows the tiles leave over
+template <int EPI>
+__device__ __forceinline__ void gemm256q_tail(char* smem, int wave) {
+    const __attribute__((address_space(4))) GemmArgs* pk0 = (const __attribute__((address_space(4))) GemmArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    if (pk0->qtail_rows <= 0) return;
+    const bool lnc = pk0->lnc_stats != nullptr;
+    // ---- The rows the tiles leave over: rows [M, M + qtail_rows), at most 64 (fc1 of PE-L14 at batch 64: 36 928 = 144 x 256 + 64).
+    // As a launch of their own (gemm_skinny_kernel) they were 13 us + a launch boundary behind every fc1: 0.54 GFLOP, i.e. nothing
+    // but latency, with the whole chip waiting.  Here every workgroup, behind its last tile and while others still work on
+    // theirs, takes 16-column strips: eight waves split K, each with all its loads in flight at once (the leftover rows of A are
+    // 128 KB that every workgroup reads: L2), four 16 x 16 accumulators per wave, the eight partial sums added through LDS in a
+    // fixed order, then the tile epilogue's arithmetic (folded LayerNorm from the rows' statistics in memory, bias, GELU).
+    {
+        const __attribute__((address_space(4))) GemmArgs& q = *pk0;
+        int lane_t;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
+        const int li = lane_t & 15, lq = lane_t >> 4;
+        const int tail = q.qtail_rows, Kw = q.K >> 3;                    // K columns per wave (a multiple of 32: launcher)
+        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)(q.A + (long)q.M * q.lda), 0, (int)(tail * q.lda * 2), 0x00020000);
+        float* part = (float*)smem;                                       // [8 waves][64 rows][16 columns] fp32 partial sums: 32 KiB
+        for (int strip = blockIdx.x; strip * 16 < q.N; strip += gridDim.x) {
+            __builtin_amdgcn_s_barrier();                                 // (the image is free: every wave is out of its last main loop / the previous strip's sums)
+            f32x4 acc4[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc4[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bf16_t* wrow = q.B + (long)(strip * 16 + li) * q.ldb + wave * Kw + lq * 8;
+            const int aoff = (li * (int)q.lda + wave * Kw + lq * 8) * 2;
+            for (int k0 = 0; k0 < Kw; k0 += 128) {                        // four 32-wide steps at a time: 20 loads per lane in flight
+                bf16x8 wf[4], af[4][4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    if (k0 + s4 * 32 < Kw) {
+                        wf[s4] = *(const bf16x8*)(wrow + k0 + s4 * 32);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            af[s4][m] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ars, aoff + (m * 16 * (int)q.lda + k0 + s4 * 32) * 2, 0, 0));
+                    }
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    if (k0 + s4 * 32 < Kw) {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc4[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s4], af[s4][m], acc4[m], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) *(f32x4*)(part + (wave * 64 + m * 16 + li) * 16 + lq * 4) = acc4[m];
+            __builtin_amdgcn_s_barrier();
+            if (wave < 4) {
+                const int tt = wave * 64 + lane_t;
+                const int row = tt >> 2, cq = tt & 3;
+                f32x4 v = *(const f32x4*)(part + row * 16 + cq * 4);
+#pragma unroll
+                for (int w = 1; w < 8; ++w) v += *(const f32x4*)(part + (w * 64 + row) * 16 + cq * 4);
+                if (row < tail) {
+                    const int col = strip * 16 + cq * 4;
+                    const long grow = (long)q.M + row;
+                    const f32x4 b4 = q.bias ? *(const f32x4*)(q.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (lnc) {
+                        float rstd, mr;
+                        lnf_merge(q.lnc_stats + grow * q.lnc_parts, q.lnc_parts, q.lnc_eps, rstd, mr);
+                        const f32x4 c = *(const f32x4*)(q.lnc_c + col);
+                        v = v * rstd + (c * mr + b4);                     // rstd (acc - mean c) + b', the tile epilogue's operation order
+                    } else {
+                        v += b4;
+                    }
+                    if (EPI == EPI_BF16_GELU) v = gelu_erf4(v);
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *(uint2*)((bf16_t*)q.C + grow * q.ldc + col) = o;
+                }
+            }
+        }
+    }
+}
+
 // ---- Persistent 256 x 256 kernel with QUEUED STORES (bf16 epilogues: plain, GELU, RoPE; 256-row tiles, N % 256 == 0, K >= 128).
 // gemm256p_kernel's phases run in series on every CU at the same moments: a tile's stores are pushed out (3.4 us at the
 // per-CU store rate), and the next main loop's first wait for an operand requested behind them also waits for every one
@@ -964,8 +1041,11 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256q_kernel(GemmArgs p, i
     const int n_cnt = (tiles_n - n_lo) < pn ? (tiles_n - n_lo) : pn;
     const int total = (m_cnt > 0 && n_cnt > 0) ? m_cnt * n_cnt : 0;
     int slot = blockIdx.x >> 3;
-    if (slot >= total) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (slot >= total) {                  // (an XCD region with fewer tiles than workgroups: its share of the leftover rows is still due)
+        gemm256q_tail<EPI>(smem, wave);
+        return;
+    }
     const int lane = threadIdx.x & 63;
 
     int sq = __builtin_amdgcn_readfirstlane(slot / n_cnt);
@@ -1214,6 +1294,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void gemm256q_kernel(GemmArgs p, i
         { float2* t = lds_mr; lds_mr = lds_mr_next; lds_mr_next = t; }
         { char* t = lds_bc; lds_bc = lds_bc_next; lds_bc_next = t; }
     }
+    gemm256q_tail<EPI>(smem, wave);
 }
 
 #ifdef REVO_EXPERIMENTS
@@ -1503,8 +1584,9 @@ static int g_dbg = 0;          // timing experiments only (EPI_BF16, librevo_exp
 void gemm_set_debug(int d) { g_dbg = d; }
 #endif
 // the persistent kernel with queued stores (gemm256q_kernel): bf16 epilogues on whole 256-column tiles
+static int g_qtail = 1;        // timing experiments only: 0 = the leftover rows behind the queued-stores kernel as a launch of their own
 static int g_qstores = 1;      // timing experiments only: 0 = gemm256p_kernel for every epilogue
-void gemm_set_qstores(int on) { g_qstores = on; }
+void gemm_set_qstores(int on) { g_qstores = on & 31; g_qtail = !(on & 32); }      // (+ 32: no fused leftover rows)
 template <int EPI>
 static bool use_256q(const GemmArgs& a) {
     if (!(EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE) || !g_qstores) return false;
@@ -1556,7 +1638,7 @@ static int launch_256(const GemmArgs& a, hipStream_t st) {
 #endif
     if (g_persistent && a.K >= 128 && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) > 256) {
 #ifdef REVO_EXPERIMENTS
-        if (use_256q<EPI>(a) && g_phase_groups <= 1 && g_stagger_cycles == 0) return launch_256q<EPI>(a, st);      // (its own stamps: revo_debug_gemm_stamps)
+        if (use_256q<EPI>(a) && (a.qtail_rows > 0 || (g_phase_groups <= 1 && g_stagger_cycles == 0))) return launch_256q<EPI>(a, st);      // (its own stamps: revo_debug_gemm_stamps)
 #else
         if (use_256q<EPI>(a)) return launch_256q<EPI>(a, st);
 #endif
@@ -1913,6 +1995,14 @@ static int launch_t(const GemmArgs& a_in, hipStream_t st) {
                 if (a2.lnc_stats) a2.lnc_stats += (long)m_main * a.lnc_parts;     // the leftover rows' statistics
                 const long esz = (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) ? 2 : 4;
                 a2.C = (char*)a.C + (long)m_main * a.ldc * esz;
+                if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+                    // at most 64 leftover rows behind whole rounds of the queued-stores kernel: done by that launch (qtail_rows)
+                    if (a2.M <= 64 && a.K % 256 == 0 && a.N % 16 == 0 && g_qtail && use_256q<EPI>(a1) && g_persistent &&
+                        (long)((a1.M + 255) / 256) * ((a1.N + 255) / 256) > 256 && (long)a2.M * a.lda * 2 < (1l << 31)) {
+                        a1.qtail_rows = a2.M;
+                        return launch_256<EPI>(a1, st);
+                    }
+                }
                 const int rc = launch_256<EPI>(a1, st);
                 if (rc) return rc;
                 if (use_skinny(a2)) return launch_skinny<EPI>(a2, st);      // fc1 at batch 64: 64 rows are left over

@@ -60,6 +60,10 @@ struct GemmArgs {
     // The 256 x 256 kernels' column-tile-0 workgroups -- each row of the launch exactly once -- add: [0] rows merged,
     // [1] rows with |mean| * rstd > LNC_TELE_RATIO, [2] rows with |mean| * rstd > 4 * LNC_TELE_RATIO.
     unsigned long long* lnc_tele;
+    // Set by the launcher (queued-stores kernel only): rows [M, M + qtail_rows) -- the few rows that whole rounds of 256-row
+    // tiles leave over (fc1 of PE-L14 at batch 64: 64) -- are done by the same launch, one 16-column strip per workgroup
+    // behind its last tile, instead of by a launch of their own (gemm.hip gemm256q_kernel)
+    int qtail_rows;
 #ifdef REVO_EXPERIMENTS
     int stagger_cycles, stagger_groups;   // timing experiment (persistent kernel): phase groups, see gemm256p_kernel
     unsigned long long* stamps; int stamp_items;   // diagnostic (gemm256pp_kernel): [workgroup][item][4] 100 MHz time stamps

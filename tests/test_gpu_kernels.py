@@ -544,7 +544,14 @@ def test_gemm_queued_stores_kernel_equals_the_drained_one(dev, gemm_tile, M, K, 
         _lib.check(lib.revo_op_set_qstores(1))
     assert torch.isfinite(queued[0].float()).all()
     assert all(torch.equal(q, queued[0]) for q in queued[1:])          # repeatable
-    assert torch.equal(queued[0], drained)
+    # rows the whole rounds of tiles leave over (fc1: 64) are done by the queued-stores launch itself, K split over eight waves:
+    # another summation order than the skinny kernel's -- equal up to the last bit of a bf16 here and there, not bit for bit
+    m_tiles = M - M % 256 if (K % 256 == 0 and epi != 5 and M % 256 and M % 256 <= 64) else M
+    assert torch.equal(queued[0][:m_tiles], drained[:m_tiles])
+    if m_tiles < M:
+        d = (queued[0][m_tiles:].float() - drained[m_tiles:].float()).abs()
+        assert d.max().item() <= 0.008 * drained[m_tiles:].float().abs().max().item() + 1e-3, d.max().item()
+        assert (d > 0).float().mean().item() < 0.02
     rows = torch.cat([torch.arange(0, 300, device=dev), torch.arange(M - 300, M, device=dev)])
     ref = a[rows].double() @ b.double().T
     if stats is not None and epi != 5:
