@@ -96,6 +96,7 @@ EXPERIMENT_SIGNATURES = {
     "revo_debug_seed_bounds": (_i32, [_p, _p]),
     "revo_debug_read_workspace": (_i64, [_p, _i64, _i64, _p]),
     "revo_debug_stream_in_planes": (_i32, [_p, _i32]),
+    "revo_probe_gridbar": (_i32, [_i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "revo_debug_scan_plan": (_i64, [_i32, _i64, C.POINTER(C.c_int64), _i32]),
 }
 BASE_SIGNATURES = dict(SIGNATURES)

@@ -54,6 +54,68 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const uint4* __restrict
     for (long i = (chunks << 12) + (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) dst[i] = src[i];
 }
 
+#ifdef REVO_EXPERIMENTS
+// ---- experiment (scripts/gridbar_probe.py; verdict round 5, item 8): what does a grid-wide barrier cost against a kernel
+// boundary?  A stage = every workgroup writes n16 x 16 bytes of its own slice, then reads the slice of the workgroup
+// half the grid away (another XCD), which is only correct after a device-wide release / acquire.  The barrier is a
+// monotonic counter in device memory: one atomic per workgroup, wave 0 spins (s_sleep) until the counter reaches
+// stage x grid, bounded by the 100-MHz clock (5 ms): a grid that is not co-resident ends with the error flag set instead
+// of hanging.  The chain kernel does one stage per launch.
+__device__ __forceinline__ bool probe_grid_barrier(unsigned* ctr, unsigned target, unsigned* err) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);            // agent scope: this workgroup's stores leave its XCD's L2
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 500000ull) { *err = 1u; break; }
+        }
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return true;
+}
+__device__ __forceinline__ float probe_stage(float4* buf, int n16, int it, int bid, int nb) {
+    float4* mine = buf + (size_t)bid * n16;
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) mine[i] = (float4){(float)(it + bid), 1.f, 2.f, (float)i};
+    return 0.f;
+}
+__device__ __forceinline__ float probe_read(const float4* buf, int n16, int bid, int nb) {
+    const float4* other = buf + (size_t)((bid + nb / 2) % nb) * n16;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) s += other[i].x;
+    return s;
+}
+__global__ __launch_bounds__(512) void probe_gridbar_kernel(unsigned* ctr, unsigned* err, float4* buf, int n16, int iters,
+                                                             float* sink, unsigned long long* stamps) {
+    const int bid = blockIdx.x, nb = gridDim.x;
+    float s = 0.f;
+    int bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        probe_stage(buf, n16, it, bid, nb);
+        if (stamps && threadIdx.x == 0 && bid == 0) stamps[2 * it] = __builtin_amdgcn_s_memrealtime();
+        probe_grid_barrier(ctr, (unsigned)(it * 2 + 1) * nb, err);
+        if (stamps && threadIdx.x == 0 && bid == 0) stamps[2 * it + 1] = __builtin_amdgcn_s_memrealtime();
+        const float r = probe_read(buf, n16, bid, nb);
+        // every lane checks what it read: the neighbour's stage-`it` values
+        const float want = (float)(it + (bid + nb / 2) % nb);
+        int cnt = 0;
+        for (int i = threadIdx.x; i < n16; i += blockDim.x) ++cnt;
+        if (r != want * (float)cnt) bad = 1;
+        s += r;
+        probe_grid_barrier(ctr, (unsigned)(it * 2 + 2) * nb, err);      // the slice is rewritten by the next stage
+    }
+    if (bad) *err = 2u;
+    sink[bid * blockDim.x + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(512) void probe_chain_kernel(float4* buf, int n16, int it, float* sink, int phase) {
+    const int bid = blockIdx.x, nb = gridDim.x;
+    if (phase == 0) probe_stage(buf, n16, it, bid, nb);
+    else sink[bid * blockDim.x + threadIdx.x] += probe_read(buf, n16, bid, nb);
+}
+#endif
+
 }  // namespace revo
 
 extern "C" int32_t revo_probe_mfma(const void* src_bf16, int64_t n_elems, float* sink, int32_t blocks, int32_t iters, void* stream) {
@@ -75,3 +137,30 @@ extern "C" int32_t revo_probe_copy(void* dst, const void* src, int64_t bytes, vo
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+#ifdef REVO_EXPERIMENTS
+// mode 0: one launch with `iters` stages separated by grid barriers (2 per stage); mode 1: 2 x iters launches (write / read).
+// ctr_err: 2 words (zeroed here), stamps: 2 x iters 100-MHz clock words of workgroup 0 around each first barrier, or null
+extern "C" int32_t revo_probe_gridbar(int32_t mode, void* ctr_err, void* buf, int32_t n16, int32_t blocks, int32_t threads,
+                                      int32_t iters, float* sink, void* stamps, void* stream) {
+    REVO_REQUIRE(ctr_err && buf && sink && n16 >= 1 && blocks >= 2 && blocks <= 512 && iters >= 1, "probe_gridbar: bad arguments");
+    REVO_REQUIRE(threads == 256 || threads == 512, "probe_gridbar: 256 or 512 threads");
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) {
+        int dev = 0, cus = 0;
+        REVO_HIP_CHECK(hipGetDevice(&dev));
+        REVO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        REVO_REQUIRE(blocks <= cus * (threads == 256 ? 2 : 1), "probe_gridbar: the grid must be co-resident");
+        REVO_HIP_CHECK(hipMemsetAsync(ctr_err, 0, 8, st));
+        hipLaunchKernelGGL(revo::probe_gridbar_kernel, dim3(blocks), dim3(threads), 0, st, (unsigned*)ctr_err, (unsigned*)ctr_err + 1,
+                           (float4*)buf, n16, iters, sink, (unsigned long long*)stamps);
+    } else {
+        for (int it = 0; it < iters; ++it) {
+            hipLaunchKernelGGL(revo::probe_chain_kernel, dim3(blocks), dim3(threads), 0, st, (float4*)buf, n16, it, sink, 0);
+            hipLaunchKernelGGL(revo::probe_chain_kernel, dim3(blocks), dim3(threads), 0, st, (float4*)buf, n16, it, sink, 1);
+        }
+    }
+    REVO_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+#endif
