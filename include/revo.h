@@ -292,9 +292,9 @@ int64_t revo_debug_read_workspace(revo_gallery* g, int64_t offset, int64_t bytes
  * bound exchanged between the shards before the scan; the caller guarantees each is <= the query's true ksel-th score. */
 int32_t revo_debug_seed_bounds(revo_gallery* g, const uint32_t* bounds);
 /* experiment (scripts/gridbar_probe.py): `iters` stages of "every workgroup writes n16 x 16 bytes, a device-wide
- * synchronisation, every workgroup reads another XCD's slice", as ONE launch with grid barriers (mode 0; the grid must be
+ * synchronisation, every workgroup reads another XCD's slice", as ONE launch with grid barriers (mode 0: a counter, mode 2: a flag word per workgroup, mode 3: XCD-hierarchical counters; the grid must be
  * co-resident; the spin is bounded: ctr_err[1] != 0 afterwards = timed out (1) or read stale data (2)) or as 2 x iters launches
- * (mode 1).  ctr_err: 2 device words; stamps: 2 x iters uint64 (100-MHz clock of workgroup 0 around each barrier) or NULL. */
+ * (mode 1).  ctr_err: 1696 device words; stamps: 2 x iters uint64 (100-MHz clock of workgroup 0 around each barrier) or NULL. */
 int32_t revo_probe_gridbar(int32_t mode, void* ctr_err, void* buf, int32_t n16, int32_t blocks, int32_t threads,
                            int32_t iters, float* sink, void* stamps, void* stream);
 /* counters of the fused scan when debug bit 14 is set */

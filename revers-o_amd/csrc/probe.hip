@@ -76,6 +76,59 @@ __device__ __forceinline__ bool probe_grid_barrier(unsigned* ctr, unsigned targe
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return true;
 }
+// the same synchronisation without read-modify-writes: every workgroup publishes the stage number in its own word of a
+// packed flag array, wave 0 of every workgroup polls all of the words (nb / 64 loads per lane per poll)
+__device__ __forceinline__ void probe_flag_barrier(unsigned* flags, unsigned stage, int nb, unsigned* err) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) {
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            __hip_atomic_store(flags + blockIdx.x, stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            bool ok = true;
+            for (int j = lane; j < nb; j += 64) ok = ok && (__hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= stage);
+            if (__all(ok)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 500000ull) { if (lane == 0) *err = 1u; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+// XCD-hierarchical form: the workgroups of one XCD arrive at that XCD's counter; the one that arrives last writes the XCD's L2
+// back ONCE (release), arrives at the top counter, waits for all XCDs, and publishes the stage in the XCD's generation word;
+// the others poll that word and invalidate their own CU's L1.  bar: [0] top counter, [32 x (1 + x)] counter of XCD x,
+// [32 x (9 + x)] generation of XCD x, [32 x (17 + x)] census of XCD x (workgroups counted by the first, flat barrier).
+__device__ __forceinline__ int probe_xcc_id() { return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u); }
+__device__ __forceinline__ void probe_xcd_barrier(unsigned* bar, unsigned stage, int xcc, unsigned n_local, unsigned n_xcc, unsigned* err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned prev = __hip_atomic_fetch_add(bar + 32 * (1 + xcc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1 == stage * n_local) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < stage * n_xcc) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 500000ull) { *err = 1u; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(bar + 32 * (9 + xcc), stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(bar + 32 * (9 + xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < stage) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 500000ull) { *err = 1u; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
 __device__ __forceinline__ float probe_stage(float4* buf, int n16, int it, int bid, int nb) {
     float4* mine = buf + (size_t)bid * n16;
     for (int i = threadIdx.x; i < n16; i += blockDim.x) mine[i] = (float4){(float)(it + bid), 1.f, 2.f, (float)i};
@@ -87,15 +140,28 @@ __device__ __forceinline__ float probe_read(const float4* buf, int n16, int bid,
     for (int i = threadIdx.x; i < n16; i += blockDim.x) s += other[i].x;
     return s;
 }
+template <int FLAGS>
 __global__ __launch_bounds__(512) void probe_gridbar_kernel(unsigned* ctr, unsigned* err, float4* buf, int n16, int iters,
                                                              float* sink, unsigned long long* stamps) {
     const int bid = blockIdx.x, nb = gridDim.x;
     float s = 0.f;
     int bad = 0;
+    int xcc = 0;
+    unsigned n_local = 0, n_xcc = 0;
+    if (FLAGS == 2) {
+        // census: who shares my XCD (one flat barrier per launch)
+        xcc = probe_xcc_id();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr + 640 + 32 * (17 + xcc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        probe_grid_barrier(ctr, (unsigned)nb, err);
+        n_local = __hip_atomic_load(ctr + 640 + 32 * (17 + xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int x = 0; x < 16; ++x) n_xcc += __hip_atomic_load(ctr + 640 + 32 * (17 + x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+    }
     for (int it = 0; it < iters; ++it) {
         probe_stage(buf, n16, it, bid, nb);
         if (stamps && threadIdx.x == 0 && bid == 0) stamps[2 * it] = __builtin_amdgcn_s_memrealtime();
-        probe_grid_barrier(ctr, (unsigned)(it * 2 + 1) * nb, err);
+        if (FLAGS == 2) probe_xcd_barrier(ctr + 640, (unsigned)(it * 2 + 1), xcc, n_local, n_xcc, err);
+        else if (FLAGS) probe_flag_barrier(ctr + 64, (unsigned)(it * 2 + 1), nb, err);
+        else probe_grid_barrier(ctr, (unsigned)(it * 2 + 1) * nb, err);
         if (stamps && threadIdx.x == 0 && bid == 0) stamps[2 * it + 1] = __builtin_amdgcn_s_memrealtime();
         const float r = probe_read(buf, n16, bid, nb);
         // every lane checks what it read: the neighbour's stage-`it` values
@@ -104,7 +170,9 @@ __global__ __launch_bounds__(512) void probe_gridbar_kernel(unsigned* ctr, unsig
         for (int i = threadIdx.x; i < n16; i += blockDim.x) ++cnt;
         if (r != want * (float)cnt) bad = 1;
         s += r;
-        probe_grid_barrier(ctr, (unsigned)(it * 2 + 2) * nb, err);      // the slice is rewritten by the next stage
+        if (FLAGS == 2) probe_xcd_barrier(ctr + 640, (unsigned)(it * 2 + 2), xcc, n_local, n_xcc, err);
+        else if (FLAGS) probe_flag_barrier(ctr + 64, (unsigned)(it * 2 + 2), nb, err);      // the slice is rewritten by the next stage
+        else probe_grid_barrier(ctr, (unsigned)(it * 2 + 2) * nb, err);
     }
     if (bad) *err = 2u;
     sink[bid * blockDim.x + threadIdx.x] = s;
@@ -139,21 +207,29 @@ extern "C" int32_t revo_probe_copy(void* dst, const void* src, int64_t bytes, vo
 }
 
 #ifdef REVO_EXPERIMENTS
-// mode 0: one launch with `iters` stages separated by grid barriers (2 per stage); mode 1: 2 x iters launches (write / read).
-// ctr_err: 2 words (zeroed here), stamps: 2 x iters 100-MHz clock words of workgroup 0 around each first barrier, or null
+// mode 0: one launch with `iters` stages separated by grid barriers (2 per stage; a counter), mode 2: the same with a flag word
+// per workgroup instead of the counter, mode 3: XCD-hierarchical counters; mode 1: 2 x iters launches (write / read).
+// ctr_err: 2 words + 62 unused + 512 flag words + 64 unused + 33 x 32 words of the hierarchical form (zeroed here), stamps: 2 x iters 100-MHz clock words of workgroup 0 around each first barrier, or null
 extern "C" int32_t revo_probe_gridbar(int32_t mode, void* ctr_err, void* buf, int32_t n16, int32_t blocks, int32_t threads,
                                       int32_t iters, float* sink, void* stamps, void* stream) {
     REVO_REQUIRE(ctr_err && buf && sink && n16 >= 1 && blocks >= 2 && blocks <= 512 && iters >= 1, "probe_gridbar: bad arguments");
     REVO_REQUIRE(threads == 256 || threads == 512, "probe_gridbar: 256 or 512 threads");
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 0) {
+    if (mode == 0 || mode == 2 || mode == 3) {
         int dev = 0, cus = 0;
         REVO_HIP_CHECK(hipGetDevice(&dev));
         REVO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         REVO_REQUIRE(blocks <= cus * (threads == 256 ? 2 : 1), "probe_gridbar: the grid must be co-resident");
-        REVO_HIP_CHECK(hipMemsetAsync(ctr_err, 0, 8, st));
-        hipLaunchKernelGGL(revo::probe_gridbar_kernel, dim3(blocks), dim3(threads), 0, st, (unsigned*)ctr_err, (unsigned*)ctr_err + 1,
-                           (float4*)buf, n16, iters, sink, (unsigned long long*)stamps);
+        REVO_HIP_CHECK(hipMemsetAsync(ctr_err, 0, (640 + 33 * 32) * 4, st));
+        if (mode == 0)
+            hipLaunchKernelGGL(revo::probe_gridbar_kernel<0>, dim3(blocks), dim3(threads), 0, st, (unsigned*)ctr_err, (unsigned*)ctr_err + 1,
+                               (float4*)buf, n16, iters, sink, (unsigned long long*)stamps);
+        else if (mode == 3)
+            hipLaunchKernelGGL(revo::probe_gridbar_kernel<2>, dim3(blocks), dim3(threads), 0, st, (unsigned*)ctr_err, (unsigned*)ctr_err + 1,
+                               (float4*)buf, n16, iters, sink, (unsigned long long*)stamps);
+        else
+            hipLaunchKernelGGL(revo::probe_gridbar_kernel<1>, dim3(blocks), dim3(threads), 0, st, (unsigned*)ctr_err, (unsigned*)ctr_err + 1,
+                               (float4*)buf, n16, iters, sink, (unsigned long long*)stamps);
     } else {
         for (int it = 0; it < iters; ++it) {
             hipLaunchKernelGGL(revo::probe_chain_kernel, dim3(blocks), dim3(threads), 0, st, (float4*)buf, n16, it, sink, 0);
