@@ -57,12 +57,15 @@ __device__ __forceinline__ void g256_operand_init(G256Operand& op, const bf16_t*
 }
 
 // one half-tile (128 rows x 64 k): two 16-byte-per-lane DMA instructions per thread
+// AUX: the loads' cache policy (0 = default; 2 = non-temporal: bytes that ONE workgroup reads ONCE -- the gallery stream of a
+// scan with a single query tile, topk256.hip; never operands that other workgroups re-read from L2)
+template <int AUX = 0>
 __device__ __forceinline__ void g256_issue_half(const G256Operand& op, int half, int kbyte, char* region, int wave) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         char* dst = region + half * 16384 + i * 8192 + wave * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(op.rsrc[half * 2 + i], (__attribute__((address_space(3))) void*)dst, 16,
-                                                 op.voff, kbyte, 0, 0);
+                                                 op.voff, kbyte, 0, AUX);
     }
 }
 
@@ -142,24 +145,26 @@ __device__ __forceinline__ void g256_cluster1(const bf16x8 (&a)[4][2], const bf1
 // DMA for the first 1.5 K-tiles of an output tile (tile 0 complete, A of tile 1).  May be
 // issued while the previous output tile's epilogue is still running: the LDS image is free
 // once gemm256_mainloop has returned (it ends with a barrier behind every wave's last read).
+template <int BAUX = 0>
 __device__ __forceinline__ void g256_issue_prologue(const G256Operand& A, const G256Operand& B, char* smem, int K,
                                                     int wave) {
     g256_issue_half(A, 0, 0, G256_A(smem, 0), wave);
     g256_issue_half(A, 1, 0, G256_A(smem, 0), wave);
-    g256_issue_half(B, 0, 0, G256_B(smem, 0), wave);
-    g256_issue_half(B, 1, 0, G256_B(smem, 0), wave);
+    g256_issue_half<BAUX>(B, 0, 0, G256_B(smem, 0), wave);
+    g256_issue_half<BAUX>(B, 1, 0, G256_B(smem, 0), wave);
     if (K > 64) {
         g256_issue_half(A, 0, 128, G256_A(smem, 1), wave);
         g256_issue_half(A, 1, 128, G256_A(smem, 1), wave);
     }
 }
 // for gemm256_mainloop<ROWS, RT, DEEP = true>: the first TWO K-tiles complete
+template <int BAUX = 0>
 __device__ __forceinline__ void g256_issue_prologue_deep(const G256Operand& A, const G256Operand& B, char* smem, int K,
                                                          int wave) {
-    g256_issue_prologue(A, B, smem, K, wave);
+    g256_issue_prologue<BAUX>(A, B, smem, K, wave);
     if (K > 64) {
-        g256_issue_half(B, 0, 128, G256_B(smem, 1), wave);
-        g256_issue_half(B, 1, 128, G256_B(smem, 1), wave);
+        g256_issue_half<BAUX>(B, 0, 128, G256_B(smem, 1), wave);
+        g256_issue_half<BAUX>(B, 1, 128, G256_B(smem, 1), wave);
     }
 }
 
@@ -193,7 +198,7 @@ __device__ __forceinline__ void g256_issue_prologue_deep(const G256Operand& A, c
 // must then skip its B requests and count differently: with those run-time tests of t == 0 hipcc peeled the first trip,
 // parked an accumulator in scratch around it and reloaded it behind an s_waitcnt vmcnt(0) -- once per output tile, a
 // drain of the DMA queue where this mode is meant to remove one.)  Needs K >= 128.
-template <int ROWS = 0, bool RT = false, bool DEEP = false, int QS = 0>
+template <int ROWS = 0, bool RT = false, bool DEEP = false, int QS = 0, int BAUX = 0>
 __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G256Operand& B, char* smem, int K,
                                                  int wave, int lane, f32x4 (&acc)[8][4], bool tall = false,
                                                  bool rt_lo = true, bool rt_hi = true) {
@@ -231,13 +236,13 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             // P0
             G256_HI(g256_read_a<64, 0>(f.ahi, ad.a););
             G256_HT(g256_read_a1<64, 0>(f.ahi, ad.a););
-            if (!DEEP && n1) g256_issue_half(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
+            if (!DEEP && n1) g256_issue_half<BAUX>(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_LO(g256_cluster<0, 0>(f.alo, f.blo, acc););
             G256_FENCE();
             // P1
             G256_LO(g256_read_b<32, 0>(f.bhi, ad.b););
-            if (!DEEP && n1) g256_issue_half(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
+            if (!DEEP && n1) g256_issue_half<BAUX>(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
             G256_HT(g256_cluster1<4, 0>(f.ahi, f.blo, acc););
@@ -246,14 +251,14 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (n2) g256_issue_half(A, 0, (t + 2) * 128, G256_A(smem, 0), wave);
-            if (DEEP && n2) g256_issue_half(B, 0, (t + 2) * 128, G256_B(smem, 0), wave);
+            if (DEEP && n2) g256_issue_half<BAUX>(B, 0, (t + 2) * 128, G256_B(smem, 0), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 2>(f.ahi, f.bhi, acc););
             G256_HT(g256_cluster1<4, 2>(f.ahi, f.bhi, acc););
             G256_FENCE();
             // P3: publish tile t+1, start reading it
             if (n2) g256_issue_half(A, 1, (t + 2) * 128, G256_A(smem, 0), wave);
-            if (DEEP && n2) g256_issue_half(B, 1, (t + 2) * 128, G256_B(smem, 0), wave);
+            if (DEEP && n2) g256_issue_half<BAUX>(B, 1, (t + 2) * 128, G256_B(smem, 0), wave);
             if (n1) {
                 if (n2) { if (DEEP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -272,14 +277,14 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             const bool n1 = u + 1 < nt, n2 = u + 2 < nt;
             // P0'
             G256_LO(g256_read_a<0, 1>(f.alo, ad.a););
-            if (!DEEP && n1) g256_issue_half(B, 0, (u + 1) * 128, G256_B(smem, 0), wave);
+            if (!DEEP && n1) g256_issue_half<BAUX>(B, 0, (u + 1) * 128, G256_B(smem, 0), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
             G256_HT(g256_cluster1<4, 0>(f.ahi, f.blo, acc););
             G256_FENCE();
             // P1'
             G256_LO(g256_read_b<32, 1>(f.bhi, ad.b););
-            if (!DEEP && n1) g256_issue_half(B, 1, (u + 1) * 128, G256_B(smem, 0), wave);
+            if (!DEEP && n1) g256_issue_half<BAUX>(B, 1, (u + 1) * 128, G256_B(smem, 0), wave);
             G256_FENCE();
             G256_LO(g256_cluster<0, 0>(f.alo, f.blo, acc););
             G256_FENCE();
@@ -287,13 +292,13 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (n2) g256_issue_half(A, 0, (u + 2) * 128, G256_A(smem, 1), wave);
-            if (DEEP && n2) g256_issue_half(B, 0, (u + 2) * 128, G256_B(smem, 1), wave);
+            if (DEEP && n2) g256_issue_half<BAUX>(B, 0, (u + 2) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_LO(g256_cluster<0, 2>(f.alo, f.bhi, acc););
             G256_FENCE();
             // P3'
             if (n2) g256_issue_half(A, 1, (u + 2) * 128, G256_A(smem, 1), wave);
-            if (DEEP && n2) g256_issue_half(B, 1, (u + 2) * 128, G256_B(smem, 1), wave);
+            if (DEEP && n2) g256_issue_half<BAUX>(B, 1, (u + 2) * 128, G256_B(smem, 1), wave);
             if (n1) {
                 if (n2) { if (DEEP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -314,13 +319,13 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             // P0
             G256_HI(g256_read_a<64, 0>(f.ahi, ad.a););
             G256_HT(g256_read_a1<64, 0>(f.ahi, ad.a););
-            if (!DEEP && n1) g256_issue_half(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
+            if (!DEEP && n1) g256_issue_half<BAUX>(B, 0, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_LO(g256_cluster<0, 0>(f.alo, f.blo, acc););
             G256_FENCE();
             // P1
             G256_LO(g256_read_b<32, 0>(f.bhi, ad.b););
-            if (!DEEP && n1) g256_issue_half(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
+            if (!DEEP && n1) g256_issue_half<BAUX>(B, 1, (t + 1) * 128, G256_B(smem, 1), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 0>(f.ahi, f.blo, acc););
             G256_HT(g256_cluster1<4, 0>(f.ahi, f.blo, acc););
@@ -329,14 +334,14 @@ __device__ __forceinline__ void gemm256_mainloop(const G256Operand& A, const G25
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (n2) g256_issue_half(A, 0, (t + 2) * 128, G256_A(smem, 0), wave);
-            if (DEEP && n2) g256_issue_half(B, 0, (t + 2) * 128, G256_B(smem, 0), wave);
+            if (DEEP && n2) g256_issue_half<BAUX>(B, 0, (t + 2) * 128, G256_B(smem, 0), wave);
             G256_FENCE();
             G256_HI(g256_cluster<4, 2>(f.ahi, f.bhi, acc););
             G256_HT(g256_cluster1<4, 2>(f.ahi, f.bhi, acc););
             G256_FENCE();
             // P3: publish tile t+1, start reading it
             if (n2) g256_issue_half(A, 1, (t + 2) * 128, G256_A(smem, 0), wave);
-            if (DEEP && n2) g256_issue_half(B, 1, (t + 2) * 128, G256_B(smem, 0), wave);
+            if (DEEP && n2) g256_issue_half<BAUX>(B, 1, (t + 2) * 128, G256_B(smem, 0), wave);
             if (n1) {
                 if (n2) { if (DEEP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

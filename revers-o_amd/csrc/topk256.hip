@@ -381,6 +381,14 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     constexpr int SEG = 2 * KSEL;
     // up to 128 queries the loop runs at the HBM rate: operands are requested a K-tile and a half ahead (gemm256_core.h)
     constexpr bool DEEP = ROWS == 64 || ROWS == 128;
+    // ROWS != 0: the whole search is ONE query tile, so every gallery row is read by one workgroup, once: non-temporal DMA
+    // (measured, 1 M x 1024, whole search: 1 query 0.416-0.427 -> 0.400-0.401 ms, 64 queries 0.441-0.451 -> 0.427-0.431,
+    //  128 queries 0.521 -> 0.493-0.499; the bytes no longer push the queries, bounds and segments out of L2 / the Infinity Cache).
+    //  With several query tiles the workgroups of an XCD that hold the same slice re-read it from L2: default policy.
+#ifndef S256_ONE_TILE_AUX
+#define S256_ONE_TILE_AUX 2
+#endif
+    constexpr int BAUX = ROWS != 0 ? S256_ONE_TILE_AUX : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     S256Lds L;
     L.queue = (uint64_t*)(smem + G256_LDS);
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
     G256Operand A, B;
     g256_operand_init(A, p.Qb, p.ldq, p.Q, q0, wave, lane);
     g256_operand_init(B, p.Gb + row_begin * p.ldg, p.ldg, p.N - row_begin, 0, wave, lane);
-    if constexpr (DEEP) g256_issue_prologue_deep(A, B, smem, p.D, wave); else g256_issue_prologue(A, B, smem, p.D, wave);
+    if constexpr (DEEP) g256_issue_prologue_deep<BAUX>(A, B, smem, p.D, wave); else g256_issue_prologue<BAUX>(A, B, smem, p.D, wave);
     // Slices that start after others have run (later rounds of workgroups on this CU) begin with what those have
     // learnt, not with the pre-pass bound: one refresh while the first operands are in flight.  (Without it every
     // slice's first tile admitted about one score per row: at 24 tiles per slice a third of all slow fragments.)
@@ -485,12 +493,12 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
                 for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             // few queries: most of the tile's MFMA work would multiply zero rows (separate kernel
             // instantiations: inside one kernel a second main loop costs the main path its register allocation)
-            gemm256_mainloop<ROWS, false, DEEP>(A, B, smem, p.D, wave, lane, acc);
+            gemm256_mainloop<ROWS, false, DEEP, 0, BAUX>(A, B, smem, p.D, wave, lane, acc);
 
             if (groups == 1 && t + 1 < t1) {
                 // next gallery tile: rebased descriptors (any gallery size), DMA in flight during the selection
                 g256_operand_init(B, p.Gb + (n0 + 256) * p.ldg, p.ldg, p.N - (n0 + 256), 0, wave, lane);
-                if constexpr (DEEP) g256_issue_prologue_deep(A, B, smem, p.D, wave); else g256_issue_prologue(A, B, smem, p.D, wave);
+                if constexpr (DEEP) g256_issue_prologue_deep<BAUX>(A, B, smem, p.D, wave); else g256_issue_prologue<BAUX>(A, B, smem, p.D, wave);
             }
             asm volatile("" : "+v"(lane) :: "memory");
             const int lr = lane & 15, lq = lane >> 4;
@@ -633,7 +641,7 @@ __global__ __launch_bounds__(G256_THREADS, 2) void topk_scan256_kernel(Scan256Ar
         if (t < t1) {
             const long nn = p.n_begin + (long)t * 256;
             g256_operand_init(B, p.Gb + nn * p.ldg, p.ldg, p.N - nn, 0, wave, lane);
-            if constexpr (DEEP) g256_issue_prologue_deep(A, B, smem, p.D, wave); else g256_issue_prologue(A, B, smem, p.D, wave);
+            if constexpr (DEEP) g256_issue_prologue_deep<BAUX>(A, B, smem, p.D, wave); else g256_issue_prologue<BAUX>(A, B, smem, p.D, wave);
         }
     }
     if (tid < qvalid) {
