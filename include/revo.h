@@ -304,6 +304,11 @@ int32_t revo_debug_scan_stats(int64_t* out8);
  * of the linear layer behind them) */
 int32_t revo_op_layernorm(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows,
                           int32_t width, void* out, int64_t ldo, int32_t out_is_bf16, void* stream);
+/* the attention pool's weighted row sums (K10; head.hip): u[(b * heads + h) * width + c] = sum_s softmax_s(logits[b, h, :])[s] *
+ * x[b * seq + s][c], all fp32; logits [batch, heads, seq].  A column's sum is taken in one fixed order whatever the batch
+ * (the batch only decides how many columns a lane carries): bit-identical between a batch and its images one at a time. */
+int32_t revo_op_pool_rows(const float* x, int64_t ldx, const float* logits, int32_t batch, int32_t seq, int32_t width,
+                          int32_t heads, float* u, void* stream);
 int32_t revo_op_rope(void* qkv_bf16, int64_t ld, const float* cos_sin, int32_t rows, int32_t seq, int32_t width,
                      int32_t heads, void* stream);
 int32_t revo_op_attention(const void* qkv_bf16, int64_t ld, void* out_bf16, int64_t ldo, int32_t batch, int32_t seq,

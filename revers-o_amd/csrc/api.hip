@@ -1416,6 +1416,13 @@ extern "C" int32_t revo_op_layernorm(const float* x, int64_t ldx, const float* w
     return revo::launch_layernorm(x, ldx, w, b, eps, rows, width, out, ldo, out_is_bf16, (hipStream_t)stream);
     API_END
 }
+extern "C" int32_t revo_op_pool_rows(const float* x, int64_t ldx, const float* logits, int32_t batch, int32_t seq, int32_t width,
+                                     int32_t heads, float* u, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(x && logits && u && batch >= 1 && seq >= 1 && width >= 4 && ldx >= width, "op_pool_rows: bad arguments");
+    return revo::launch_pool_head_rows(x, ldx, batch, seq, width, heads, logits, u, (hipStream_t)stream);
+    API_END
+}
 extern "C" int32_t revo_op_rope(void* qkv, int64_t ld, const float* cs, int32_t rows, int32_t seq, int32_t width,
                                 int32_t heads, void* stream) {
     API_BEGIN

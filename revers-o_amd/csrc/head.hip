@@ -47,18 +47,23 @@ constexpr int PL_MAXH = LN_MAXH;        // heads a thread of the accumulation ca
 
 // --------------------------------------------------------------- pooled rows ----
 // u[(b * H + h) * W + c] = sum_s softmax_s(logits[b, h, :])[s] * x[b * S + s][c]
-// grid (W / 64, B): a workgroup owns 64 columns of one image; its sixteen waves take the token rows s = w, w + 16, ...
-// (every element of x is read once, by one lane; eight rows in flight per lane -- with four waves and four rows one
-// image took 94 us), each thread carries all H heads; the partial sums meet in LDS in a fixed order.  The softmax of the
-// image's H x S logits is recomputed by every workgroup (a few thousand exps).
+// grid (W / (64 CPL), B): a workgroup owns 64 x CPL columns of one image; its sixteen waves take the token rows
+// s = w, w + 16, ... (every element of x is read once, by one lane; eight rows in flight per lane -- with four waves and four
+// rows one image took 94 us), each thread carries all H heads; the partial sums meet in LDS in a fixed order.  The softmax
+// of the image's H x S logits is recomputed by every workgroup (a few thousand exps).
+// CPL = columns per lane: 1 for a few images (B x W / 64 workgroups: one image keeps 16), 4 for a batch (16-byte loads, and
+// the H probabilities of a row -- LDS broadcasts -- are read once per FOUR elements: at batch 64 the one-column form spent its
+// time on them, 90 us for 151 MB).  A column's sum is taken in the same order either way: bit-identical results.
 constexpr int PA_WAVES = 16;
+constexpr int PA_HC = 4;          // heads per pass of the final reduction (LDS: PA_WAVES x PA_HC x 64 CPL floats)
+template <int CPL>
 __global__ __launch_bounds__(PA_WAVES * 64) void pool_accumulate_kernel(const float* __restrict__ x, long ldx,
                                                               const float* __restrict__ logits, int S, int W, int H,
                                                               float* __restrict__ u) {
-    extern __shared__ float psm[];                    // [H][S] probabilities, then [PA_WAVES][H][64] partial sums
-    float* red = psm + (long)H * S;
+    extern __shared__ float psm[];                    // [H][S] probabilities, then [PA_WAVES][PA_HC][64 CPL] partial sums
+    float* red = psm + (((long)H * S + 3) & ~3l);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b = blockIdx.y, c = blockIdx.x * 64 + lane;
+    const int b = blockIdx.y, c = (blockIdx.x * 64 + lane) * CPL;
     for (int h = w; h < H; h += PA_WAVES) {
         const float* lg = logits + ((long)b * H + h) * S;
         float m = -INFINITY;
@@ -75,49 +80,87 @@ __global__ __launch_bounds__(PA_WAVES * 64) void pool_accumulate_kernel(const fl
         for (int s = lane; s < S; s += 64) psm[(long)h * S + s] *= inv;
     }
     __syncthreads();
-    float acc[PL_MAXH];
-#pragma unroll
-    for (int h = 0; h < PL_MAXH; ++h) acc[h] = 0.f;
-    if (c < W) {
-        const float* xc = x + (long)b * S * ldx + c;
-        int s = w;
-        for (; s + 7 * PA_WAVES < S; s += 8 * PA_WAVES) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = xc[(long)(s + u * PA_WAVES) * ldx];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int h = 0; h < PL_MAXH; ++h)
-                    if (h < H) acc[h] = fmaf(psm[(long)h * S + s + u * PA_WAVES], v[u], acc[h]);
-        }
-        for (; s < S; s += PA_WAVES) {
-            const float v = xc[(long)s * ldx];
-#pragma unroll
-            for (int h = 0; h < PL_MAXH; ++h)
-                if (h < H) acc[h] = fmaf(psm[(long)h * S + s], v, acc[h]);
-        }
-    }
+    float acc[PL_MAXH][CPL];
 #pragma unroll
     for (int h = 0; h < PL_MAXH; ++h)
-        if (h < H) red[((long)w * H + h) * 64 + lane] = acc[h];
-    __syncthreads();
-    if (c < W)
-        for (int h = w; h < H; h += PA_WAVES) {
-            float t = red[((long)0 * H + h) * 64 + lane];
 #pragma unroll
-            for (int o = 1; o < PA_WAVES; ++o) t += red[((long)o * H + h) * 64 + lane];
-            u[((long)b * H + h) * W + c] = t;
+        for (int j = 0; j < CPL; ++j) acc[h][j] = 0.f;
+    if (c < W) {
+        const float* xc = x + (long)b * S * ldx + c;
+        auto load = [&](int s, float (&v)[CPL]) {
+            if constexpr (CPL == 4) {
+                const f32x4 t = *(const f32x4*)(xc + (long)s * ldx);
+                v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+            } else {
+                v[0] = xc[(long)s * ldx];
+            }
+        };
+        int s = w;
+        for (; s + 7 * PA_WAVES < S; s += 8 * PA_WAVES) {
+            float v[8][CPL];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) load(s + r * PA_WAVES, v[r]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int h = 0; h < PL_MAXH; ++h)
+                    if (h < H) {
+                        const float pr = psm[(long)h * S + s + r * PA_WAVES];
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) acc[h][j] = fmaf(pr, v[r][j], acc[h][j]);
+                    }
         }
+        for (; s < S; s += PA_WAVES) {
+            float v[CPL];
+            load(s, v);
+#pragma unroll
+            for (int h = 0; h < PL_MAXH; ++h)
+                if (h < H) {
+                    const float pr = psm[(long)h * S + s];
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) acc[h][j] = fmaf(pr, v[j], acc[h][j]);
+                }
+        }
+    }
+    // the sixteen waves' partial sums, PA_HC heads at a time: thread t adds column t % (64 CPL) of head h0 + t / (64 CPL) ... in wave order
+    constexpr int NC = 64 * CPL;
+#pragma unroll
+    for (int h0 = 0; h0 < PL_MAXH; h0 += PA_HC) {
+        if (h0 >= H) break;
+        if (h0) __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < PA_HC; ++hh)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) red[((long)w * PA_HC + hh) * NC + lane * CPL + j] = acc[h0 + hh][j];
+        __syncthreads();
+        for (int t = threadIdx.x; t < PA_HC * NC; t += PA_WAVES * 64) {
+            const int hh = t / NC, cc = t - hh * NC;
+            const int col = blockIdx.x * NC + cc;
+            if (h0 + hh < H && col < W) {
+                float sum = red[((long)0 * PA_HC + hh) * NC + cc];
+#pragma unroll
+                for (int o = 1; o < PA_WAVES; ++o) sum += red[((long)o * PA_HC + hh) * NC + cc];
+                u[((long)b * H + h0 + hh) * W + col] = sum;
+            }
+        }
+    }
 }
 int launch_pool_head_rows(const float* x, long ldx, int B, int S, int W, int H, const float* logits, float* u, hipStream_t st) {
     REVO_REQUIRE(H >= 1 && H <= PL_MAXH && W % 4 == 0 && ldx % 4 == 0, "pool head: at most 16 heads, width a multiple of 4");
     const long rows = (long)B * S;
     if (rows <= 0) return 0;
-    const size_t lds = ((size_t)H * S + PA_WAVES * (size_t)H * 64) * 4;
+    // a batch: four columns per lane once that still gives most CUs a workgroup
+    const bool wide = (long)B * ((W + 255) / 256) >= 192;
+    const int cpl = wide ? 4 : 1;
+    const size_t lds = ((((size_t)H * S + 3) & ~(size_t)3) + PA_WAVES * (size_t)PA_HC * 64 * cpl) * 4;
     REVO_REQUIRE(lds <= 160 * 1024, "pool head: sequence too long for the probability table in LDS");
-    REVO_FUNC_LDS(pool_accumulate_kernel, (int)lds);
-    hipLaunchKernelGGL(pool_accumulate_kernel, dim3((W + 63) / 64, B), dim3(PA_WAVES * 64), lds, st, x, ldx, logits, S, W, H, u);
+    if (wide) {
+        REVO_FUNC_LDS(pool_accumulate_kernel<4>, (int)lds);
+        hipLaunchKernelGGL(pool_accumulate_kernel<4>, dim3((W + 255) / 256, B), dim3(PA_WAVES * 64), lds, st, x, ldx, logits, S, W, H, u);
+    } else {
+        REVO_FUNC_LDS(pool_accumulate_kernel<1>, (int)lds);
+        hipLaunchKernelGGL(pool_accumulate_kernel<1>, dim3((W + 63) / 64, B), dim3(PA_WAVES * 64), lds, st, x, ldx, logits, S, W, H, u);
+    }
     REVO_HIP_CHECK(hipGetLastError());
     return 0;
 }

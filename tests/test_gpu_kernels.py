@@ -125,6 +125,28 @@ def test_layernorm(lib, dev, W, out_bf16):
     assert (out.float() - ref).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("B,S,W,H", [(64, 577, 1024, 8), (48, 197, 768, 8), (5, 577, 1024, 8), (32, 1025, 1536, 8), (200, 17, 192, 3)])
+def test_pool_rows_equal_the_softmax_weighted_sum_and_do_not_depend_on_the_batch(lib, dev, B, S, W, H):
+    """K10's weighted row sums (head.hip pool_accumulate_kernel) against fp64 softmax-weighted sums, in both forms -- a batch
+    (four columns per lane) and a few images (one column per lane): the same column sums, bit for bit."""
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + S)
+    x = torch.randn(B * S, W, generator=g).to(dev)
+    logits = (torch.randn(B, H, S, generator=g) * 2).to(dev)
+    u = torch.zeros(B, H, W, device=dev)
+    _lib.check(lib.revo_op_pool_rows(_lib.ptr(x), W, _lib.ptr(logits), B, S, W, H, _lib.ptr(u), _lib.current_stream()))
+    torch.cuda.synchronize()
+    p = torch.softmax(logits.double(), dim=-1)
+    ref = torch.einsum("bhs,bsw->bhw", p, x.double().view(B, S, W))
+    assert (u.double() - ref).abs().max().item() <= 2e-5
+    # image by image: the narrow form (few workgroups per image)
+    for b in (0, B - 1):
+        u1 = torch.zeros(1, H, W, device=dev)
+        _lib.check(lib.revo_op_pool_rows(_lib.ptr(x[b * S:(b + 1) * S]), W, _lib.ptr(logits[b:b + 1].contiguous()), 1, S, W, H,
+                                         _lib.ptr(u1), _lib.current_stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(u1[0], u[b]), b
+
+
 def test_layernorm_constant_row_is_bias(lib, dev):
     W = 1024
     x = torch.full((4, W), 3.25, device=dev)
