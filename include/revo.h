@@ -304,6 +304,12 @@ int32_t revo_debug_scan_stats(int64_t* out8);
  * of the linear layer behind them) */
 int32_t revo_op_layernorm(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows,
                           int32_t width, void* out, int64_t ldo, int32_t out_is_bf16, void* stream);
+/* ln_post with the attention pool's logits out of the same pass (K9 + K10's scores): out = LayerNorm(x) in fp32 and
+ * logits[(r / seq * heads + h) * seq + r % seq] = out[r] . qk[h] + ck[h] (qk [heads, width], ck [heads]; rows % seq == 0).
+ * A row's results do not depend on how many rows the call has (a batch takes four rows per wave): same bits. */
+int32_t revo_op_layernorm_logits(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows,
+                                 int32_t width, float* out, int64_t ldo, const float* qk, const float* ck, int32_t heads,
+                                 int32_t seq, float* logits, void* stream);
 /* the attention pool's weighted row sums (K10; head.hip): u[(b * heads + h) * width + c] = sum_s softmax_s(logits[b, h, :])[s] *
  * x[b * seq + s][c], all fp32; logits [batch, heads, seq].  A column's sum is taken in one fixed order whatever the batch
  * (the batch only decides how many columns a lane carries): bit-identical between a batch and its images one at a time. */

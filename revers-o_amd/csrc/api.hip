@@ -1416,6 +1416,15 @@ extern "C" int32_t revo_op_layernorm(const float* x, int64_t ldx, const float* w
     return revo::launch_layernorm(x, ldx, w, b, eps, rows, width, out, ldo, out_is_bf16, (hipStream_t)stream);
     API_END
 }
+extern "C" int32_t revo_op_layernorm_logits(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows,
+                                            int32_t width, float* out, int64_t ldo, const float* qk, const float* ck,
+                                            int32_t heads, int32_t seq, float* logits, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(x && out && qk && ck && logits && rows >= 1 && seq >= 1 && rows % seq == 0, "op_layernorm_logits: bad arguments");
+    const revo::LnLogits lg{qk, ck, logits, heads, seq};
+    return revo::launch_layernorm(x, ldx, w, b, eps, rows, width, out, ldo, 0, (hipStream_t)stream, &lg);
+    API_END
+}
 extern "C" int32_t revo_op_pool_rows(const float* x, int64_t ldx, const float* logits, int32_t batch, int32_t seq, int32_t width,
                                      int32_t heads, float* u, void* stream) {
     API_BEGIN

@@ -35,6 +35,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// N sums at once (N a power of two <= 32): lane l returns the wave's total of value idx -- with the addition tree of wave_sum,
+// so the same bits -- where idx = bit 5 of l + 2 x bit 4 + 4 x bit 3 ... (one index bit per halving); lanes that differ only in
+// the bits below the last halving hold the same value.  N - 1 + log2(64 / N) shuffles instead of 6 N.
+template <int N>
+__device__ __forceinline__ float wave_sum_transposed(float (&v)[N], int lane, int& idx) {
+    static_assert(N >= 2 && N <= 32 && (N & (N - 1)) == 0, "a power of two, at most 32");
+    idx = 0;
+    int bit = 32, mul = 1;
+#pragma unroll
+    for (int n = N; n > 1; n >>= 1) {
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int i = 0; i < n / 2; ++i) {
+            const float keep = up ? v[2 * i + 1] : v[2 * i];
+            const float send = up ? v[2 * i] : v[2 * i + 1];
+            v[i] = keep + __shfl_xor(send, bit, 64);
+        }
+        idx += up ? mul : 0;
+        mul <<= 1;
+        bit >>= 1;
+    }
+#pragma unroll
+    for (; bit > 0; bit >>= 1) v[0] += __shfl_xor(v[0], bit, 64);
+    return v[0];
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

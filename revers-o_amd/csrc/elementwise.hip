@@ -92,6 +92,130 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// ln_post with the pool logits for a BATCH: R rows per wave.  The logits read H probe-key vectors against every row -- in
+// the one-row form 128 sixteen-byte loads per lane and row, 128 KB per row through the CU's vector L1 (64 bytes a cycle):
+// at batch 64 that, not the 302 MB the kernel moves, set its time (110 us).  Here a wave holds R rows in registers and
+// every key chunk it loads serves all of them (HM = heads compiled in).  Per row the arithmetic and its order are the one-row
+// kernel's: same bits.
+template <int MAXC, int R, int HM>
+__global__ __launch_bounds__(256) void layernorm_logits_kernel(const float* __restrict__ x, long ldx,
+                                                               const float* __restrict__ w, const float* __restrict__ b,
+                                                               float eps, int rows, int W, float* __restrict__ out, long ldo,
+                                                               LnLogits lg) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    const int nchunk = W >> 2;
+    f32x4 v[R][MAXC];
+    float mean[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r < rows ? row0 + r : rows - 1;            // (a wave's rows past the end repeat the last one; not stored)
+        const float* xr = x + (long)row * ldx;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            v[r][i] = c < nchunk ? *(const f32x4*)(xr + c * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // the rows' statistics: R sums in one transposing butterfly, handed back to every lane through scalar registers
+    // (lane of sum r: index bit k of r is lane bit 5 - k)
+    auto all_rows = [&](float (&part)[R], float (&tot)[R]) {
+        int ix;
+        const float t = wave_sum_transposed<R>(part, lane, ix);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int src = 0;
+#pragma unroll
+            for (int k = 0; (1 << k) < R; ++k) src |= ((r >> k) & 1) << (5 - k);
+            tot[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), src));
+        }
+    };
+    {
+        float part[R], tot[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nchunk) s += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
+            }
+            part[r] = s;
+        }
+        all_rows(part, tot);
+#pragma unroll
+        for (int r = 0; r < R; ++r) mean[r] = tot[r] / (float)W;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nchunk) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = v[r][i][j] - mean[r];
+                        q = fmaf(d, d, q);
+                    }
+                }
+            }
+            part[r] = q;
+        }
+        all_rows(part, tot);
+#pragma unroll
+        for (int r = 0; r < R; ++r) rstd[r] = rsqrtf(tot[r] / (float)W + eps);
+    }
+    float lacc[R][HM];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int h = 0; h < HM; ++h) lacc[r][h] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            const f32x4 g = w ? *(const f32x4*)(w + c * 4) : (f32x4){1.f, 1.f, 1.f, 1.f};
+            const f32x4 be = b ? *(const f32x4*)(b + c * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 y[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[r][j] = fmaf((v[r][i][j] - mean[r]) * rstd[r], g[j], be[j]);
+                if (row0 + r < rows) *(f32x4*)(out + (long)(row0 + r) * ldo + c * 4) = y[r];
+            }
+#pragma unroll
+            for (int h = 0; h < HM; ++h)
+                if (h < lg.H) {
+                    const f32x4 k4 = *(const f32x4*)(lg.qk + (long)h * W + c * 4);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        lacc[r][h] = fmaf(y[r][0], k4[0], lacc[r][h]);
+                        lacc[r][h] = fmaf(y[r][1], k4[1], lacc[r][h]);
+                        lacc[r][h] = fmaf(y[r][2], k4[2], lacc[r][h]);
+                        lacc[r][h] = fmaf(y[r][3], k4[3], lacc[r][h]);
+                    }
+                }
+        }
+    }
+    // the R x HM sums of the wave in one transposing butterfly (common.h: wave_sum's addition tree, R x HM + 0 shuffles instead of
+    // 6 R x HM -- as R x HM full reductions they were a third of this kernel's time), one store instruction for all of them
+    static_assert(R * HM <= 32, "");
+    float flat[R * HM];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int h = 0; h < HM; ++h) flat[r * HM + h] = lacc[r][h];
+    int idx;
+    const float t = wave_sum_transposed<R * HM>(flat, lane, idx);
+    constexpr int SAME = 64 / (R * HM);            // lanes that hold the same sum
+    const int r = idx / HM, h = idx - r * HM;
+    if ((lane & (SAME - 1)) == 0 && h < lg.H && row0 + r < rows) {
+        const long bb = (row0 + r) / lg.S, ss = (row0 + r) - bb * lg.S;
+        lg.logits[(bb * lg.H + h) * lg.S + ss] = t + lg.ck[h];
+    }
+}
+
 // Same statistics, 8 consecutive elements per lane and step: two adjacent 16-byte loads and ONE 16-byte
 // bf16 store (8-byte stores run at 0.5-0.7x the 16-byte rate).  W % 8 == 0, bf16 output.
 template <int MAXG>
@@ -176,6 +300,15 @@ int launch_layernorm(const float* x, long ldx, const float* w, const float* b, f
         return 0;
     }
     const int chunks = (W / 4 + 63) / 64;
+    // ln_post of a batch: four rows per wave (the keys of the pool logits are loaded once for the four)
+    if (lg.qk && !out_is_bf16 && rows >= 4096 && lg.H <= 8 && chunks <= 6) {
+        dim3 grid4((rows + 15) / 16);
+        if (chunks <= 3) hipLaunchKernelGGL((layernorm_logits_kernel<3, 4, 8>), grid4, block, 0, st, x, ldx, w, b, eps, rows, W, (float*)out, ldo, lg);
+        else if (chunks <= 4) hipLaunchKernelGGL((layernorm_logits_kernel<4, 4, 8>), grid4, block, 0, st, x, ldx, w, b, eps, rows, W, (float*)out, ldo, lg);
+        else hipLaunchKernelGGL((layernorm_logits_kernel<6, 4, 8>), grid4, block, 0, st, x, ldx, w, b, eps, rows, W, (float*)out, ldo, lg);
+        REVO_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
 #define LN_LAUNCH(MC)                                                                                              \
     if (out_is_bf16)                                                                                               \
         hipLaunchKernelGGL((layernorm_kernel<MC, true>), grid, block, 0, st, x, ldx, w, b, eps, rows, W, out, ldo, lg); \

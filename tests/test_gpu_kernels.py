@@ -147,6 +147,31 @@ def test_pool_rows_equal_the_softmax_weighted_sum_and_do_not_depend_on_the_batch
         assert torch.equal(u1[0], u[b]), b
 
 
+@pytest.mark.parametrize("B,S,W,H", [(8, 577, 1024, 8), (24, 197, 768, 8), (5, 1025, 1536, 8), (3, 577, 1024, 8)])
+def test_layernorm_with_pool_logits_batch_form_equals_the_row_form(lib, dev, B, S, W, H):
+    """ln_post + the pool's logits (elementwise.hip): against torch, and the batch form (four rows per wave, >= 4096 rows)
+    against the one-row-per-wave form image by image -- the same bits for rows and logits."""
+    g = torch.Generator(device="cpu").manual_seed(B * 100 + S)
+    rows = B * S
+    x = (torch.randn(rows, W, generator=g) * 2 + 0.5).to(dev)
+    w, b = torch.randn(W, generator=g).to(dev), torch.randn(W, generator=g).to(dev)
+    qk, ck = (torch.randn(H, W, generator=g) * 0.05).to(dev), torch.randn(H, generator=g).to(dev)
+    out, lg = torch.zeros(rows, W, device=dev), torch.zeros(B, H, S, device=dev)
+    _lib.check(lib.revo_op_layernorm_logits(_lib.ptr(x), W, _lib.ptr(w), _lib.ptr(b), 1e-5, rows, W, _lib.ptr(out), W, _lib.ptr(qk),
+                                            _lib.ptr(ck), H, S, _lib.ptr(lg), _lib.current_stream()))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x.double(), (W,), w.double(), b.double(), 1e-5)
+    assert (out.double() - ref).abs().max().item() <= 2e-5
+    ref_lg = (ref @ qk.double().T + ck.double()).view(B, S, H).permute(0, 2, 1)
+    assert (lg.double() - ref_lg).abs().max().item() <= 2e-4
+    for i in (0, B - 1):
+        o1, l1 = torch.zeros(S, W, device=dev), torch.zeros(1, H, S, device=dev)
+        _lib.check(lib.revo_op_layernorm_logits(_lib.ptr(x[i * S:(i + 1) * S]), W, _lib.ptr(w), _lib.ptr(b), 1e-5, S, W, _lib.ptr(o1), W,
+                                                _lib.ptr(qk), _lib.ptr(ck), H, S, _lib.ptr(l1), _lib.current_stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(o1, out[i * S:(i + 1) * S]) and torch.equal(l1[0], lg[i]), i
+
+
 def test_layernorm_constant_row_is_bias(lib, dev):
     W = 1024
     x = torch.full((4, W), 3.25, device=dev)
