@@ -66,6 +66,26 @@ def test_tiny_vit_layer_by_layer(dev, fname, cname):
     engx.close()
 
 
+def test_band_patchify_writes_the_gather_forms_bytes(dev):
+    """u8 batches of images whose side is a multiple of 16 are patchified a band of patches per workgroup (pixel rows staged
+    in LDS); everything else one output chunk per thread.  Same patch matrix: the embedded tokens (patch GEMM + position, the
+    experiment library's tap) of one batch under both forms are equal bit for bit, and so are the embeddings."""
+    import os
+    for name, side in (("PE-Core-B16-224", 224), ("PE-Core-L14-336", 336)):
+        cfg = reverso_amd.get_config(name)
+        engx = engine.VitEngine.synthetic(cfg, seed=1, device=0, max_batch=8, experiments=True)
+        g = torch.Generator().manual_seed(side)
+        u8 = torch.randint(0, 256, (8, 3, side, side), generator=g, dtype=torch.uint8).to(dev)
+        tok_band, emb_band = engx.residual_after(u8, -2).clone(), engx.embed(u8).clone()
+        os.environ["REVO_PATCHIFY_GATHER"] = "1"
+        try:
+            tok_gather, emb_gather = engx.residual_after(u8, -2).clone(), engx.embed(u8).clone()
+        finally:
+            del os.environ["REVO_PATCHIFY_GATHER"]
+        assert torch.equal(tok_band, tok_gather) and torch.equal(emb_band, emb_gather), name
+        engx.close()
+
+
 def test_uint8_input_matches_float_preprocess(dev):
     cfg, sd, _ = make_golden.tiny_case()
     eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=8)
