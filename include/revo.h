@@ -310,6 +310,12 @@ int32_t revo_op_layernorm(const float* x, int64_t ldx, const float* w, const flo
 int32_t revo_op_layernorm_logits(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows,
                                  int32_t width, float* out, int64_t ldo, const float* qk, const float* ck, int32_t heads,
                                  int32_t seq, float* logits, void* stream);
+/* the head's fp32 linear layers (head.hip gemm_f32_skinny_kernel; M = batch rows, weights [N, K] streamed once):
+ * C = epi(A . Wt^T + bias), epi 0 = none, 1 = exact GELU, 2 = added to what C holds.  K % 16 == 0, rows 16-byte aligned.
+ * K is cut into the same sixteen ranges, summed in the same order, whatever M is: a row's result does not depend on the
+ * other rows of the call, bit for bit. */
+int32_t revo_op_linear_f32(int32_t epi, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, int32_t M,
+                           int32_t N, int32_t K, float* C, int64_t ldc, void* stream);
 /* the attention pool's weighted row sums (K10; head.hip): u[(b * heads + h) * width + c] = sum_s softmax_s(logits[b, h, :])[s] *
  * x[b * seq + s][c], all fp32; logits [batch, heads, seq].  A column's sum is taken in one fixed order whatever the batch
  * (the batch only decides how many columns a lane carries): bit-identical between a batch and its images one at a time. */

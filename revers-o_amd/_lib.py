@@ -67,6 +67,7 @@ SIGNATURES = {
     "revo_op_gemm_rope": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
     "revo_op_layernorm": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i64, _i32, _p]),
     "revo_op_layernorm_logits": (_i32, [_p, _i64, _p, _p, _f32, _i32, _i32, _p, _i64, _p, _p, _i32, _i32, _p, _p]),
+    "revo_op_linear_f32": (_i32, [_i32, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _i64, _p]),
     "revo_op_pool_rows": (_i32, [_p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "revo_op_rope": (_i32, [_p, _i64, _p, _i32, _i32, _i32, _i32, _p]),
     "revo_op_attention": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p]),

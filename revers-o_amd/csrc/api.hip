@@ -1425,6 +1425,13 @@ extern "C" int32_t revo_op_layernorm_logits(const float* x, int64_t ldx, const f
     return revo::launch_layernorm(x, ldx, w, b, eps, rows, width, out, ldo, 0, (hipStream_t)stream, &lg);
     API_END
 }
+extern "C" int32_t revo_op_linear_f32(int32_t epi, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias,
+                                      int32_t M, int32_t N, int32_t K, float* C, int64_t ldc, void* stream) {
+    API_BEGIN
+    REVO_REQUIRE(A && Wt && C && M >= 1 && N >= 1 && K >= 16 && lda >= K && ldw >= K && ldc >= N, "op_linear_f32: bad arguments");
+    return revo::launch_gemm_f32_skinny(epi, A, lda, 0, 0, Wt, ldw, bias, M, N, K, C, ldc, (hipStream_t)stream);
+    API_END
+}
 extern "C" int32_t revo_op_pool_rows(const float* x, int64_t ldx, const float* logits, int32_t batch, int32_t seq, int32_t width,
                                      int32_t heads, float* u, void* stream) {
     API_BEGIN

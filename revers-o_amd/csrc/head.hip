@@ -192,7 +192,10 @@ __global__ __launch_bounds__(SK_NW * 64) void gemm_f32_skinny_kernel(const float
     const float* wrow = Wt + (long)nr * ldw + kq * 4;
     const int kper = ((K / 16 + NW - 1) / NW) * 16;                  // k range of a wave, a multiple of 16
     const int k0 = w * kper, k1 = (k0 + kper) < K ? (k0 + kper) : K;
-    for (int m0 = 0; m0 < M; m0 += MB * 16) {
+    // (grid.y > 1: this workgroup takes the 16 rows [16 y, 16 y + 16) -- launch_skinny_f32)
+    const int rows_y = gridDim.y > 1 ? 16 : M;
+    const int m_begin = (int)blockIdx.y * rows_y, m_end = m_begin + rows_y < M ? m_begin + rows_y : M;
+    for (int m0 = m_begin; m0 < m_end; m0 += MB * 16) {
         f32x4 acc[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(SK_NW * 64) void gemm_f32_skinny_kernel(const float
         for (int e = threadIdx.x; e < MB * 16 * 16; e += NW * 64) {
             const int row = e >> 4, col = e & 15;
             const int m = m0 + row, n = n0 + col;
-            if (m < M && n < N) {
+            if (m < m_end && n < N) {
                 float t = part[0][row][col];
 #pragma unroll
                 for (int o = 1; o < NW; ++o) t += part[o][row][col];     // fixed order: deterministic
@@ -256,8 +259,17 @@ __global__ __launch_bounds__(SK_NW * 64) void gemm_f32_skinny_kernel(const float
 template <int EPI>
 static void launch_skinny_f32(const float* A, long lda, long a_group_stride, int group_cols, const float* Wt, long ldw,
                               const float* bias, int M, int N, int K, float* C, long ldc, hipStream_t st) {
-    const dim3 grid((unsigned)((N + 15) / 16));
+    dim3 grid((unsigned)((N + 15) / 16));
     // sixteen waves split K (the weights' latency chain is what costs); up to 16 rows in one pass, else 64 rows at a time
+    // -- unless 16 columns per workgroup leave most CUs without one (N = 1024: 64 workgroups, and the fp32 MFMAs of 64 CUs were
+    // the kernel's time: the pool's fc2 at batch 64 took 47 us): then a workgroup takes 16 ROWS as well, grid.y = M / 16; the
+    // weights are read once from HBM and M / 16 - 1 times from L2.  A row's K split and order do not depend on the form.
+    if (M > 16 && (N + 15) / 16 < 192) {
+        grid.y = (unsigned)((M + 15) / 16);
+        hipLaunchKernelGGL((gemm_f32_skinny_kernel<EPI, 1>), grid, dim3(SK_NW * 64), SK_NW * 16 * 17 * 4, st, A, lda, a_group_stride,
+                           group_cols, Wt, ldw, bias, M, N, K, C, ldc);
+        return;
+    }
     if (M <= 16) {
         hipLaunchKernelGGL((gemm_f32_skinny_kernel<EPI, 1>), grid, dim3(SK_NW * 64), SK_NW * 16 * 17 * 4, st, A, lda, a_group_stride,
                            group_cols, Wt, ldw, bias, M, N, K, C, ldc);

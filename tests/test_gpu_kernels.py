@@ -172,6 +172,33 @@ def test_layernorm_with_pool_logits_batch_form_equals_the_row_form(lib, dev, B, 
         assert torch.equal(o1, out[i * S:(i + 1) * S]) and torch.equal(l1[0], lg[i]), i
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 1024, 4096), (64, 4096, 1024), (50, 1024, 1024), (33, 1280, 1536), (7, 1024, 1024), (64, 1000, 1024)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_head_linear_f32_rows_do_not_depend_on_the_batch(lib, dev, M, N, K, epi):
+    """The head's fp32 linear layers (head.hip): against fp64, and a batch (64-row passes, or 16 rows per workgroup where 16
+    columns per workgroup would leave CUs idle) against its rows one at a time -- the same bits."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + epi)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.03).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    c0 = torch.randn(M, N, generator=g).to(dev)
+    c = c0.clone()
+    st = _lib.current_stream()
+    _lib.check(lib.revo_op_linear_f32(epi, _lib.ptr(a), K, _lib.ptr(w), K, _lib.ptr(bias), M, N, K, _lib.ptr(c), N, st))
+    torch.cuda.synchronize()
+    ref = a.double() @ w.double().T + bias.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 2:
+        ref = ref + c0.double()
+    assert (c.double() - ref).abs().max().item() <= 1e-4 * math.sqrt(K / 1024)
+    for r in (0, M // 2, M - 1):
+        c1 = c0[r:r + 1].clone()
+        _lib.check(lib.revo_op_linear_f32(epi, _lib.ptr(a[r:r + 1]), K, _lib.ptr(w), K, _lib.ptr(bias), 1, N, K, _lib.ptr(c1), N, st))
+        torch.cuda.synchronize()
+        assert torch.equal(c1[0], c[r]), r
+
+
 def test_layernorm_constant_row_is_bias(lib, dev):
     W = 1024
     x = torch.full((4, W), 3.25, device=dev)
