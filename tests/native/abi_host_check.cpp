@@ -161,6 +161,15 @@ int main() {
         EXPECT(revo_prof_report(big, 64) == 0 && std::strcmp(big, "{}") == 0);
     }
     EXPECT(revo_preprocess_crop_resize(nullptr, 1, 56, nullptr, nullptr) != 0);
+    // round 6's entries: argument validation before anything touches a device
+    EXPECT(revo_vit_stats(nullptr, nullptr, 0, nullptr) == -2);
+    EXPECT(revo_probe_mfma(nullptr, 0, nullptr, 1, 1, nullptr) == -2 && err_has("probe_mfma"));
+    EXPECT(revo_probe_copy(nullptr, nullptr, 16, nullptr) == -2 && err_has("probe_copy"));
+    EXPECT(revo_probe_mfma_flops(1024, 10) == (int64_t)1024 * 4 * 10 * 32 * (2ll * 16 * 16 * 32));
+    EXPECT(revo_op_pool_rows(nullptr, 0, nullptr, 1, 1, 4, 1, nullptr, nullptr) == -2 && err_has("op_pool_rows"));
+    EXPECT(revo_op_layernorm_logits(nullptr, 0, nullptr, nullptr, 1e-5f, 1, 4, nullptr, 0, nullptr, nullptr, 1, 1, nullptr, nullptr) == -2 &&
+           err_has("op_layernorm_logits"));
+    EXPECT(revo_op_linear_f32(0, nullptr, 0, nullptr, 0, nullptr, 1, 1, 16, nullptr, 0, nullptr) == -2 && err_has("op_linear_f32"));
 
     if (failures) { std::printf("%d check(s) failed\n", failures); return 1; }
     std::printf("ALL OK\n");
