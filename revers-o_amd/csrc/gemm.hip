@@ -1587,9 +1587,14 @@ void gemm_set_debug(int d) { g_dbg = d; }
 static int g_qtail = 1;        // timing experiments only: 0 = the leftover rows behind the queued-stores kernel as a launch of their own
 static int g_qstores = 1;      // timing experiments only: 0 = gemm256p_kernel for every epilogue
 void gemm_set_qstores(int on) { g_qstores = on & 31; g_qtail = !(on & 32); }      // (+ 32: no fused leftover rows)
+#ifdef REVO_EXPERIMENTS
+constexpr bool G256Q_ROPE_BUILT = true;       // the RoPE form of the queued-stores kernel: measured, not adopted; experiment build only
+#else
+constexpr bool G256Q_ROPE_BUILT = false;
+#endif
 template <int EPI>
 static bool use_256q(const GemmArgs& a) {
-    if (!(EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE) || !g_qstores) return false;
+    if (!(EPI == EPI_BF16 || EPI == EPI_BF16_GELU || (EPI == EPI_BF16_ROPE && G256Q_ROPE_BUILT)) || !g_qstores) return false;
     if (a.N % 256 || a.K < 128 || (a.ldc & 7) || 256l * a.ldc * 2 >= (1l << 31)) return false;
     if (EPI == EPI_BF16_ROPE && (a.rope_cols % 64 || (long)a.rope_S * (a.rope_hd >> 1) * 8 >= (1l << 31))) return false;
     // RoPE: measured, not adopted (profiles/r06_gemm_queued_stores.json): the rotation's 32 table loads per lane must be
@@ -1601,7 +1606,7 @@ static bool use_256q(const GemmArgs& a) {
 }
 template <int EPI>
 static int launch_256q(const GemmArgs& a, hipStream_t st) {
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_ROPE) {
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || (EPI == EPI_BF16_ROPE && G256Q_ROPE_BUILT)) {
         GemmArgs b = a;
 #ifdef REVO_EXPERIMENTS
         b.stamps = g_stamps; b.stamp_items = g_stamp_items;
