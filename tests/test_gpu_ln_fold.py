@@ -282,7 +282,15 @@ def test_forward_with_the_fold_equals_the_layernorm_kernel_form(dev):
     cfg, sd, u8 = mg.batch_case()
     eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=64, experiments=True)
     img = u8.to(dev)
+    eng.ln_fold_stats(reset=True)
     e_fold = eng.embed(img)
+    # the fold's run-time telemetry (include/revo.h revo_vit_stats): every row of every consuming GEMM of the forward is counted
+    # once -- ln_1 of blocks 1..23 (qkv: all 36 928 rows are tile rows) and ln_2 of all 24 (fc1: the 64 rows its tiles leave over
+    # are finished by the launch's fused tail, which is not sampled) -- and a random-init tower has no row beyond 8 sigma
+    st = eng.ln_fold_stats(reset=True)
+    assert st["rows"] == 23 * 64 * 577 + 24 * (64 * 577 - 64), st
+    assert st["rows_above_ratio"] == 0 and st["rows_above_4x_ratio"] == 0 and st["ratio"] == 8.0, st
+    assert eng.ln_fold_stats()["rows"] == 0
     x_fold = eng.residual_after(img[:2], 24)            # (two images: the LayerNorm-kernel path either way)
     assert exp.revo_debug_stream_in_planes(eng._h, 64) == 1 and exp.revo_debug_stream_in_planes(eng._h, 2) == 0
     _lib.check(exp.revo_op_set_ln_fold(0))
@@ -325,7 +333,11 @@ def test_forward_with_the_fold_equals_the_layernorm_kernel_form(dev):
     cfg, sd, u8o, big = mg.outlier_case()
     eng = engine.VitEngine(cfg, {k: v.to(dev) for k, v in sd.items()}, device=0, max_batch=64, experiments=True)
     img = u8o.to(dev).repeat(16, 1, 1, 1)                 # 64 images: the folded form
+    eng.ln_fold_stats(reset=True)
     e_fold = eng.embed(img)
+    st = eng.ln_fold_stats()
+    print("outlier tower, rows beyond the telemetry's ratios:", st)
+    assert st["rows"] > 0 and st["rows_above_4x_ratio"] <= st["rows_above_ratio"] <= st["rows"]
     _lib.check(exp.revo_op_set_ln_fold(0))
     try:
         e_kern = eng.embed(img)
