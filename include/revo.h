@@ -74,8 +74,8 @@ int32_t revo_vit_seq_len(const revo_vit* vit);
  * (tests/test_gpu_ln_fold.py::test_fold_error_against_the_row_offset records the curve and holds it to a bound).  The
  * reference normalises in the activations' precision before the matmul (oracle/pe_vit.py:146-155 <- core_system.py:341), so on
  * a trained checkpoint this is the number to look at first if embeddings drift: out4 = { rows the consuming GEMMs merged
- * statistics for since the last reset (each row of each folded LayerNorm of each forward, counted once; rows that the
- * leftover-row kernels take are not sampled), of those: rows with |mean| * rstd > out4[3], rows with |mean| * rstd > 4 *
+ * statistics for since the last reset (each row of each folded LayerNorm of each forward, counted once; rows that a
+ * separate leftover-row kernel takes -- none at the headline shapes -- are not sampled), of those: rows with |mean| * rstd > out4[3], rows with |mean| * rstd > 4 *
  * out4[3], the ratio that counts as large (8) }.  Synchronises `stream`; reset != 0 clears the counters. */
 int32_t revo_vit_stats(revo_vit* vit, double* out4, int32_t reset, void* stream);
 

@@ -990,6 +990,14 @@ __device__ __forceinline__ void gemm256q_tail(char* smem, int wave) {
                     if (lnc) {
                         float rstd, mr;
                         lnf_merge(q.lnc_stats + grow * q.lnc_parts, q.lnc_parts, q.lnc_eps, rstd, mr);
+                        if (q.lnc_tele && strip == 0 && cq == 0) {        // the fold's telemetry (revo_vit_stats): these rows once, by strip 0
+                            unsigned long long* tp = q.lnc_tele;
+                            asm volatile("" : "+v"(tp));
+                            const float am = __builtin_fabsf(mr);
+                            atomicAdd(tp, 1ull);
+                            if (am > LNC_TELE_RATIO) atomicAdd(tp + 1, 1ull);
+                            if (am > 4.0f * LNC_TELE_RATIO) atomicAdd(tp + 2, 1ull);
+                        }
                         const f32x4 c = *(const f32x4*)(q.lnc_c + col);
                         v = v * rstd + (c * mr + b4);                     // rstd (acc - mean c) + b', the tile epilogue's operation order
                     } else {
